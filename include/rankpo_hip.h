@@ -1,0 +1,155 @@
+/*
+ * rankpo_hip.h -- C ABI of librankpo_hip.so: the MI355X (gfx950) scoring hot path of a
+ * contrastive / RankPO embedding trainer.
+ *
+ * The reference (yflyzhang/RankPO) is pure Python and has no FFI; each entry point below replaces the
+ * stock-PyTorch op sequence at the cited reference lines.  Plain device pointers + sizes + a HIP stream;
+ * no torch types.  Every call is asynchronous on `stream`, allocates nothing, never synchronises with
+ * the host, never throws and never exits: it returns RPO_OK or a negative rpo_status.  All buffers are
+ * owned by the caller.  The library keeps no global mutable state, so forward may be called from the
+ * Python main thread and backward from PyTorch's autograd thread concurrently on different streams.
+ *
+ * Embedding matrices are row-major [rows, d] with a contiguous inner dimension; dtype selects the
+ * storage type of embeddings / hidden states / scores (f32 or bf16; accumulation is always f32).
+ */
+#ifndef RANKPO_HIP_H
+#define RANKPO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rpo_stream_t; /* hipStream_t */
+
+typedef enum {
+    RPO_OK = 0,
+    RPO_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad enum */
+    RPO_ERR_UNSUPPORTED = -2,   /* shape / dtype / alignment this build does not handle */
+    RPO_ERR_WORKSPACE = -3,     /* workspace too small (see *_workspace_bytes) */
+    RPO_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after the launch */
+} rpo_status;
+
+typedef enum { RPO_DT_F32 = 0, RPO_DT_BF16 = 1 } rpo_dtype;
+typedef enum { RPO_POOL_LAST = 0, RPO_POOL_CLS = 1 } rpo_pool_mode;
+/* INBATCH: scores [Q,P], target_i = i * (P / Q)  (modeling.py:292-302)
+ * FIRST:   scores [Q,G] with G = P / Q, row i scored against p rows i*G .. i*G+G-1, target 0 (305-311) */
+typedef enum { RPO_TARGET_INBATCH = 0, RPO_TARGET_FIRST = 1 } rpo_target_mode;
+typedef enum { RPO_LOSS_SIGMOID = 0, RPO_LOSS_HINGE = 1 } rpo_loss_type;
+
+int rpo_version(void);
+const char* rpo_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * (1) pooling + L2 normalisation.
+ * Replaces modeling.py:224-236 (== rankpo_trainer.py:409-417, modeling.py:523-534):
+ *   idx_n = (argmin_l mask[n,l] - 1) mod L   (first index of the row minimum; RPO_POOL_LAST)
+ *        or 0                                  (RPO_POOL_CLS, modeling.py:231-232)
+ *   x_n = h[n, idx_n, :];  out_n = normalize ? x_n / max(||x_n||_2, eps) : x_n
+ * h: [N, L, d] with element strides (h_stride_n, h_stride_l, 1).  mask: int64 [N, L] contiguous
+ * (may be NULL for RPO_POOL_CLS).  Saved for backward: idx_out int32 [N], norm_out f32 [N] (= ||x_n||).
+ * --------------------------------------------------------------------------------------------- */
+int rpo_pool_normalize_fwd(const void* h, int64_t h_stride_n, int64_t h_stride_l, const int64_t* mask,
+                           int64_t N, int64_t L, int64_t d, int dtype, int pool_mode, int normalize,
+                           float eps, void* out, int32_t* idx_out, float* norm_out, rpo_stream_t stream);
+
+/* Backward of (1) (autograd of index-select + F.normalize).  grad_out, out: [N, d].
+ *   dx_n = normalize ? (norm_n >= eps ? (g_n - out_n <out_n, g_n>) / norm_n : g_n / eps) : g_n
+ * If dh != NULL the dense gradient [N, L, d] (contiguous) is written IN FULL: zeros everywhere except
+ * row idx_n of sample n (one pass; replaces zeros() + index_put_).  If drow != NULL, dx is also
+ * written as [N, d] (for callers that scatter themselves).  At least one of them must be non-NULL. */
+int rpo_pool_normalize_bwd(const void* grad_out, const void* out, const int32_t* idx, const float* norm,
+                           int64_t N, int64_t L, int64_t d, int dtype, int normalize, float eps,
+                           void* dh, void* drow, rpo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (2) similarity + temperature + InfoNCE cross-entropy, fused.
+ * Replaces modeling.py:292-314 (training) and :321 (eval: pass lse_out = loss_out = NULL, temperature 1).
+ *   INBATCH: scores[i,j] = <q_i, p_j> / T                      [Q, P]
+ *   FIRST:   scores[i,g] = <q_i, p_{iG+g}> / T                  [Q, G]
+ *   lse_i = log sum_j exp(scores[i,j]);  loss = mean_i (lse_i - scores[i, target_i])
+ * scores_out has the storage dtype; with bf16 storage the rounding points are the reference's
+ * (dot -> bf16, / T -> bf16) and lse / loss are computed in f32 from the stored (rounded) scores.
+ * lse_out f32 [Q], loss_out f32 [1].  workspace: rpo_infonce_workspace_bytes(), 256-byte aligned.
+ * --------------------------------------------------------------------------------------------- */
+size_t rpo_infonce_workspace_bytes(int64_t Q, int64_t P, int64_t d, int dtype);
+
+int rpo_infonce_fwd(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int dtype,
+                    float temperature, int target_mode, void* scores_out, float* lse_out, float* loss_out,
+                    void* workspace, size_t workspace_bytes, rpo_stream_t stream);
+
+/* Backward of (2): gradients of grad_loss[0] * loss with respect to the caller's OWN rows only
+ * (q rows [q_row0, q_row0 + q_rows), p rows [p_row0, p_row0 + p_rows)): with cross-device negatives
+ * the other rows of the gathered matrices are constants (modeling.py:374-377), so nothing else is
+ * needed and no backward collective exists.  grad_loss: device f32 scalar.  dq_out [q_rows, d],
+ * dp_out [p_rows, d] in the storage dtype.  Either output may be NULL (then it is skipped). */
+int rpo_infonce_bwd(const void* q, const void* p, const void* scores, const float* lse,
+                    const float* grad_loss, int64_t Q, int64_t P, int64_t d, int dtype, float temperature,
+                    int target_mode, int64_t q_row0, int64_t q_rows, int64_t p_row0, int64_t p_rows,
+                    void* dq_out, void* dp_out, void* workspace, size_t workspace_bytes, rpo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (3) RankPO paired scoring + loss + metrics.
+ * Replaces rankpo_trainer.py:436-443 (scores), 545-566 (rankpo_loss), 482-520 (loss mix + metrics).
+ *   scores[b,g] = <q_b, p_{2b+g}>   (g = 0 chosen, 1 rejected; unscaled)
+ *   adv = (c - r) - (reference_free ? 0 : ref_c - ref_r);  logits = adv / T - gamma_beta_ratio
+ *   sigmoid: -logsig(beta z)(1 - eps) - logsig(-beta z) eps ;  hinge: relu(1 - beta z)
+ *   loss = rankpo_weight * mean(losses) [if > 0] + sft_weight * CE(scores / T, 0) [if > 0]
+ * ref_chosen / ref_rejected: f32 [B] or NULL (no reference model -> 0).  Outputs (all f32):
+ * scores_out [B,2], losses_out [B], loss_out [1], metrics_out [RPO_NUM_METRICS], dscores_out [B,2]
+ * (= d loss / d scores, consumed by rpo_rankpo_bwd).
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+    float beta;
+    float temperature;
+    float gamma_beta_ratio;
+    float label_smoothing;
+    float rankpo_weight;
+    float sft_weight;
+    int32_t loss_type;      /* rpo_loss_type */
+    int32_t reference_free; /* 0 / 1 */
+} rpo_rankpo_params;
+
+enum {
+    RPO_METRIC_RANKPO_LOSS = 0,      /* valid iff rankpo_weight > 0 */
+    RPO_METRIC_SFT_LOSS = 1,         /* valid iff sft_weight > 0 */
+    RPO_METRIC_REWARDS_CHOSEN = 2,   /* mean beta (c - ref_c) */
+    RPO_METRIC_REWARDS_REJECTED = 3,
+    RPO_METRIC_REWARDS_ACCURACIES = 4,
+    RPO_METRIC_REWARDS_MARGINS = 5,
+    RPO_METRIC_SCORES_CHOSEN = 6,
+    RPO_METRIC_SCORES_REJECTED = 7,
+    RPO_METRIC_SCORES_MARGINS = 8,
+    RPO_NUM_METRICS = 9
+};
+
+int rpo_rankpo_fwd(const void* q, const void* p, const float* ref_chosen, const float* ref_rejected,
+                   int64_t B, int64_t d, int dtype, const rpo_rankpo_params* params, float* scores_out,
+                   float* losses_out, float* loss_out, float* metrics_out, float* dscores_out,
+                   rpo_stream_t stream);
+
+/* dq_b = gl (ds[b,0] p_{2b} + ds[b,1] p_{2b+1});  dp_{2b+g} = gl ds[b,g] q_b;  gl = grad_loss[0]. */
+int rpo_rankpo_bwd(const void* q, const void* p, const float* dscores, const float* grad_loss, int64_t B,
+                   int64_t d, int dtype, void* dq_out, void* dp_out, rpo_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * (4) "next" row f2: flat-buffer AdamW step (replaces the DeepSpeed ZeRO-1 bf16 optimizer step the reference
+ * scripts configure: configs/ds_zero1_config_llama.json, scripts/train/run_contrastive.sh:33-40).
+ * torch.optim.AdamW semantics on n elements (n % 4 == 0, 16-byte aligned buffers):
+ *   g = grad * (grad_scale ? grad_scale[0] : 1);  w *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2
+ *   w -= (lr / bias_corr1) * m / (sqrt(v) / sqrt(bias_corr2) + eps)
+ * dtype = storage type of param and grad.  bf16 params need an f32 `master` copy (updated, then rounded into
+ * param); for f32 params master may be NULL.  grad_scale: device f32 scalar or NULL (clip / 1/GAS factor).
+ * rpo_sumsq_partial: partial_out[b] = sum of squares of block b's share of x (for the global grad norm).
+ * --------------------------------------------------------------------------------------------- */
+int rpo_adamw_step(void* param, float* master, const void* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                   int dtype, float lr, float beta1, float beta2, float eps, float weight_decay,
+                   float bias_corr1, float bias_corr2, const float* grad_scale, rpo_stream_t stream);
+int rpo_sumsq_partial(const void* x, int64_t n, int dtype, float* partial_out, int nblocks, rpo_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RANKPO_HIP_H */

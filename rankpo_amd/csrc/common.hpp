@@ -1,0 +1,103 @@
+// Shared device helpers for librankpo_hip (gfx950 / CDNA4 only: 64-wide waves, MFMA, 160 KiB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/rankpo_hip.h"
+
+#define RPO_WAVE 64
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef __attribute__((ext_vector_type(8))) short short8_t;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float float4_t;   // 16x16 MFMA accumulator fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int uint4_t;
+
+// ---- bf16 <-> f32 ------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }
+
+// Round to nearest even; NaN stays NaN (plain cast -> v_cvt_pk_bf16_f32 on gfx950).
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    __bf16 h = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ float round_to_bf16(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int kVec = 4;  // elements per 16-byte access
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float round(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int kVec = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    __device__ static __forceinline__ float round(float v) { return round_to_bf16(v); }
+};
+
+// 16-byte vector of T held as f32 in registers
+template <typename T> struct Vec16;
+template <> struct Vec16<float> {
+    float v[4];
+    __device__ __forceinline__ void load(const float* p) {
+        float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ __forceinline__ void store(float* p) const {
+        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    }
+};
+template <> struct Vec16<bf16_t> {
+    float v[8];
+    __device__ __forceinline__ void load(const bf16_t* p) {
+        uint4 t = *reinterpret_cast<const uint4*>(p);
+        unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void store(bf16_t* p) const {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            w[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+};
+
+__device__ __forceinline__ bool rpo_aligned16_dev(const void* p) {
+    return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
+}
+
+// ---- wave / block reductions (64-wide waves) -----------------------------------------------------
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o, 64));
+    return x;
+}
+// Sum over a block of NW waves; every thread gets the total.  `scratch` holds >= NW floats.
+// Fixed summation order -> bitwise reproducible.
+template <int NW>
+__device__ __forceinline__ float block_sum(float x, float* scratch) {
+    x = wave_sum(x);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) scratch[w] = x;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) t += scratch[i];
+    return t;
+}
+
+// ---- host-side helpers -----------------------------------------------------------------------------
+static inline int rpo_launch_status() { return hipGetLastError() == hipSuccess ? RPO_OK : RPO_ERR_LAUNCH; }
+static inline bool rpo_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int64_t rpo_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,776 @@
+// (2) similarity GEMM + temperature + InfoNCE cross-entropy, fused.  Reference: modeling.py:292-314, :321.
+//
+// Forward kernels (all write the temperature-scaled scores in the storage dtype and, per score row and
+// per block of passage columns, an online-softmax partial (max, sum exp)):
+//   sim_tile_kernel    Q > 64: 128(p) x 128(q) x 128-byte MFMA tile, LDS double-buffered, filled by
+//                      16-byte global_load_lds with an XOR-swizzled source (conflict-free ds_read_b128),
+//                      XCD-aware block order.  bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_16x16x4_f32.
+//   sim_skinny_kernel  Q <= 64 (every shape the reference scripts produce: 8x48 ... 64x384): 16 passage
+//                      rows per block, fragments loaded straight into registers, K split over the 4 waves.
+//   sim_rowwise_kernel any d / alignment (scalar loads), one block per score row.
+//   ce_finalize_kernel combines the partials -> lse[Q], loss (fixed summation order; a ticket counter with
+//                      agent-scope release/acquire picks the block that adds up the per-block sums).
+// The MFMA computes scores^T tiles (A = passages, B = queries) so that each lane ends up with 4 consecutive
+// passage columns of ONE query row: 8/16-byte score stores and an almost lane-local row reduction.
+//
+// Backward: dS = grad * (softmax(S) - onehot) / (Q T) is recomputed from the stored scores and lse;
+//   dq = dS p (own q rows), dp = dS^T q (own p rows).
+#include "common.hpp"
+
+int rpo_launch_grouped_dots(const void* q, const void* p, int64_t B, int64_t G, int64_t d, int dtype, float* out,
+                            hipStream_t st);
+
+namespace {
+
+#define RPO_NEG_INF (-__builtin_huge_valf())
+
+// ------------------------------------------------------------------------------------------------
+// MFMA fragment op per storage type.  A fragment is 16 bytes per lane; lane group g = lane>>4 holds the
+// 16-byte chunk g of a 64-byte K segment of row (lane & 15).
+//   bf16: chunk g = k 8g..8g+7  -> exactly the v_mfma_f32_16x16x32_bf16 operand layout.
+//   f32 : chunk g = k 4g..4g+3  -> four v_mfma_f32_16x16x4_f32, MFMA t consuming element t of every
+//         lane's chunk (k = 4g + t on lane group g, for A and B alike), i.e. a permuted but complete K sum.
+// ------------------------------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    typedef short8_t Frag;
+    __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, float4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ Frag zero() { return Frag{0, 0, 0, 0, 0, 0, 0, 0}; }
+};
+template <> struct Mma<float> {
+    typedef float4_t Frag;
+    __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, float4_t& c) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ Frag zero() { return Frag{0.f, 0.f, 0.f, 0.f}; }
+};
+
+// scores = round(round(dot) / T) in the storage dtype (the reference's rounding points for bf16;
+// identity roundings for f32).  T == 1 (eval branch) skips the division.
+template <typename T>
+__device__ __forceinline__ float finish_score(float acc, float temperature, bool scale) {
+    float x = Elem<T>::round(acc);
+    if (scale) x = Elem<T>::round(x / temperature);
+    return x;
+}
+
+__device__ __forceinline__ void softmax_merge(float& m, float& l, float om, float ol) {
+    const float M = fmaxf(m, om);
+    const float a = (m == RPO_NEG_INF) ? 0.f : l * __expf(m - M);
+    const float b = (om == RPO_NEG_INF) ? 0.f : ol * __expf(om - M);
+    m = M;
+    l = a + b;
+}
+
+// Store 4 consecutive scores of one row.
+template <typename T>
+__device__ __forceinline__ void store_scores4(T* row_ptr, int64_t col, int64_t ncols, const float v[4], bool vec_ok) {
+    if (vec_ok && col + 3 < ncols) {
+        if constexpr (sizeof(T) == 2) {
+            uint2 w;
+            w.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *reinterpret_cast<uint2*>(row_ptr + col) = w;
+        } else {
+            *reinterpret_cast<float4*>(row_ptr + col) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (col + j < ncols) Elem<T>::st(row_ptr + col + j, v[j]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Big tile kernel
+// ------------------------------------------------------------------------------------------------
+constexpr int kTileP = 128, kTileQ = 128, kTileRowBytes = 128;
+constexpr int kTileThreads = 256;
+constexpr int kTileBufBytes = kTileP * kTileRowBytes;          // 16 KiB per operand per buffer
+constexpr int kTileLdsBytes = 4 * kTileBufBytes;               // A0 A1 B0 B1 = 64 KiB
+
+template <typename T>
+__global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
+    const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
+    int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef typename Mma<T>::Frag Frag;
+    constexpr int KE = kTileRowBytes / (int)sizeof(T);   // K elements per tile row (64 bf16 / 32 f32)
+    constexpr int CE = 16 / (int)sizeof(T);              // elements per 16-byte chunk
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 1, wq = wave & 1;
+    const int g = lane >> 4;
+
+    // XCD-aware order: blocks b and b+8 share an XCD (speed only); give each XCD a contiguous run of
+    // tiles, walked in groups of 8 passage tiles so that co-resident blocks share q / p panels in L2.
+    const int nwg = nPt * nQt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    constexpr int GROUP = 8;
+    const int width = GROUP * nQt;
+    const int group_id = wg / width;
+    const int first_p = group_id * GROUP;
+    const int gsz = min(nPt - first_p, GROUP);
+    const int pt = first_p + (wg % width) % gsz;
+    const int qt = (wg % width) / gsz;
+    const int64_t p0 = (int64_t)pt * kTileP, q0 = (int64_t)qt * kTileQ;
+
+    // staging: instruction i of wave w fills tile rows (4i + w)*8 .. +7 (1 KiB, lane-linear in LDS);
+    // lane l carries row (l >> 3), physical chunk (l & 7) = logical chunk (l & 7) ^ (row & 7).
+    const int srow = lane >> 3;
+    const int lchunk = (lane & 7) ^ srow;
+    const T* a_src[4];
+    const T* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (4 * i + wave) * 8 + srow;
+        const int64_t pr = min(p0 + r, P - 1), qr = min(q0 + r, Q - 1);   // clamp: edge rows are masked later
+        a_src[i] = p + pr * d + lchunk * CE;
+        b_src[i] = q + qr * d + lchunk * CE;
+    }
+    auto stage = [&](int t, int buf) {
+        const int64_t k0 = (int64_t)t * KE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            char* a_dst = smem + buf * kTileBufBytes + (4 * i + wave) * 1024;
+            char* b_dst = smem + (2 + buf) * kTileBufBytes + (4 * i + wave) * 1024;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)a_dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
+                                             (__attribute__((address_space(3))) void*)b_dst, 16, 0, 0);
+        }
+    };
+
+    float4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(d / KE);
+    const int frow = lane & 15;
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        if (t + 1 < nk) stage(t + 1, cur ^ 1);
+        const char* Ab = smem + cur * kTileBufBytes + (wp * 64 + frow) * kTileRowBytes;
+        const char* Bb = smem + (2 + cur) * kTileBufBytes + (wq * 64 + frow) * kTileRowBytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int coff = (((ks * 4 + g) ^ (lane & 7)) << 4);
+            Frag a[4], b[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const Frag*>(Ab + m * 16 * kTileRowBytes + coff);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const Frag*>(Bb + n * 16 * kTileRowBytes + coff);
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 4; ++n) Mma<T>::mma(a[m], b[n], acc[m][n]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue: acc[m][n][j] = <p_{pbase + 16m + 4g + j}, q_{qbase + 16n + (lane&15)}>
+    const int64_t pbase = p0 + wp * 64 + g * 4;
+    const int64_t qbase = q0 + wq * 64 + frow;
+    const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
+    float2* s_stat = reinterpret_cast<float2*>(smem);   // [wq][64] from the wp == 1 waves (LDS is free now)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int64_t qi = qbase + 16 * n;
+        const bool qv = qi < Q;
+        float mx = RPO_NEG_INF;
+        float v[4][4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[m][j] = finish_score<T>(acc[m][n][j], temperature, scale);
+                if (pbase + 16 * m + j < P) mx = fmaxf(mx, v[m][j]);
+            }
+            if (qv) store_scores4<T>(scores + qi * P, pbase + 16 * m, P, v[m], vec_ok);
+        }
+        if (do_stats) {
+            float sum = 0.f;
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (pbase + 16 * m + j < P) sum += __expf(v[m][j] - mx);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
+                softmax_merge(mx, sum, om, ol);
+            }
+            if (wp == 1 && g == 0) s_stat[wq * 64 + 16 * n + frow] = make_float2(mx, sum);
+            acc[0][n][0] = mx;   // keep for the cross-wave merge below
+            acc[0][n][1] = sum;
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (wp == 0 && g == 0) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int64_t qi = qbase + 16 * n;
+                float mx = acc[0][n][0], sum = acc[0][n][1];
+                const float2 o = s_stat[wq * 64 + 16 * n + frow];
+                softmax_merge(mx, sum, o.x, o.y);
+                if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Skinny kernel: Q <= 16 * NQ <= 64.  grid = ceil(P / 16).  Wave w accumulates K segments w, w+4, ...
+// ------------------------------------------------------------------------------------------------
+constexpr int kSkinnyThreads = 256;
+
+template <typename T, int NQ>
+__global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
+    const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
+    int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial) {
+    typedef typename Mma<T>::Frag Frag;
+    constexpr int CE = 16 / (int)sizeof(T);   // elements per chunk
+    constexpr int SE = 4 * CE;                // elements per 64-byte K segment
+    __shared__ float4_t s_acc[3][NQ][64];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, frow = lane & 15;
+    const int64_t p0 = (int64_t)blockIdx.x * 16;
+    const int64_t pr = p0 + frow;
+    const bool pv = pr < P;
+    const T* a_row = p + (pv ? pr : 0) * d + g * CE;
+    const T* b_row[NQ];
+    bool bv[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+        const int64_t qr = 16 * n + frow;
+        bv[n] = qr < Q;
+        b_row[n] = q + (bv[n] ? qr : 0) * d + g * CE;
+    }
+    float4_t acc[NQ];
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) acc[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const int64_t nseg = (d + SE - 1) / SE;
+    for (int64_t s = wave; s < nseg; s += 4) {
+        const int64_t k = s * SE;
+        const bool kv = k + g * CE < d;       // d % CE == 0 is guaranteed by the host
+        Frag a = Mma<T>::zero();
+        if (pv && kv) a = *reinterpret_cast<const Frag*>(a_row + k);
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) {
+            Frag b = Mma<T>::zero();
+            if (bv[n] && kv) b = *reinterpret_cast<const Frag*>(b_row[n] + k);
+            Mma<T>::mma(a, b, acc[n]);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int n = 0; n < NQ; ++n) s_acc[wave - 1][n][lane] = acc[n];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int64_t pbase = p0 + g * 4;
+    const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
+#pragma unroll
+    for (int n = 0; n < NQ; ++n) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {   // fixed order: wave 0 + 1 + 2 + 3
+            const float4_t o = s_acc[w][n][lane];
+            acc[n] += o;
+        }
+        const int64_t qi = 16 * n + frow;
+        float v[4];
+        float mx = RPO_NEG_INF;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            v[j] = finish_score<T>(acc[n][j], temperature, scale);
+            if (pbase + j < P) mx = fmaxf(mx, v[j]);
+        }
+        if (qi < Q) store_scores4<T>(scores + qi * P, pbase, P, v, vec_ok);
+        if (do_stats) {
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (pbase + j < P) sum += __expf(v[j] - mx);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
+                softmax_merge(mx, sum, om, ol);
+            }
+            if (g == 0 && qi < Q) partial[(int64_t)blockIdx.x * Q + qi] = make_float2(mx, sum);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-wise kernel: any d, any alignment.  grid = Q, 4 waves stride over the passages.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void sim_rowwise_kernel(const T* __restrict__ q, const T* __restrict__ p,
+                                                           int64_t Q, int64_t P, int64_t d, float temperature,
+                                                           int scale, int do_stats, T* __restrict__ scores,
+                                                           float2* __restrict__ partial) {
+    __shared__ float2 s_part[4];
+    const int64_t i = blockIdx.x;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const T* qi = q + i * d;
+    float mx = RPO_NEG_INF, sum = 0.f;
+    for (int64_t j = wave; j < P; j += 4) {
+        const T* pj = p + j * d;
+        float a = 0.f;
+        for (int64_t c = lane; c < d; c += 64) a = fmaf(Elem<T>::ld(qi + c), Elem<T>::ld(pj + c), a);
+        a = wave_sum(a);
+        const float v = finish_score<T>(a, temperature, scale);
+        if (lane == 0) Elem<T>::st(scores + i * P + j, v);
+        softmax_merge(mx, sum, v, 1.0f);
+    }
+    if (!do_stats) return;
+    if (lane == 0) s_part[wave] = make_float2(mx, sum);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float m = s_part[0].x, l = s_part[0].y;
+        for (int w = 1; w < 4; ++w) softmax_merge(m, l, s_part[w].x, s_part[w].y);
+        partial[i] = make_float2(m, l);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CE finalize: thread per score row.  partial is [nPb][Q].  loss = mean_i (lse_i - S[i, i * group]).
+// ------------------------------------------------------------------------------------------------
+constexpr int kFinThreads = 256;
+
+template <typename T>
+__global__ __launch_bounds__(kFinThreads) void ce_finalize_kernel(const float2* __restrict__ partial,
+                                                                   const T* __restrict__ scores, int64_t Q,
+                                                                   int64_t P, int nPb, int64_t group,
+                                                                   float* __restrict__ lse_out,
+                                                                   float* __restrict__ loss_out,
+                                                                   float* __restrict__ blocksum,
+                                                                   unsigned* __restrict__ ticket) {
+    __shared__ float s_red[kFinThreads / 64];
+    __shared__ int s_last;
+    const int64_t i = (int64_t)blockIdx.x * kFinThreads + threadIdx.x;
+    float rowloss = 0.f;
+    if (i < Q) {
+        float m = RPO_NEG_INF, l = 0.f;
+        for (int b = 0; b < nPb; ++b) {
+            const float2 o = partial[(int64_t)b * Q + i];
+            softmax_merge(m, l, o.x, o.y);
+        }
+        const float lse = m + logf(l);
+        lse_out[i] = lse;
+        rowloss = lse - Elem<T>::ld(scores + i * P + i * group);
+    }
+    const float bs = block_sum<kFinThreads / 64>(rowloss, s_red);
+    if (gridDim.x == 1) {
+        if (threadIdx.x == 0) loss_out[0] = bs / (float)Q;
+        return;
+    }
+    // several blocks: publish the block sum, take a ticket; the last arriver adds them up in index order.
+    if (threadIdx.x == 0) {
+        blocksum[blockIdx.x] = bs;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1);
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            float tot = 0.f;
+            for (unsigned b = 0; b < gridDim.x; ++b)
+                tot += __hip_atomic_load(blocksum + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            loss_out[0] = tot / (float)Q;
+        }
+    }
+}
+
+// RPO_TARGET_FIRST: raw [B, G] dots -> scores, lse, loss.  One block, thread per row.
+template <typename T>
+__global__ __launch_bounds__(kFinThreads) void first_finalize_kernel(const float* __restrict__ raw, int64_t B,
+                                                                      int64_t G, float temperature, int scale,
+                                                                      T* __restrict__ scores,
+                                                                      float* __restrict__ lse_out,
+                                                                      float* __restrict__ loss_out) {
+    __shared__ float s_red[kFinThreads / 64];
+    float rowloss = 0.f;
+    for (int64_t b = threadIdx.x; b < B; b += kFinThreads) {
+        float m = RPO_NEG_INF, l = 0.f, s0 = 0.f;
+        for (int64_t gi = 0; gi < G; ++gi) {
+            const float v = finish_score<T>(raw[b * G + gi], temperature, scale);
+            Elem<T>::st(scores + b * G + gi, v);
+            if (gi == 0) s0 = v;
+            softmax_merge(m, l, v, 1.0f);
+        }
+        if (lse_out) {
+            const float lse = m + logf(l);
+            lse_out[b] = lse;
+            rowloss += lse - s0;
+        }
+    }
+    if (loss_out) {
+        const float tot = block_sum<kFinThreads / 64>(rowloss, s_red);
+        if (threadIdx.x == 0) loss_out[0] = tot / (float)B;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward, VALU form (one wave per output row x column chunk).
+//   blocks [0, q_rows*nchunk): dq row;  blocks [q_rows*nchunk, +p_rows*nchunk): dp row.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64) void infonce_bwd_valu_kernel(
+    const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ scores, const float* __restrict__ lse,
+    const float* __restrict__ grad_loss, int64_t Q, int64_t P, int64_t d, float temperature, int64_t group,
+    int64_t q_row0, int64_t q_rows, int64_t p_row0, int64_t p_rows, T* __restrict__ dq, T* __restrict__ dp,
+    int nchunk) {
+    constexpr int V = Elem<T>::kVec;
+    const int lane = threadIdx.x;
+    const float coef = grad_loss[0] / ((float)Q * temperature);
+    int64_t b = blockIdx.x;
+    const int64_t ndq = dq ? q_rows * nchunk : 0;
+    const bool is_dq = b < ndq;
+    if (!is_dq) b -= ndq;
+    const int64_t row = b / nchunk;
+    const int chunk = (int)(b % nchunk);
+    float accv[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) accv[k] = 0.f;
+    const int64_t c0 = ((int64_t)chunk * 64 + lane) * V;
+    if (is_dq) {
+        const int64_t gi = q_row0 + row;
+        const float lse_i = lse[gi];
+        const int64_t tgt = gi * group;
+        for (int64_t j0 = 0; j0 < P; j0 += 64) {
+            const int64_t j = j0 + lane;
+            float w = 0.f;
+            if (j < P) w = coef * (__expf(Elem<T>::ld(scores + gi * P + j) - lse_i) - (j == tgt ? 1.f : 0.f));
+            const int jn = (int)min((int64_t)64, P - j0);
+            for (int jj = 0; jj < jn; ++jj) {
+                const float wj = __shfl(w, jj, 64);     // uniform trip count: every lane takes part
+                if (c0 < d) {
+                    Vec16<T> x;
+                    x.load(p + (j0 + jj) * d + c0);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) accv[k] = fmaf(wj, x.v[k], accv[k]);
+                }
+            }
+        }
+        if (c0 < d) {
+            Vec16<T> o;
+#pragma unroll
+            for (int k = 0; k < V; ++k) o.v[k] = accv[k];
+            o.store(dq + row * d + c0);
+        }
+    } else {
+        const int64_t gj = p_row0 + row;
+        for (int64_t i0 = 0; i0 < Q; i0 += 64) {
+            const int64_t i = i0 + lane;
+            float w = 0.f;
+            if (i < Q) w = coef * (__expf(Elem<T>::ld(scores + i * P + gj) - lse[i]) - (gj == i * group ? 1.f : 0.f));
+            const int in = (int)min((int64_t)64, Q - i0);
+            for (int ii = 0; ii < in; ++ii) {
+                const float wi = __shfl(w, ii, 64);
+                if (c0 < d) {
+                    Vec16<T> x;
+                    x.load(q + (i0 + ii) * d + c0);
+#pragma unroll
+                    for (int k = 0; k < V; ++k) accv[k] = fmaf(wi, x.v[k], accv[k]);
+                }
+            }
+        }
+        if (c0 < d) {
+            Vec16<T> o;
+#pragma unroll
+            for (int k = 0; k < V; ++k) o.v[k] = accv[k];
+            o.store(dp + row * d + c0);
+        }
+    }
+}
+
+// Scalar backward for shapes the vector form cannot take (d % V != 0 or unaligned): thread per column.
+template <typename T>
+__global__ __launch_bounds__(64) void infonce_bwd_scalar_kernel(
+    const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ scores, const float* __restrict__ lse,
+    const float* __restrict__ grad_loss, int64_t Q, int64_t P, int64_t d, float temperature, int64_t group,
+    int64_t q_row0, int64_t q_rows, int64_t p_row0, int64_t p_rows, T* __restrict__ dq, T* __restrict__ dp,
+    int nchunk) {
+    const float coef = grad_loss[0] / ((float)Q * temperature);
+    int64_t b = blockIdx.x;
+    const int64_t ndq = dq ? q_rows * nchunk : 0;
+    const bool is_dq = b < ndq;
+    if (!is_dq) b -= ndq;
+    const int64_t row = b / nchunk;
+    const int64_t c = (b % nchunk) * 64 + threadIdx.x;
+    if (c >= d) return;
+    float acc = 0.f;
+    if (is_dq) {
+        const int64_t gi = q_row0 + row;
+        const float lse_i = lse[gi];
+        for (int64_t j = 0; j < P; ++j) {
+            const float w = coef * (__expf(Elem<T>::ld(scores + gi * P + j) - lse_i) - (j == gi * group ? 1.f : 0.f));
+            acc = fmaf(w, Elem<T>::ld(p + j * d + c), acc);
+        }
+        Elem<T>::st(dq + row * d + c, acc);
+    } else {
+        const int64_t gj = p_row0 + row;
+        for (int64_t i = 0; i < Q; ++i) {
+            const float w = coef * (__expf(Elem<T>::ld(scores + i * P + gj) - lse[i]) - (gj == i * group ? 1.f : 0.f));
+            acc = fmaf(w, Elem<T>::ld(q + i * d + c), acc);
+        }
+        Elem<T>::st(dp + row * d + c, acc);
+    }
+}
+
+// RPO_TARGET_FIRST backward: grid = own q rows (b) ; w[b,g] = coef (softmax(s_b)[g] - [g == 0]).
+//   dq_b = sum_g w[b,g] p_{bG+g}   ;   dp_{bG+g} = w[b,g] q_b   (only rows inside the own ranges are written)
+template <typename T>
+__global__ __launch_bounds__(256) void infonce_first_bwd_kernel(
+    const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ scores, const float* __restrict__ lse,
+    const float* __restrict__ grad_loss, int64_t B, int64_t G, int64_t d, float temperature, int64_t q_row0,
+    int64_t q_rows, int64_t p_row0, int64_t p_rows, T* __restrict__ dq, T* __restrict__ dp) {
+    const int64_t b = blockIdx.x;   // all B rows; a row may own its q, some of its p's, or neither
+    const float coef = grad_loss[0] / ((float)B * temperature);
+    const float lse_b = lse[b];
+    const bool own_q = dq && b >= q_row0 && b < q_row0 + q_rows;
+    for (int64_t c = threadIdx.x; c < d; c += 256) {
+        float aq = 0.f;
+        const float qv = Elem<T>::ld(q + b * d + c);
+        for (int64_t g = 0; g < G; ++g) {
+            const float w = coef * (__expf(Elem<T>::ld(scores + b * G + g) - lse_b) - (g == 0 ? 1.f : 0.f));
+            const int64_t pj = b * G + g;
+            aq = fmaf(w, Elem<T>::ld(p + pj * d + c), aq);
+            if (dp && pj >= p_row0 && pj < p_row0 + p_rows) Elem<T>::st(dp + (pj - p_row0) * d + c, w * qv);
+        }
+        if (own_q) Elem<T>::st(dq + (b - q_row0) * d + c, aq);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+enum FwdPath { PATH_TILE = 0, PATH_SKINNY = 1, PATH_ROWWISE = 2 };
+
+struct Plan {
+    int path;
+    int nPb;          // passage column blocks (partials per row)
+    int nPt, nQt;     // tile grid
+    int nFin;         // finalize blocks
+    size_t off_partial, off_blocksum, off_raw, total;
+};
+
+template <typename T> constexpr int row_elems() { return kTileRowBytes / (int)sizeof(T); }
+
+static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) {
+    Plan pl{};
+    const int es = dtype == RPO_DT_BF16 ? 2 : 4;
+    const int CE = 16 / es, KE = kTileRowBytes / es;
+    const bool chunk_ok = aligned && (d % CE == 0);
+    if (!chunk_ok) {
+        pl.path = PATH_ROWWISE;
+        pl.nPb = 1;
+    } else if (Q <= 64 || (d % KE != 0)) {
+        if (Q <= 64) {
+            pl.path = PATH_SKINNY;
+            pl.nPb = (int)rpo_cdiv(P, 16);
+        } else {
+            pl.path = PATH_ROWWISE;
+            pl.nPb = 1;
+        }
+    } else {
+        pl.path = PATH_TILE;
+        pl.nPt = (int)rpo_cdiv(P, kTileP);
+        pl.nQt = (int)rpo_cdiv(Q, kTileQ);
+        pl.nPb = pl.nPt;
+    }
+    pl.nFin = (int)rpo_cdiv(Q, kFinThreads);
+    size_t off = 256;                                   // [0,16): ticket counter
+    pl.off_partial = off;
+    off += (size_t)pl.nPb * (size_t)Q * sizeof(float2);
+    off = (off + 255) & ~(size_t)255;
+    pl.off_blocksum = off;
+    off += (size_t)pl.nFin * sizeof(float);
+    off = (off + 255) & ~(size_t)255;
+    pl.off_raw = off;                                   // RPO_TARGET_FIRST raw dots [Q, P/Q]
+    off += (size_t)P * sizeof(float);
+    pl.total = (off + 255) & ~(size_t)255;
+    return pl;
+}
+
+template <typename T>
+int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, float temperature, int target_mode,
+             void* scores_out, float* lse_out, float* loss_out, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int dtype = sizeof(T) == 2 ? RPO_DT_BF16 : RPO_DT_F32;
+    const bool do_stats = lse_out != nullptr;
+    const int scale = temperature != 1.0f;
+    const bool aligned = rpo_aligned16(q) && rpo_aligned16(p);
+    Plan pl = make_plan(Q, P, d, dtype, aligned);
+    if (do_stats || target_mode == RPO_TARGET_FIRST) {
+        if (!ws || ws_bytes < pl.total || (reinterpret_cast<uintptr_t>(ws) & 255)) return RPO_ERR_WORKSPACE;
+    }
+    char* wsb = (char*)ws;
+    if (target_mode == RPO_TARGET_FIRST) {
+        const int64_t G = P / Q;
+        float* raw = (float*)(wsb + pl.off_raw);
+        int rc = rpo_launch_grouped_dots(q, p, Q, G, d, dtype, raw, st);
+        if (rc != RPO_OK) return rc;
+        hipLaunchKernelGGL(first_finalize_kernel<T>, dim3(1), dim3(kFinThreads), 0, st, raw, Q, G, temperature,
+                           scale, (T*)scores_out, lse_out, loss_out);
+        return rpo_launch_status();
+    }
+    float2* partial = do_stats ? (float2*)(wsb + pl.off_partial) : nullptr;
+    if (pl.path == PATH_TILE) {
+        static bool attr_set = false;   // idempotent; a race only repeats the same call
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kTileLdsBytes);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(sim_tile_kernel<T>, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kTileThreads), kTileLdsBytes,
+                           st, (const T*)q, (const T*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
+                           (T*)scores_out, partial, pl.nPt, pl.nQt);
+    } else if (pl.path == PATH_SKINNY) {
+        const dim3 grid((unsigned)pl.nPb), block(kSkinnyThreads);
+        const int nq = (int)rpo_cdiv(Q, 16);
+#define RPO_SKINNY(NQ)                                                                                       \
+    hipLaunchKernelGGL((sim_skinny_kernel<T, NQ>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d,     \
+                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial)
+        switch (nq) {
+            case 1: RPO_SKINNY(1); break;
+            case 2: RPO_SKINNY(2); break;
+            case 3: RPO_SKINNY(3); break;
+            default: RPO_SKINNY(4); break;
+        }
+#undef RPO_SKINNY
+    } else {
+        hipLaunchKernelGGL(sim_rowwise_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q, (const T*)p, Q,
+                           P, d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial);
+    }
+    int rc = rpo_launch_status();
+    if (rc != RPO_OK || !do_stats) return rc;
+    unsigned* ticket = (unsigned*)wsb;
+    if (pl.nFin > 1) (void)hipMemsetAsync(ticket, 0, 16, st);
+    hipLaunchKernelGGL(ce_finalize_kernel<T>, dim3((unsigned)pl.nFin), dim3(kFinThreads), 0, st, partial,
+                       (const T*)scores_out, Q, P, pl.nPb, P / Q, lse_out, loss_out,
+                       (float*)(wsb + pl.off_blocksum), ticket);
+    return rpo_launch_status();
+}
+
+template <typename T>
+int bwd_impl(const void* q, const void* p, const void* scores, const float* lse, const float* grad_loss, int64_t Q,
+             int64_t P, int64_t d, float temperature, int target_mode, int64_t q_row0, int64_t q_rows,
+             int64_t p_row0, int64_t p_rows, void* dq, void* dp, hipStream_t st) {
+    if (target_mode == RPO_TARGET_FIRST) {
+        hipLaunchKernelGGL(infonce_first_bwd_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q,
+                           (const T*)p, (const T*)scores, lse, grad_loss, Q, P / Q, d, temperature, q_row0, q_rows,
+                           p_row0, p_rows, (T*)dq, (T*)dp);
+        return rpo_launch_status();
+    }
+    constexpr int V = Elem<T>::kVec;
+    const bool vec = (d % V == 0) && rpo_aligned16(q) && rpo_aligned16(p) && (!dq || rpo_aligned16(dq)) &&
+                     (!dp || rpo_aligned16(dp));
+    const int64_t group = P / Q;
+    if (vec) {
+        const int nchunk = (int)rpo_cdiv(d, 64 * V);
+        const int64_t blocks = ((dq ? q_rows : 0) + (dp ? p_rows : 0)) * nchunk;
+        if (blocks <= 0) return RPO_OK;
+        hipLaunchKernelGGL(infonce_bwd_valu_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, st, (const T*)q,
+                           (const T*)p, (const T*)scores, lse, grad_loss, Q, P, d, temperature, group, q_row0,
+                           q_rows, p_row0, p_rows, (T*)dq, (T*)dp, nchunk);
+    } else {
+        const int nchunk = (int)rpo_cdiv(d, 64);
+        const int64_t blocks = ((dq ? q_rows : 0) + (dp ? p_rows : 0)) * nchunk;
+        if (blocks <= 0) return RPO_OK;
+        hipLaunchKernelGGL(infonce_bwd_scalar_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, st, (const T*)q,
+                           (const T*)p, (const T*)scores, lse, grad_loss, Q, P, d, temperature, group, q_row0,
+                           q_rows, p_row0, p_rows, (T*)dq, (T*)dp, nchunk);
+    }
+    return rpo_launch_status();
+}
+
+static int check_common(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int dtype, float temperature,
+                        int target_mode) {
+    if (!q || !p || Q <= 0 || P <= 0 || d <= 0) return RPO_ERR_INVALID_ARG;
+    if (dtype != RPO_DT_F32 && dtype != RPO_DT_BF16) return RPO_ERR_INVALID_ARG;
+    if (target_mode != RPO_TARGET_INBATCH && target_mode != RPO_TARGET_FIRST) return RPO_ERR_INVALID_ARG;
+    if (!(temperature > 0.f)) return RPO_ERR_INVALID_ARG;
+    if (target_mode == RPO_TARGET_FIRST && P % Q != 0) return RPO_ERR_INVALID_ARG;  // .view(Q, G, -1)
+    if (Q > INT32_MAX || P > INT32_MAX || d > INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    if (rpo_cdiv(P, kTileP) * rpo_cdiv(Q, kTileQ) > INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    return RPO_OK;
+}
+
+}  // namespace
+
+extern "C" size_t rpo_infonce_workspace_bytes(int64_t Q, int64_t P, int64_t d, int dtype) {
+    if (Q <= 0 || P <= 0 || d <= 0) return 0;
+    // sized for the path with the most partials so that the answer does not depend on pointer alignment
+    Plan a = make_plan(Q, P, d, dtype, true), b = make_plan(Q, P, d, dtype, false);
+    return a.total > b.total ? a.total : b.total;
+}
+
+extern "C" int rpo_infonce_fwd(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int dtype,
+                               float temperature, int target_mode, void* scores_out, float* lse_out,
+                               float* loss_out, void* workspace, size_t workspace_bytes, rpo_stream_t stream) {
+    int rc = check_common(q, p, Q, P, d, dtype, temperature, target_mode);
+    if (rc != RPO_OK) return rc;
+    if (!scores_out) return RPO_ERR_INVALID_ARG;
+    if ((lse_out == nullptr) != (loss_out == nullptr)) return RPO_ERR_INVALID_ARG;
+    if (lse_out && P < Q) return RPO_ERR_INVALID_ARG;   // target_i = i * (P // Q) needs group_size >= 1
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RPO_DT_F32)
+        return fwd_impl<float>(q, p, Q, P, d, temperature, target_mode, scores_out, lse_out, loss_out, workspace,
+                               workspace_bytes, st);
+    return fwd_impl<bf16_t>(q, p, Q, P, d, temperature, target_mode, scores_out, lse_out, loss_out, workspace,
+                            workspace_bytes, st);
+}
+
+extern "C" int rpo_infonce_bwd(const void* q, const void* p, const void* scores, const float* lse,
+                               const float* grad_loss, int64_t Q, int64_t P, int64_t d, int dtype,
+                               float temperature, int target_mode, int64_t q_row0, int64_t q_rows, int64_t p_row0,
+                               int64_t p_rows, void* dq_out, void* dp_out, void* workspace, size_t workspace_bytes,
+                               rpo_stream_t stream) {
+    (void)workspace;
+    (void)workspace_bytes;
+    int rc = check_common(q, p, Q, P, d, dtype, temperature, target_mode);
+    if (rc != RPO_OK) return rc;
+    if (!scores || !lse || !grad_loss || P < Q) return RPO_ERR_INVALID_ARG;
+    if (!dq_out && !dp_out) return RPO_ERR_INVALID_ARG;
+    if (q_row0 < 0 || q_rows < 0 || q_row0 + q_rows > Q || p_row0 < 0 || p_rows < 0 || p_row0 + p_rows > P)
+        return RPO_ERR_INVALID_ARG;
+    if (dq_out && q_rows == 0) dq_out = nullptr;
+    if (dp_out && p_rows == 0) dp_out = nullptr;
+    if (!dq_out && !dp_out) return RPO_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RPO_DT_F32)
+        return bwd_impl<float>(q, p, scores, lse, grad_loss, Q, P, d, temperature, target_mode, q_row0, q_rows,
+                               p_row0, p_rows, dq_out, dp_out, st);
+    return bwd_impl<bf16_t>(q, p, scores, lse, grad_loss, Q, P, d, temperature, target_mode, q_row0, q_rows, p_row0,
+                            p_rows, dq_out, dp_out, st);
+}
+
+extern "C" int rpo_version(void) { return 100; }
+
+extern "C" const char* rpo_status_string(int status) {
+    switch (status) {
+        case RPO_OK: return "ok";
+        case RPO_ERR_INVALID_ARG: return "invalid argument";
+        case RPO_ERR_UNSUPPORTED: return "unsupported shape / dtype / alignment";
+        case RPO_ERR_WORKSPACE: return "workspace missing, misaligned or too small";
+        case RPO_ERR_LAUNCH: return "HIP launch error";
+        default: return "unknown status";
+    }
+}

@@ -1,0 +1,249 @@
+"""torch.autograd wrappers around the C ABI (include/rankpo_hip.h).
+
+PyTorch is plumbing here: it owns device memory and streams; every computation of the scoring hot path is
+done by librankpo_hip.so.  There is no fallback: tensors must live on a HIP device.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import (RPO_DT_BF16, RPO_DT_F32, RPO_LOSS_HINGE, RPO_LOSS_SIGMOID, RPO_NUM_METRICS, RPO_POOL_CLS,
+                   RPO_POOL_LAST, RPO_TARGET_FIRST, RPO_TARGET_INBATCH, METRIC_KEYS, RankPOParams, check)
+
+F_NORMALIZE_EPS = 1e-12  # torch.nn.functional.normalize default (modeling.py:236)
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return RPO_DT_F32
+    if t.dtype == torch.bfloat16:
+        return RPO_DT_BF16
+    raise TypeError(f"rankpo_amd HIP kernels take float32 or bfloat16 tensors, got {t.dtype}")
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("rankpo_amd scoring ops run only on a HIP device (no CPU fallback); "
+                               f"got a tensor on {t.device}")
+
+
+def _stream(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+# ------------------------------------------------------------------------------------------------
+# (1) pooling + normalisation
+# ------------------------------------------------------------------------------------------------
+class _PoolNormalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, mask, pool_mode, normalize, eps):
+        _need_gpu(h, mask)
+        lib = _lib.load()
+        if h.dim() != 3:
+            raise ValueError(f"last_hidden_state must be [N, L, d], got {tuple(h.shape)}")
+        if h.stride(2) != 1:
+            h = h.contiguous()
+        N, L, d = h.shape
+        if pool_mode == RPO_POOL_LAST:
+            if mask is None or tuple(mask.shape) != (N, L):
+                raise ValueError("attention_mask must be [N, L] for last-token pooling")
+            mask = mask.to(torch.int64).contiguous()
+        out = torch.empty((N, d), dtype=h.dtype, device=h.device)
+        idx = torch.empty((N,), dtype=torch.int32, device=h.device)
+        norm = torch.empty((N,), dtype=torch.float32, device=h.device)
+        with torch.cuda.device(h.device):
+            check(lib.rpo_pool_normalize_fwd(h.data_ptr(), h.stride(0), h.stride(1), _p(mask), N, L, d, _dt(h),
+                                             pool_mode, int(normalize), eps, out.data_ptr(), idx.data_ptr(),
+                                             norm.data_ptr(), _stream(h)), "rpo_pool_normalize_fwd")
+        ctx.save_for_backward(out, idx, norm)
+        ctx.meta = (N, L, d, int(normalize), eps)
+        ctx.mark_non_differentiable(idx)
+        return out, idx
+
+    @staticmethod
+    def backward(ctx, grad_out, _grad_idx):
+        out, idx, norm = ctx.saved_tensors
+        N, L, d, normalize, eps = ctx.meta
+        lib = _lib.load()
+        g = grad_out.contiguous()
+        dh = torch.empty((N, L, d), dtype=out.dtype, device=out.device)   # written in full by the kernel
+        with torch.cuda.device(out.device):
+            check(lib.rpo_pool_normalize_bwd(g.data_ptr(), out.data_ptr(), idx.data_ptr(), norm.data_ptr(), N, L, d,
+                                             _dt(out), normalize, eps, dh.data_ptr(), None, _stream(out)),
+                  "rpo_pool_normalize_bwd")
+        return dh, None, None, None, None
+
+
+def pool_normalize(last_hidden_state, attention_mask, mode: str = "last", normalize: bool = True,
+                   eps: float = F_NORMALIZE_EPS, return_index: bool = False):
+    """modeling.py:224-236: last-token (mode='last') or CLS (mode='cls') pooling + optional F.normalize."""
+    pm = {"last": RPO_POOL_LAST, "cls": RPO_POOL_CLS}[mode]
+    out, idx = _PoolNormalize.apply(last_hidden_state, attention_mask, pm, normalize, eps)
+    return (out, idx) if return_index else out
+
+
+# ------------------------------------------------------------------------------------------------
+# (2) similarity + InfoNCE
+# ------------------------------------------------------------------------------------------------
+def _workspace(lib, Q, P, d, dt, device):
+    n = lib.rpo_infonce_workspace_bytes(Q, P, d, dt)
+    return torch.empty((max(n, 256),), dtype=torch.uint8, device=device), n
+
+
+class _InfoNCE(torch.autograd.Function):
+    """loss, scores = f(q_local, p_local ; q_all, p_all).  q_all / p_all are the (possibly gathered) matrices the
+    loss is computed on; rows [q_row0, +len(q_local)) / [p_row0, +len(p_local)) of them are q_local / p_local.
+    Gradients flow to q_local / p_local only (modeling.py:374-377 semantics)."""
+
+    @staticmethod
+    def forward(ctx, q_local, p_local, q_all, p_all, temperature, target_mode, q_row0, p_row0):
+        _need_gpu(q_all, p_all)
+        lib = _lib.load()
+        q_all = q_all.contiguous()
+        p_all = p_all.contiguous()
+        if q_all.dtype != p_all.dtype:
+            raise TypeError("query and passage embeddings must share a dtype")
+        Q, d = q_all.shape
+        P = p_all.shape[0]
+        dt = _dt(q_all)
+        G = P // Q
+        shape = (Q, P) if target_mode == RPO_TARGET_INBATCH else (Q, G)
+        scores = torch.empty(shape, dtype=q_all.dtype, device=q_all.device)
+        lse = torch.empty((Q,), dtype=torch.float32, device=q_all.device)
+        loss = torch.empty((), dtype=torch.float32, device=q_all.device)
+        ws, nws = _workspace(lib, Q, P, d, dt, q_all.device)
+        with torch.cuda.device(q_all.device):
+            check(lib.rpo_infonce_fwd(q_all.data_ptr(), p_all.data_ptr(), Q, P, d, dt, temperature, target_mode,
+                                      scores.data_ptr(), lse.data_ptr(), loss.data_ptr(), ws.data_ptr(), nws,
+                                      _stream(q_all)), "rpo_infonce_fwd")
+        ctx.save_for_backward(q_all, p_all, scores, lse)
+        ctx.meta = (Q, P, d, dt, temperature, target_mode, q_row0, q_local.shape[0], p_row0, p_local.shape[0])
+        ctx.mark_non_differentiable(scores)
+        return loss, scores
+
+    @staticmethod
+    def backward(ctx, grad_loss, _grad_scores):
+        q_all, p_all, scores, lse = ctx.saved_tensors
+        Q, P, d, dt, temperature, target_mode, q_row0, q_rows, p_row0, p_rows = ctx.meta
+        lib = _lib.load()
+        need_q, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gl = grad_loss.to(torch.float32).contiguous()
+        dq = torch.empty((q_rows, d), dtype=q_all.dtype, device=q_all.device) if need_q else None
+        dp = torch.empty((p_rows, d), dtype=q_all.dtype, device=q_all.device) if need_p else None
+        if need_q or need_p:
+            with torch.cuda.device(q_all.device):
+                check(lib.rpo_infonce_bwd(q_all.data_ptr(), p_all.data_ptr(), scores.data_ptr(), lse.data_ptr(),
+                                          gl.data_ptr(), Q, P, d, dt, temperature, target_mode, q_row0, q_rows,
+                                          p_row0, p_rows, _p(dq), _p(dp), None, 0, _stream(q_all)),
+                      "rpo_infonce_bwd")
+        return dq, dp, None, None, None, None, None, None
+
+
+def infonce_loss(q_local, p_local, temperature: float, use_inbatch_neg: bool = True, q_all=None, p_all=None,
+                 q_row0: int = 0, p_row0: int = 0):
+    """modeling.py:292-314.  Returns (loss f32 scalar, temperature-scaled scores)."""
+    mode = RPO_TARGET_INBATCH if use_inbatch_neg else RPO_TARGET_FIRST
+    if q_all is None:
+        q_all, p_all = q_local.detach(), p_local.detach()
+    return _InfoNCE.apply(q_local, p_local, q_all, p_all, float(temperature), mode, int(q_row0), int(p_row0))
+
+
+def similarity(q, p):
+    """modeling.py:252 / :321 on 2-D inputs: q @ p.T in the storage dtype (no temperature, no loss)."""
+    _need_gpu(q, p)
+    lib = _lib.load()
+    q = q.contiguous()
+    p = p.contiguous()
+    Q, d = q.shape
+    P = p.shape[0]
+    scores = torch.empty((Q, P), dtype=q.dtype, device=q.device)
+    with torch.cuda.device(q.device):
+        check(lib.rpo_infonce_fwd(q.data_ptr(), p.data_ptr(), Q, P, d, _dt(q), 1.0,
+                                  RPO_TARGET_INBATCH, scores.data_ptr(), None, None, None, 0, _stream(q)),
+              "rpo_infonce_fwd(eval)")
+    return scores
+
+
+# ------------------------------------------------------------------------------------------------
+# (3) RankPO
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class RankPOConfig:
+    beta: float = 0.1
+    temperature: float = 1.0
+    gamma_beta_ratio: float = 0.0
+    label_smoothing: float = 0.0
+    rankpo_weight: float = 1.0
+    sft_weight: float = 0.0
+    loss_type: str = "sigmoid"
+    reference_free: bool = False
+
+    def to_c(self) -> RankPOParams:
+        if self.loss_type not in ("sigmoid", "hinge"):   # rankpo_trainer.py:563-566
+            raise ValueError(f"Unknown loss type: {self.loss_type}. Should be one of ['sigmoid', 'hinge']")
+        return RankPOParams(self.beta, self.temperature, self.gamma_beta_ratio, self.label_smoothing,
+                            self.rankpo_weight, self.sft_weight,
+                            RPO_LOSS_SIGMOID if self.loss_type == "sigmoid" else RPO_LOSS_HINGE,
+                            int(bool(self.reference_free)))
+
+
+class _RankPO(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, p, ref_chosen, ref_rejected, cfg: RankPOConfig):
+        _need_gpu(q, p, ref_chosen, ref_rejected)
+        lib = _lib.load()
+        q = q.contiguous()
+        p = p.contiguous()
+        B, d = q.shape
+        if p.shape[0] != 2 * B:
+            raise ValueError(f"RankPO needs 2 passages (chosen, rejected) per query: got {p.shape[0]} for B={B}")
+        dev = q.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        scores = torch.empty((B, 2), **f32)
+        losses = torch.empty((B,), **f32)
+        loss = torch.empty((), **f32)
+        metrics = torch.empty((RPO_NUM_METRICS,), **f32)
+        dscores = torch.empty((B, 2), **f32)
+        rc = None if ref_chosen is None else ref_chosen.to(torch.float32).contiguous()
+        rr = None if ref_rejected is None else ref_rejected.to(torch.float32).contiguous()
+        prm = cfg.to_c()
+        with torch.cuda.device(dev):
+            check(lib.rpo_rankpo_fwd(q.data_ptr(), p.data_ptr(), _p(rc), _p(rr), B, d, _dt(q), C.byref(prm),
+                                     scores.data_ptr(), losses.data_ptr(), loss.data_ptr(), metrics.data_ptr(),
+                                     dscores.data_ptr(), _stream(q)), "rpo_rankpo_fwd")
+        ctx.save_for_backward(q, p, dscores)
+        ctx.mark_non_differentiable(scores, losses, metrics)
+        return loss, scores, losses, metrics
+
+    @staticmethod
+    def backward(ctx, grad_loss, *_):
+        q, p, dscores = ctx.saved_tensors
+        lib = _lib.load()
+        B, d = q.shape
+        need_q, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        gl = grad_loss.to(torch.float32).contiguous()
+        dq = torch.empty_like(q) if need_q else None
+        dp = torch.empty_like(p) if need_p else None
+        if need_q or need_p:
+            with torch.cuda.device(q.device):
+                check(lib.rpo_rankpo_bwd(q.data_ptr(), p.data_ptr(), dscores.data_ptr(), gl.data_ptr(), B, d,
+                                         _dt(q), _p(dq), _p(dp), _stream(q)), "rpo_rankpo_bwd")
+        return dq, dp, None, None, None
+
+
+def rankpo_loss_metrics(q, p, cfg: RankPOConfig, ref_chosen=None, ref_rejected=None):
+    """rankpo_trainer.py:458-520 on embeddings.  Returns (loss, scores[B,2] f32, losses[B], metrics[9] f32);
+    `metrics` stays on the device (slot order = _lib.METRIC_KEYS) so that logging costs ONE host copy."""
+    return _RankPO.apply(q, p, ref_chosen, ref_rejected, cfg)
+
+
+__all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS"]

@@ -1,0 +1,374 @@
+"""GPU parity tests of the HIP hot path, called through the C ABI (rankpo_amd.ops -> ctypes -> librankpo_hip.so)
+against the numpy oracle (oracle/scoring_ref.py) and the golden vectors the reference itself produced.
+
+Tolerances (stated per check):
+  f32 storage : scores/loss 2e-5 (f32 accumulation order), gradients 1e-4 relative to the largest entry.
+  bf16 storage: scores within 2 bf16 ulps (<= 2^-6 relative) of the oracle evaluated on the same bf16-rounded
+                inputs with the reference's rounding points; lse/loss are additionally required to equal the
+                oracle applied to the RETURNED scores to 2e-5, which pins the fused softmax exactly.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import scoring_ref as R
+from conftest import contrastive_inputs, seeded, unit
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def ops():
+    from rankpo_amd import ops as o
+    return o
+
+
+def t(x, dtype=torch.float32, grad=False):
+    return torch.tensor(np.asarray(x), dtype=torch.float32).to(dtype).to(DEV).requires_grad_(grad)
+
+
+def npf(x):
+    return x.detach().float().cpu().numpy().astype(np.float64)
+
+
+def relmax(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+# ------------------------------------------------------------------------------------------------ pooling
+POOL_CASES = [(a, n, m) for a in ("llama", "bert") for n in (True, False)
+              for m in ("allones", "rightpad", "leftpad", "mixed")]
+
+
+@pytest.mark.parametrize("arch,normalize,mask", POOL_CASES)
+def test_pool_normalize_golden(golden, arch, normalize, mask):
+    g = golden("pooling")
+    mode = "last" if arch == "llama" else "cls"
+    key = f"{arch}_{'norm' if normalize else 'raw'}_{mask}"
+    h = t(g["h"], grad=True)
+    mk = torch.tensor(g["mask_" + mask]).to(DEV)
+    e = ops().pool_normalize(h, mk, mode, normalize)
+    np.testing.assert_allclose(npf(e), g[key + "_embeds"], rtol=2e-6, atol=2e-6)
+    e.backward(t(g["g"]))
+    np.testing.assert_allclose(npf(h.grad), g[key + "_dh"], rtol=2e-5, atol=2e-6)
+
+
+def test_pool_normalize_zero_norm(golden):
+    g = golden("pooling")
+    h = t(g["zeronorm_h"], grad=True)
+    mk = torch.tensor(g["mask_rightpad"]).to(DEV)
+    e = ops().pool_normalize(h, mk, "last", True)
+    ref = g["zeronorm_embeds"]
+    np.testing.assert_allclose(npf(e)[[0, 1, 3, 4, 5]], ref[[0, 1, 3, 4, 5]], rtol=2e-6, atol=1e-30)
+    e.backward(t(g["g"]))
+    dh = npf(h.grad)
+    assert np.isfinite(dh).all()
+    np.testing.assert_allclose(dh[1], g["zeronorm_dh"][1], rtol=1e-5)      # the eps-clamped (zero) row: g / eps
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,L,d", [(6, 512, 2048), (3, 33, 40), (5, 7, 12)])
+def test_pool_normalize_random(dtype, N, L, d):
+    rs = np.random.RandomState(N * 1000 + L)
+    h_np = rs.randn(N, L, d)
+    lens = rs.randint(1, L + 1, size=N)
+    lens[0] = L
+    mk = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    g_np = rs.randn(N, d)
+    h = t(h_np, dtype, grad=True)
+    hq = npf(h)                                                # the (possibly bf16-rounded) values actually used
+    e, idx = ops().pool_normalize(h, torch.tensor(mk).to(DEV), "last", True, return_index=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), R.last_token_index(mk))
+    tol = 2e-6 if dtype == torch.float32 else 2.0 ** -8
+    np.testing.assert_allclose(npf(e), R.pool_normalize(hq, mk), rtol=tol, atol=tol * 1e-2)
+    gt = t(g_np, dtype)
+    e.backward(gt)
+    ref = R.pool_normalize_bwd(hq, mk, npf(gt))
+    assert relmax(npf(h.grad), ref) < (1e-5 if dtype == torch.float32 else 2.0 ** -7)
+    # the dense gradient is exactly zero off the pooled rows
+    off = npf(h.grad).copy()
+    off[np.arange(N), R.last_token_index(mk)] = 0
+    assert not off.any()
+
+
+def test_pool_strided_hidden():
+    rs = np.random.RandomState(3)
+    big = t(rs.randn(4, 9, 2, 64))
+    h = big[:, :, 1, :]                                        # stride_l = 128, inner contiguous
+    mk = torch.ones((4, 9), dtype=torch.int64, device=DEV)
+    e = ops().pool_normalize(h, mk, "last", True)
+    np.testing.assert_allclose(npf(e), R.pool_normalize(npf(h), mk.cpu().numpy()), rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------ InfoNCE
+T = 0.02
+
+
+@pytest.mark.parametrize("d", [64, 384, 2048])
+@pytest.mark.parametrize("mode", ["inbatch", "noinbatch"])
+def test_infonce_golden_fp32(golden, d, mode):
+    g = golden("contrastive")
+    qn, pn = contrastive_inputs(d)
+    q, p = t(qn, grad=True), t(pn, grad=True)
+    loss, scores = ops().infonce_loss(q, p, T, use_inbatch_neg=(mode == "inbatch"))
+    loss.backward()
+    k = f"{mode}_d{d}_fp32_"
+    np.testing.assert_allclose(npf(scores), g[k + "scores"], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(loss.item(), g[k + "loss"], rtol=2e-5, atol=2e-6)
+    if d == 2048:
+        Rm = seeded(77, d, 8)
+        np.testing.assert_allclose(npf(q.grad) @ Rm, g[k + "dq_proj"], rtol=5e-4, atol=5e-4)
+        np.testing.assert_allclose(npf(p.grad) @ Rm, g[k + "dp_proj"], rtol=5e-4, atol=5e-4)
+    else:
+        assert relmax(npf(q.grad), g[k + "dq"]) < 1e-4
+        assert relmax(npf(p.grad), g[k + "dp"]) < 1e-4
+
+
+@pytest.mark.parametrize("d", [64, 2048])
+def test_infonce_golden_bf16_vs_reference(golden, d):
+    """Against what the reference itself produced in bf16: same rounding points -> scores agree to one bf16 ulp;
+    the reference's loss is itself bf16-rounded, hence the 2^-7 relative tolerance on it."""
+    g = golden("contrastive")
+    qn, pn = contrastive_inputs(d)
+    q, p = t(qn, torch.bfloat16, grad=True), t(pn, torch.bfloat16, grad=True)
+    loss, scores = ops().infonce_loss(q, p, T)
+    ref = g[f"inbatch_d{d}_bf16_scores"]
+    assert np.all(np.abs(npf(scores) - ref) <= np.maximum(np.abs(ref), 1e-2) * 2.0 ** -7)
+    assert abs(loss.item() - float(g[f"inbatch_d{d}_bf16_loss"])) <= 2.0 ** -6 * max(1.0, abs(loss.item()))
+    sev = ops().similarity(q.detach(), p.detach())
+    ref = g[f"eval_d{d}_bf16_scores"] if f"eval_d{d}_bf16_scores" in g.files else None
+    if ref is not None:
+        assert np.all(np.abs(npf(sev) - ref) <= np.maximum(np.abs(ref), 1e-3) * 2.0 ** -7)
+
+
+SHAPES = [
+    # Q, P, d            path exercised
+    (8, 48, 2048),      # skinny NQ=1   (cfg 2)
+    (64, 384, 2048),    # skinny NQ=4   (cfg 3: W=8 gathered)
+    (64, 384, 4096),    # cfg 5
+    (17, 51, 40),       # skinny, ragged rows, K tail
+    (33, 99, 72),       # skinny NQ=3
+    (5, 35, 36),        # rowwise for bf16 (36 % 8 != 0), skinny for f32
+    (3, 9, 7),          # rowwise
+    (256, 1536, 128),   # tile
+    (130, 390, 192),    # tile, ragged edges
+    (128, 128, 64),     # tile, single K step (bf16)
+    (100, 700, 96),     # Q > 64 with d % 64 != 0 -> rowwise (bf16) / tile (f32)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Q,P,d", SHAPES)
+def test_infonce_forward_backward_shapes(dtype, Q, P, d):
+    rs = np.random.RandomState(Q * 7 + P)
+    qn, pn = unit(rs.randn(Q, d)), unit(rs.randn(P, d))
+    G = P // Q
+    pn[::G][:Q] = unit(pn[::G][:Q] + (2.0 / np.sqrt(d)) * qn)
+    q, p = t(qn, dtype, grad=True), t(pn, dtype, grad=True)
+    qv, pv = npf(q), npf(p)
+    loss, scores = ops().infonce_loss(q, p, T)
+    gl = 0.37
+    (loss * gl).backward()
+    s = npf(scores)
+    if dtype == torch.float32:
+        f = R.infonce_backward(qv, pv, T, True, grad_loss=gl)
+        np.testing.assert_allclose(s, f["scores"], rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(loss.item(), f["loss"], rtol=3e-5, atol=3e-6)
+        assert relmax(npf(q.grad), f["dq"]) < 2e-4
+        assert relmax(npf(p.grad), f["dp"]) < 2e-4
+    else:
+        exp = R.round_bf16(R.round_bf16(R.similarity(qv, pv)).astype(np.float64) / T)
+        # one bf16 ulp is at most 2^-7 relative.  f32-vs-f64 accumulation order can flip the FIRST rounding
+        # (dot -> bf16) by one ulp; after the division by T that ulp can be two ulps of the result's binade.
+        ulps = (np.abs(s - exp) / (np.maximum(np.abs(exp), 1e-2) * 2.0 ** -7)).max()
+        assert ulps <= 2.0 + 1e-6, ulps
+        # the fused softmax / CE must be exact on the scores that were actually returned
+        tgt = np.arange(Q) * G
+        m = s.max(-1, keepdims=True)
+        lse = (m + np.log(np.exp(s - m).sum(-1, keepdims=True)))[:, 0]
+        np.testing.assert_allclose(loss.item(), (lse - s[np.arange(Q), tgt]).mean(), rtol=2e-5, atol=2e-6)
+        # gradients: softmax of the returned scores, applied to the bf16 inputs; outputs are bf16-rounded
+        ds = np.exp(s - lse[:, None])
+        ds[np.arange(Q), tgt] -= 1
+        ds *= gl / Q / T
+        assert relmax(npf(q.grad), ds @ pv) < 2.0 ** -7
+        assert relmax(npf(p.grad), ds.T @ qv) < 2.0 ** -7
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_infonce_no_inbatch(dtype):
+    rs = np.random.RandomState(11)
+    B, G, d = 8, 6, 256
+    qn, pn = unit(rs.randn(B, d)), unit(rs.randn(B * G, d))
+    q, p = t(qn, dtype, grad=True), t(pn, dtype, grad=True)
+    loss, scores = ops().infonce_loss(q, p, T, use_inbatch_neg=False)
+    loss.backward()
+    f = R.infonce_backward(npf(q), npf(p), T, False)
+    tol = 3e-5 if dtype == torch.float32 else 2.0 ** -7
+    assert tuple(scores.shape) == (B, G)
+    np.testing.assert_allclose(npf(scores), f["scores"], rtol=tol, atol=tol)
+    np.testing.assert_allclose(loss.item(), f["loss"], rtol=max(tol, 1e-4), atol=tol)
+    assert relmax(npf(q.grad), f["dq"]) < (2e-4 if dtype == torch.float32 else 2.0 ** -6)
+    assert relmax(npf(p.grad), f["dp"]) < (2e-4 if dtype == torch.float32 else 2.0 ** -6)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_infonce_cross_device_own_slice(golden, world):
+    """The gathered problem of G5 (reference on W gloo ranks): every 'rank' computes the same loss and receives
+    gradients for its own rows only."""
+    g = golden("crossdevice")
+    qs = [g[f"w{world}_r{r}_q"] for r in range(world)]
+    ps = [g[f"w{world}_r{r}_p"] for r in range(world)]
+    qa, pa = t(np.concatenate(qs)), t(np.concatenate(ps))
+    B, PB = qs[0].shape[0], ps[0].shape[0]
+    for r in range(world):
+        ql, pl = t(qs[r], grad=True), t(ps[r], grad=True)
+        loss, scores = ops().infonce_loss(ql, pl, T, True, q_all=qa, p_all=pa, q_row0=r * B, p_row0=r * PB)
+        loss.backward()
+        k = f"w{world}_r{r}_"
+        np.testing.assert_allclose(loss.item(), g[k + "loss"], rtol=3e-5)
+        np.testing.assert_allclose(npf(scores), g[k + "scores"], rtol=3e-5, atol=3e-5)
+        assert relmax(npf(ql.grad), g[k + "dq"]) < 2e-4
+        assert relmax(npf(pl.grad), g[k + "dp"]) < 2e-4
+
+
+def test_infonce_analytic():
+    v = np.ones((1, 64)) / 8.0
+    loss, _ = ops().infonce_loss(t(np.repeat(v, 4, 0)), t(np.repeat(v, 24, 0)), 0.02)
+    np.testing.assert_allclose(loss.item(), np.log(24), rtol=1e-6)
+    Q, G = 4, 3
+    P = Q * G
+    p = np.eye(P, 64)
+    loss, _ = ops().infonce_loss(t(p[::G]), t(p), 0.05)
+    np.testing.assert_allclose(loss.item(), np.log(np.exp(20.0) + P - 1) - 20.0, rtol=1e-4, atol=1e-7)
+
+
+def test_infonce_large_size_properties():
+    """Full-size property checks where the oracle would be slow: Q = P = 4096, d = 2048 bf16.
+    (i) row-permutation equivariance of scores, (ii) loss == CE recomputed by torch from the returned scores,
+    (iii) gradient rows sum rule: sum_j dS[i,j] = 0  =>  dq_i . 1-vector identity via linearity check."""
+    torch.manual_seed(0)
+    Q = P = 4096
+    d = 2048
+    q = torch.nn.functional.normalize(torch.randn(Q, d, device=DEV), dim=-1).to(torch.bfloat16).requires_grad_(True)
+    p = torch.nn.functional.normalize(torch.randn(P, d, device=DEV), dim=-1).to(torch.bfloat16).requires_grad_(True)
+    loss, scores = ops().infonce_loss(q, p, T)
+    loss.backward()
+    ref = torch.nn.functional.cross_entropy(scores.float(), torch.arange(Q, device=DEV))
+    np.testing.assert_allclose(loss.item(), ref.item(), rtol=2e-5)
+    perm = torch.randperm(Q, device=DEV)
+    _, s2 = ops().infonce_loss(q.detach()[perm], p.detach(), T)
+    assert torch.equal(s2, scores[perm])
+    # spot-check 64 rows of the scores against an f32 matmul with the reference's rounding points
+    rows = torch.arange(0, Q, 64, device=DEV)
+    exp = ((q.detach()[rows].float() @ p.detach().float().T).to(torch.bfloat16).float() / T).to(torch.bfloat16)
+    diff = (scores[rows].float() - exp.float()).abs()
+    assert (diff <= exp.float().abs().clamp_min(1e-2) * 2.0 ** -6).all()   # <= 2 bf16 ulps, see above
+    # gradient spot check by linearity: <dq, u> == d/d eps loss(q + eps u) is too noisy in bf16; instead
+    # compare dq rows against the dense formula on the returned scores
+    sm = torch.softmax(scores[rows].float(), -1)
+    sm[torch.arange(len(rows)), rows] -= 1
+    dq_ref = (sm / (Q * T)) @ p.detach().float()
+    err = (q.grad[rows].float() - dq_ref).abs().max() / dq_ref.abs().max()
+    assert err < 2.0 ** -7
+
+
+# ------------------------------------------------------------------------------------------------ RankPO
+def _rankpo_cfg(c):
+    return ops().RankPOConfig(beta=c["beta"], temperature=c["temperature"], gamma_beta_ratio=c["gamma_beta_ratio"],
+                              label_smoothing=c["label_smoothing"], rankpo_weight=c["rankpo_weight"],
+                              sft_weight=c["sft_weight"], loss_type=c["loss_type"], reference_free=c["reference_free"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_rankpo_golden(golden, dtype):
+    g = golden("rankpo")
+    meta = json.loads(str(g["meta"]))
+    from rankpo_amd._lib import METRIC_KEYS
+    for c in meta["cases"]:
+        with_ref = not c["reference_free"]
+        q, p = t(g["q"], dtype, grad=True), t(g["p"], dtype, grad=True)
+        rc = t(g["ref_chosen"]) if with_ref else None
+        rr = t(g["ref_rejected"]) if with_ref else None
+        loss, scores, losses, metrics = ops().rankpo_loss_metrics(q, p, _rankpo_cfg(c), rc, rr)
+        loss.backward()
+        n = c["name"]
+        if dtype == torch.float32:
+            np.testing.assert_allclose(npf(scores), g[n + "_scores"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(loss.item(), c["loss"], rtol=2e-5, atol=1e-6, err_msg=str(c))
+            np.testing.assert_allclose(npf(losses), g[n + "_losses"] if c["rankpo_weight"] > 0 else 0 * g[n + "_losses"],
+                                       rtol=2e-5, atol=2e-6)
+            m = metrics.cpu().numpy()
+            for i, k in enumerate(METRIC_KEYS):
+                if k in c["metrics"]:
+                    np.testing.assert_allclose(m[i], c["metrics"][k], rtol=2e-5, atol=2e-6, err_msg=k)
+            assert relmax(npf(q.grad), g[n + "_dq"]) < 1e-4, c
+            assert relmax(npf(p.grad), g[n + "_dp"]) < 1e-4, c
+        else:
+            o = R.rankpo_batch_loss_metrics(
+                npf(q), npf(p), g["ref_chosen"] if with_ref else None, g["ref_rejected"] if with_ref else None,
+                beta=c["beta"], temperature=c["temperature"], gamma_beta_ratio=c["gamma_beta_ratio"],
+                label_smoothing=c["label_smoothing"], loss_type=c["loss_type"], reference_free=c["reference_free"],
+                rankpo_weight=c["rankpo_weight"], sft_weight=c["sft_weight"])
+            np.testing.assert_allclose(npf(scores), o["scores"], rtol=1e-5, atol=1e-6)   # f32 accumulate, f32 out
+            np.testing.assert_allclose(loss.item(), o["loss"], rtol=3e-5, atol=1e-6)
+            assert relmax(npf(q.grad), o["dq"]) < 2.0 ** -7
+            assert relmax(npf(p.grad), o["dp"]) < 2.0 ** -7
+
+
+def test_rankpo_kat_and_errors():
+    # analytic KAT of SURVEY §8c through the kernel: embeddings engineered to give scores c, r
+    c, r = np.array([.8, .2, .5]), np.array([.3, .6, .5])
+    B, d = 3, 8
+    q = np.zeros((B, d)); q[:, 0] = 1
+    p = np.zeros((2 * B, d)); p[0::2, 0] = c; p[1::2, 0] = r
+    o = ops()
+    cfg = o.RankPOConfig(beta=2.0, temperature=0.1, reference_free=True)
+    _, _, losses, _ = o.rankpo_loss_metrics(t(q), t(p), cfg)
+    np.testing.assert_allclose(npf(losses), [4.5399e-05, 8.000335, 0.693147], rtol=1e-4)
+    cfg.loss_type = "hinge"
+    _, _, losses, _ = o.rankpo_loss_metrics(t(q), t(p), cfg)
+    np.testing.assert_allclose(npf(losses), [0, 9, 1], atol=1e-5)
+    cfg.loss_type = "bogus"
+    with pytest.raises(ValueError, match="Unknown loss type: bogus"):
+        o.rankpo_loss_metrics(t(q), t(p), cfg)
+
+
+def test_rankpo_large_batch_bf16():
+    rs = np.random.RandomState(5)
+    B, d = 700, 2048
+    qn, pn = unit(rs.randn(B, d)), unit(rs.randn(2 * B, d))
+    q, p = t(qn, torch.bfloat16, grad=True), t(pn, torch.bfloat16, grad=True)
+    cfg = ops().RankPOConfig(beta=2.0, temperature=0.1, sft_weight=0.5, reference_free=True)
+    loss, scores, losses, metrics = ops().rankpo_loss_metrics(q, p, cfg)
+    loss.backward()
+    o = R.rankpo_batch_loss_metrics(npf(q), npf(p), beta=2.0, temperature=0.1, sft_weight=0.5)
+    np.testing.assert_allclose(loss.item(), o["loss"], rtol=1e-4)
+    assert relmax(npf(q.grad), o["dq"]) < 2.0 ** -7
+
+
+# ------------------------------------------------------------------------------------------------ errors
+def test_no_cpu_fallback():
+    q = torch.randn(4, 16)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops().infonce_loss(q, torch.randn(12, 16), 0.02)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops().pool_normalize(torch.randn(2, 3, 8), torch.ones(2, 3, dtype=torch.long))
+
+
+def test_c_abi_argument_errors():
+    import ctypes as C
+    from rankpo_amd import _lib
+    lib = _lib.load()
+    x = torch.zeros(64, 64, device=DEV)
+    assert lib.rpo_infonce_fwd(None, x.data_ptr(), 8, 8, 64, 0, 0.02, 0, x.data_ptr(), None, None, None, 0, None) == -1
+    assert lib.rpo_infonce_fwd(x.data_ptr(), x.data_ptr(), 8, 8, 64, 7, 0.02, 0, x.data_ptr(), None, None, None, 0, None) == -1
+    lse = torch.zeros(8, device=DEV)
+    # statistics requested but no workspace
+    assert lib.rpo_infonce_fwd(x.data_ptr(), x.data_ptr(), 8, 8, 64, 0, 0.02, 0, x.data_ptr(), lse.data_ptr(),
+                               lse.data_ptr(), None, 0, None) == -3
+    assert lib.rpo_pool_normalize_fwd(None, 0, 0, None, 1, 1, 1, 0, 0, 1, 1e-12, None, None, None, None) == -1
+    torch.cuda.synchronize()
