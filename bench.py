@@ -1,0 +1,345 @@
+#!/usr/bin/env python3
+"""bench.py -- query-passage pairs/sec of the contrastive training step on N MI355X (BASELINE.json metric).
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one synthetic batch per GPU, i.e. a full training micro-step:
+encode B queries + B*(1+K) passages (Llama-3.2-1B architecture, bf16, random init) -> last-token pool + L2 normalise
+(HIP) -> [N > 1: RCCL all-gather of embeddings, overlapped with the query tower] -> similarity + InfoNCE (HIP)
+-> backward (HIP scoring backward, encoder backward under PyTorch-ROCm, bucketed gradient all-reduce) -> clip +
+AdamW (HIP, one launch).  value = N * B * (1 + K) * steps / time.  Weak scaling: per-GPU work is fixed.
+
+Workload at N = 1: BASELINE.json configs[1] (q_len 1280, p_len 4096, K = 5, B = 8, in-batch negatives, T = 0.02).
+The JSON line also carries `roofline` (dominant hand-written kernel of the timed step, HIP-event timed live),
+`kernels` (every hand-written entry point in the step), `roofline_sweep` (the similarity+InfoNCE kernel on the
+scaled shapes of SURVEY.md §8d where it is MFMA-bound) and `cpu_baseline` (the oracle's step on the host cores).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+WORKLOADS = {
+    # name: (arch, B, K, Lq, Lp, temperature, dtype)
+    "cfg2": ("llama-3.2-1b", 8, 5, 1280, 4096, 0.02, "bf16"),
+    "cfg1": ("bge-small", 8, 5, 128, 256, 0.02, "f32"),
+    "tiny": ("llama-tiny", 8, 5, 160, 512, 0.02, "bf16"),
+}
+
+
+# ----------------------------------------------------------------------------------------------------------
+# live HIP-event timing of the C entry points (events are recorded on the stream the kernels are launched on)
+# ----------------------------------------------------------------------------------------------------------
+def _es(dt):
+    return 2 if dt == 1 else 4
+
+
+def _algo(name, a):
+    """(algorithmic bytes, flops) of one call, from its C arguments (SURVEY.md §8d figures)."""
+    if name == "rpo_infonce_fwd":
+        Q, P, d, dt, mode = a[2], a[3], a[4], a[5], a[7]
+        s = _es(dt)
+        ns = Q * P if mode == 0 else P
+        return (Q + P) * d * s + ns * s + 4 * Q + 4, 2 * (Q * P if mode == 0 else P) * d
+    if name == "rpo_infonce_bwd":
+        Q, P, d, dt, mode = a[5], a[6], a[7], a[8], a[10]
+        qr, pr = a[12], a[14]
+        s = _es(dt)
+        ns = Q * P if mode == 0 else P
+        return (Q + P) * d * s + ns * s + (qr + pr) * d * s, 2 * ((qr * P + pr * Q) if mode == 0 else 2 * P) * d
+    if name == "rpo_pool_normalize_fwd":
+        N, L, d, dt = a[4], a[5], a[6], a[7]
+        return N * L * 8 + 2 * N * d * _es(dt), 3 * N * d
+    if name == "rpo_pool_normalize_bwd":
+        N, L, d, dt = a[4], a[5], a[6], a[7]
+        dense = a[10] is not None
+        return (N * L * d * _es(dt) if dense else N * d * _es(dt)) + 2 * N * d * _es(dt), 4 * N * d
+    if name == "rpo_adamw_step":
+        n, dt = a[5], a[6]
+        return n * (2 * _es(dt) + 24), 12 * n
+    if name == "rpo_sumsq_partial":
+        n, dt = a[1], a[2]
+        return n * _es(dt), 2 * n
+    if name == "rpo_rankpo_fwd":
+        B, d, dt = a[4], a[5], a[6]
+        return 3 * B * d * _es(dt), 4 * B * d
+    if name == "rpo_rankpo_bwd":
+        B, d, dt = a[4], a[5], a[6]
+        return 6 * B * d * _es(dt), 6 * B * d
+    return 0, 0
+
+
+class TimedLib:
+    """Proxy of the ctypes library that brackets every kernel entry point with HIP events while `enabled`."""
+
+    def __init__(self, real):
+        self._real = real
+        self.enabled = False
+        self.records = []     # (name, start_event, end_event, bytes, flops)
+
+    def __getattr__(self, name):
+        fn = getattr(self._real, name)
+        if not name.startswith("rpo_") or name in ("rpo_version", "rpo_status_string", "rpo_last_hip_error", "rpo_infonce_workspace_bytes"):
+            return fn
+
+        def wrapped(*a):
+            if not self.enabled:
+                return fn(*a)
+            s = torch.cuda.current_stream()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+            rc = fn(*a)
+            e1.record(s)
+            b, f = _algo(name, a)
+            self.records.append((name, e0, e1, b, f))
+            return rc
+        return wrapped
+
+    def summary(self):
+        agg = {}
+        for name, e0, e1, b, f in self.records:
+            ms = e0.elapsed_time(e1)
+            d = agg.setdefault(name, dict(calls=0, ms=0.0, bytes=0, flops=0))
+            d["calls"] += 1
+            d["ms"] += ms
+            d["bytes"] += b
+            d["flops"] += f
+        out = []
+        for name, d in agg.items():
+            avg_us = 1e3 * d["ms"] / d["calls"]
+            gbs = d["bytes"] / d["calls"] / (avg_us * 1e-6) / 1e9
+            out.append(dict(entry=name, calls=d["calls"], avg_us=round(avg_us, 2), total_ms=round(d["ms"], 3),
+                            algo_bytes=d["bytes"] // d["calls"], algo_flops=d["flops"] // d["calls"],
+                            achieved_GBs=round(gbs, 2), frac_hbm=round(gbs / HBM_PEAK_GBS, 5)))
+        out.sort(key=lambda r: -r["total_ms"])
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------------
+def build_config(arch):
+    from rankpo_amd import encoder as PE
+    if arch == "llama-3.2-1b":
+        return PE.llama_3_2_1b_config()
+    if arch == "llama-3-8b":
+        return PE.llama_3_8b_config()
+    if arch == "bge-small":
+        return PE.bge_small_config()
+    if arch == "llama-tiny":
+        return PE.llama_config(vocab_size=32000, hidden_size=512, intermediate_size=1536, num_hidden_layers=4,
+                               num_attention_heads=8, num_key_value_heads=4, pad_token_id=0)
+    raise ValueError(arch)
+
+
+def synth_batch(cfg, B, K, Lq, Lp, seed, device):
+    """SURVEY.md §8d synthetic inputs: ids in [1000, vocab-1000), right padded, lengths in [L/2, L], one full row."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lo, hi = (1000, cfg.vocab_size - 1000) if cfg.vocab_size > 4000 else (1, cfg.vocab_size)
+    pad = cfg.pad_token_id if cfg.pad_token_id is not None else 0
+
+    def side(N, L):
+        ids = torch.randint(lo, hi, (N, L), generator=g)
+        lens = torch.randint(L // 2, L + 1, (N,), generator=g)
+        lens[0] = L
+        m = (torch.arange(L)[None, :] < lens[:, None]).long()
+        ids = ids * m + pad * (1 - m)
+        return {"input_ids": ids.to(device), "attention_mask": m.to(device)}
+    return {"query": side(B, Lq), "passage": side(B * (1 + K), Lp)}
+
+
+def sweep(lib_timed, device):
+    """Similarity + InfoNCE kernel on the scaled shapes where it is MFMA-bound."""
+    from rankpo_amd import ops
+    res = []
+    for Q, d in ((1024, 2048), (4096, 2048), (16384, 2048), (4096, 4096)):
+        P = Q
+        q = torch.nn.functional.normalize(torch.randn(Q, d, device=device), dim=-1).to(torch.bfloat16).requires_grad_(True)
+        p = torch.nn.functional.normalize(torch.randn(P, d, device=device), dim=-1).to(torch.bfloat16).requires_grad_(True)
+        for _ in range(2):
+            loss, _ = ops.infonce_loss(q, p, 0.02)
+        torch.cuda.synchronize()
+        reps = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            loss, _ = ops.infonce_loss(q, p, 0.02)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        fl = 2.0 * Q * P * d
+        res.append(dict(kernel="rpo_infonce_fwd", Q=Q, P=P, d=d, dtype="bf16", ms=round(ms, 4),
+                        achieved_TFLOPs=round(fl / ms / 1e9, 1), frac_mfma=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)))
+        del q, p, loss
+    return res
+
+
+def cpu_baseline(model, cfg, temperature, sample=(160, 512, 2)):
+    """The oracle's training micro-step (encoder fwd+bwd + scoring, float32, eager) on the host cores, on a bounded
+    sample of the workload: 1 query of Lq_s tokens + G_s passages of Lp_s tokens through the SAME architecture and
+    weights.  pairs/s is extrapolated linearly in tokens to the full-length pair (optimistic for the CPU: the
+    quadratic attention term is ignored)."""
+    from oracle import encoder_ref as E
+    Lq_s, Lp_s, G_s = sample
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))      # the GPU box gives one GPU's job a 16-core share; more threads only thrash
+    torch.set_num_threads(cores)
+    w = {k: v.detach().to("cpu", torch.float32).requires_grad_(True) for k, v in model.model.state_dict().items()}
+    cd = cfg.to_dict()
+    g = torch.Generator().manual_seed(7)
+    mk = lambda N, L: {"input_ids": torch.randint(1000, cfg.vocab_size - 1000, (N, L), generator=g),
+                       "attention_mask": torch.ones(N, L, dtype=torch.long)}
+    warm = {"query": mk(1, 16), "passage": mk(G_s, 16)}
+    E.contrastive_step(w, cd, warm, temperature)[0].backward()
+    batch = {"query": mk(1, Lq_s), "passage": mk(G_s, Lp_s)}
+    t0 = time.perf_counter()
+    loss = E.contrastive_step(w, cd, batch, temperature)[0]
+    loss.backward()
+    dt = time.perf_counter() - t0
+    return dt, Lq_s + G_s * Lp_s, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--ckpt-layers", type=int, default=-1, help="checkpoint the first k blocks (-1 = all, 0 = none)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
+                         f"--nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    import rankpo_amd
+    from rankpo_amd import _lib
+    from rankpo_amd.encoder import build_encoder
+    from rankpo_amd.train_step import TrainStep
+
+    arch, B, K, Lq, Lp, temperature, dtn = WORKLOADS[args.workload]
+    dtype = torch.bfloat16 if dtn == "bf16" else torch.float32
+    cfg = build_config(arch)
+    torch.manual_seed(0)                      # identical weights on every rank (data parallel replicas)
+    with torch.device(device):
+        enc = build_encoder(cfg)
+    enc = enc.to(dtype)
+    model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
+                                        negatives_cross_device=(world > 1)).train()
+    if args.ckpt_layers != 0 and hasattr(enc, "layers"):
+        model.gradient_checkpointing_enable(layers=None if args.ckpt_layers < 0 else args.ckpt_layers)
+    elif args.ckpt_layers != 0:
+        model.gradient_checkpointing_enable()
+
+    timed = TimedLib(_lib.load())
+    if not args.no_kernel_timing:
+        _lib._lib = timed
+    ts = TrainStep(model.parameters(), lambda b: model(**b)["loss"], lr=1e-5, max_grad_norm=1.0,
+                   gradient_accumulation_steps=1, total_steps=max(10, args.steps + args.warmup), warmup_ratio=0.1)
+
+    nb = args.steps + args.warmup
+    batches = [synth_batch(cfg, B, K, Lq, Lp, 1234 + rank * 1000 + i, device) for i in range(nb)]
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    note(f"model + {nb} synthetic batches ready ({arch}, world {world}); warmup {args.warmup} steps")
+    losses = []
+    for i in range(args.warmup):
+        losses.append(ts.step(batches[i]))
+        torch.cuda.synchronize()
+        note(f"warmup step {i} done, loss {float(losses[-1]):.4f}, peak mem {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timed.enabled = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for i in range(args.warmup, nb):
+        losses.append(ts.step(batches[i]))
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timed.enabled = False
+    note(f"timed {args.steps} steps in {elapsed:.3f} s")
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    pairs = world * B * (1 + K) * args.steps
+    peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
+
+    if rank == 0:
+        kernels = [] if args.no_kernel_timing else timed.summary()
+        out = {
+            "metric": "query-passage pairs/sec", "value": round(pairs / elapsed, 3), "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": dtn, "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {arch} contrastive, B={B}/GPU, K={K}, q_len={Lq}, p_len={Lp}, "
+                                   f"T={temperature}, in-batch negs" + (", cross-device negs" if world > 1 else ""),
+                       "global_batch": world * B, "pairs_per_step": world * B * (1 + K),
+                       "parallelism": f"dp{world}", "optimizer": "AdamW(flat, HIP) + clip 1.0, GAS=1",
+                       "grad_checkpointing": "all" if args.ckpt_layers < 0 else f"first {args.ckpt_layers}",
+                       "weights": "random init (seed 0)"},
+            "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
+            "peak_mem_GiB": round(peak_mem, 2),
+        }
+        if kernels:
+            top = kernels[0]
+            out["roofline"] = {"kernel": top["entry"], "bound": "hbm", "achieved": top["achieved_GBs"],
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": None,
+                               "avg_us": top["avg_us"], "algo_bytes": top["algo_bytes"]}
+            out["kernels"] = kernels
+        if world == 1 and not args.no_sweep:
+            out["roofline_sweep"] = sweep(timed, device)
+            note("sweep done")
+        if world == 1 and not args.no_cpu_baseline:
+            note("cpu baseline (oracle on host cores) ...")
+            dt, toks, cores = cpu_baseline(model, cfg, temperature)
+            toks_per_pair = Lp + Lq / (1 + K)
+            out["cpu_baseline"] = {"value": round(toks / dt / toks_per_pair, 5), "unit": "pairs/s", "cores": cores,
+                                   "kind": "port",
+                                   "sample": f"oracle (eager torch f32) fwd+bwd of 1 query x 160 tok + 2 passages x 512 tok "
+                                             f"through the same {arch} weights: {toks} tokens in {dt:.2f} s; pairs/s "
+                                             f"extrapolated linearly in tokens to {toks_per_pair:.0f} tokens per "
+                                             f"full-length pair"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

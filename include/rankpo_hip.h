@@ -41,6 +41,8 @@ typedef enum { RPO_LOSS_SIGMOID = 0, RPO_LOSS_HINGE = 1 } rpo_loss_type;
 
 int rpo_version(void);
 const char* rpo_status_string(int status);
+/* hipGetErrorString of the HIP error behind the calling thread's most recent RPO_ERR_LAUNCH (diagnostics). */
+const char* rpo_last_hip_error(void);
 
 /* ---------------------------------------------------------------------------------------------
  * (1) pooling + L2 normalisation.

@@ -41,6 +41,7 @@ _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size
 SIGNATURES = {
     "rpo_version": (C.c_int, []),
     "rpo_status_string": (C.c_char_p, [C.c_int]),
+    "rpo_last_hip_error": (C.c_char_p, []),
     "rpo_pool_normalize_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "rpo_pool_normalize_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "rpo_infonce_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32]),
@@ -66,6 +67,10 @@ def load():
             f"{LIB_PATH} not found: the HIP scoring library is not built.  Run "
             "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C rankpo_amd/csrc`).  "
             "rankpo_amd has no CPU fallback for its hot path.")
+    # PyTorch ships its own libamdhip64.so.7; the process must use ONE HIP runtime, the one that owns torch's
+    # streams and allocations.  Importing torch first makes the dynamic loader bind librankpo_hip.so's
+    # libamdhip64.so.7 dependency to that already-loaded copy instead of /opt/rocm's.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         try:
@@ -81,4 +86,6 @@ def load():
 def check(rc: int, what: str):
     if rc != RPO_OK:
         msg = load().rpo_status_string(rc).decode()
+        if rc == -4:
+            msg += ": " + load().rpo_last_hip_error().decode()
         raise RankPOHipError(f"{what} failed: {msg} (status {rc})")

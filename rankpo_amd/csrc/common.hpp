@@ -97,7 +97,21 @@ __device__ __forceinline__ float block_sum(float x, float* scratch) {
     return t;
 }
 
-// ---- host-side helpers -----------------------------------------------------------------------------
-static inline int rpo_launch_status() { return hipGetLastError() == hipSuccess ? RPO_OK : RPO_ERR_LAUNCH; }
+// ---- host-side helpers
+// hipGetLastError() is sticky per host thread and also reports benign codes left behind by OTHER users of the
+// runtime (e.g. hipErrorNotReady from PyTorch's event queries): clear it right before our launch so that the
+// status we return describes this launch only.
+#define RPO_LAUNCH(...)                   \
+    do {                                  \
+        (void)hipGetLastError();          \
+        hipLaunchKernelGGL(__VA_ARGS__);  \
+    } while (0)
+extern thread_local int rpo_tls_last_hip_error;   // defined in infonce.hip; read by rpo_last_hip_error()
+static inline int rpo_launch_status() {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return RPO_OK;
+    rpo_tls_last_hip_error = (int)e;
+    return RPO_ERR_LAUNCH;
+}
 static inline bool rpo_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline int64_t rpo_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -627,7 +627,7 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         float* raw = (float*)(wsb + pl.off_raw);
         int rc = rpo_launch_grouped_dots(q, p, Q, G, d, dtype, raw, st);
         if (rc != RPO_OK) return rc;
-        hipLaunchKernelGGL(first_finalize_kernel<T>, dim3(1), dim3(kFinThreads), 0, st, raw, Q, G, temperature,
+        RPO_LAUNCH(first_finalize_kernel<T>, dim3(1), dim3(kFinThreads), 0, st, raw, Q, G, temperature,
                            scale, (T*)scores_out, lse_out, loss_out);
         return rpo_launch_status();
     }
@@ -639,14 +639,14 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
                                 kTileLdsBytes);
             attr_set = true;
         }
-        hipLaunchKernelGGL(sim_tile_kernel<T>, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kTileThreads), kTileLdsBytes,
+        RPO_LAUNCH(sim_tile_kernel<T>, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kTileThreads), kTileLdsBytes,
                            st, (const T*)q, (const T*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
                            (T*)scores_out, partial, pl.nPt, pl.nQt);
     } else if (pl.path == PATH_SKINNY) {
         const dim3 grid((unsigned)pl.nPb), block(kSkinnyThreads);
         const int nq = (int)rpo_cdiv(Q, 16);
 #define RPO_SKINNY(NQ)                                                                                       \
-    hipLaunchKernelGGL((sim_skinny_kernel<T, NQ>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d,     \
+    RPO_LAUNCH((sim_skinny_kernel<T, NQ>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d,     \
                        temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial)
         switch (nq) {
             case 1: RPO_SKINNY(1); break;
@@ -656,14 +656,14 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         }
 #undef RPO_SKINNY
     } else {
-        hipLaunchKernelGGL(sim_rowwise_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q, (const T*)p, Q,
+        RPO_LAUNCH(sim_rowwise_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q, (const T*)p, Q,
                            P, d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial);
     }
     int rc = rpo_launch_status();
     if (rc != RPO_OK || !do_stats) return rc;
     unsigned* ticket = (unsigned*)wsb;
     if (pl.nFin > 1) (void)hipMemsetAsync(ticket, 0, 16, st);
-    hipLaunchKernelGGL(ce_finalize_kernel<T>, dim3((unsigned)pl.nFin), dim3(kFinThreads), 0, st, partial,
+    RPO_LAUNCH(ce_finalize_kernel<T>, dim3((unsigned)pl.nFin), dim3(kFinThreads), 0, st, partial,
                        (const T*)scores_out, Q, P, pl.nPb, P / Q, lse_out, loss_out,
                        (float*)(wsb + pl.off_blocksum), ticket);
     return rpo_launch_status();
@@ -674,7 +674,7 @@ int bwd_impl(const void* q, const void* p, const void* scores, const float* lse,
              int64_t P, int64_t d, float temperature, int target_mode, int64_t q_row0, int64_t q_rows,
              int64_t p_row0, int64_t p_rows, void* dq, void* dp, hipStream_t st) {
     if (target_mode == RPO_TARGET_FIRST) {
-        hipLaunchKernelGGL(infonce_first_bwd_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q,
+        RPO_LAUNCH(infonce_first_bwd_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q,
                            (const T*)p, (const T*)scores, lse, grad_loss, Q, P / Q, d, temperature, q_row0, q_rows,
                            p_row0, p_rows, (T*)dq, (T*)dp);
         return rpo_launch_status();
@@ -687,14 +687,14 @@ int bwd_impl(const void* q, const void* p, const void* scores, const float* lse,
         const int nchunk = (int)rpo_cdiv(d, 64 * V);
         const int64_t blocks = ((dq ? q_rows : 0) + (dp ? p_rows : 0)) * nchunk;
         if (blocks <= 0) return RPO_OK;
-        hipLaunchKernelGGL(infonce_bwd_valu_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, st, (const T*)q,
+        RPO_LAUNCH(infonce_bwd_valu_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, st, (const T*)q,
                            (const T*)p, (const T*)scores, lse, grad_loss, Q, P, d, temperature, group, q_row0,
                            q_rows, p_row0, p_rows, (T*)dq, (T*)dp, nchunk);
     } else {
         const int nchunk = (int)rpo_cdiv(d, 64);
         const int64_t blocks = ((dq ? q_rows : 0) + (dp ? p_rows : 0)) * nchunk;
         if (blocks <= 0) return RPO_OK;
-        hipLaunchKernelGGL(infonce_bwd_scalar_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, st, (const T*)q,
+        RPO_LAUNCH(infonce_bwd_scalar_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, st, (const T*)q,
                            (const T*)p, (const T*)scores, lse, grad_loss, Q, P, d, temperature, group, q_row0,
                            q_rows, p_row0, p_rows, (T*)dq, (T*)dp, nchunk);
     }
@@ -762,7 +762,13 @@ extern "C" int rpo_infonce_bwd(const void* q, const void* p, const void* scores,
                             p_rows, dq_out, dp_out, st);
 }
 
+thread_local int rpo_tls_last_hip_error = 0;
+
 extern "C" int rpo_version(void) { return 100; }
+
+extern "C" const char* rpo_last_hip_error(void) {
+    return hipGetErrorString((hipError_t)rpo_tls_last_hip_error);
+}
 
 extern "C" const char* rpo_status_string(int status) {
     switch (status) {

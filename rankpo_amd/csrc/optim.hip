@@ -103,11 +103,11 @@ extern "C" int rpo_adamw_step(void* param, float* master, const void* grad, floa
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RPO_DT_BF16)
-        hipLaunchKernelGGL(adamw_kernel<bf16_t>, dim3((unsigned)blocks), dim3(kOptThreads), 0, st, (bf16_t*)param,
+        RPO_LAUNCH(adamw_kernel<bf16_t>, dim3((unsigned)blocks), dim3(kOptThreads), 0, st, (bf16_t*)param,
                            master, (const bf16_t*)grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
                            bias_corr1, bias_corr2, grad_scale);
     else if (dtype == RPO_DT_F32)
-        hipLaunchKernelGGL(adamw_kernel<float>, dim3((unsigned)blocks), dim3(kOptThreads), 0, st, (float*)param,
+        RPO_LAUNCH(adamw_kernel<float>, dim3((unsigned)blocks), dim3(kOptThreads), 0, st, (float*)param,
                            master, (const float*)grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay,
                            bias_corr1, bias_corr2, grad_scale);
     else
@@ -121,10 +121,10 @@ extern "C" int rpo_sumsq_partial(const void* x, int64_t n, int dtype, float* par
     if (!rpo_aligned16(x)) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RPO_DT_BF16)
-        hipLaunchKernelGGL(sumsq_kernel<bf16_t>, dim3((unsigned)nblocks), dim3(kOptThreads), 0, st, (const bf16_t*)x, n,
+        RPO_LAUNCH(sumsq_kernel<bf16_t>, dim3((unsigned)nblocks), dim3(kOptThreads), 0, st, (const bf16_t*)x, n,
                            partial_out);
     else if (dtype == RPO_DT_F32)
-        hipLaunchKernelGGL(sumsq_kernel<float>, dim3((unsigned)nblocks), dim3(kOptThreads), 0, st, (const float*)x, n,
+        RPO_LAUNCH(sumsq_kernel<float>, dim3((unsigned)nblocks), dim3(kOptThreads), 0, st, (const float*)x, n,
                            partial_out);
     else
         return RPO_ERR_INVALID_ARG;

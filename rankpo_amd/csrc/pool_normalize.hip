@@ -164,7 +164,7 @@ template <typename T>
 int launch_fwd(const void* h, int64_t sn, int64_t sl, const int64_t* mask, int64_t N, int64_t L, int64_t d,
                int pool_mode, int normalize, float eps, void* out, int32_t* idx_out, float* norm_out,
                hipStream_t st) {
-    hipLaunchKernelGGL(pool_normalize_fwd_kernel<T>, dim3((unsigned)N), dim3(kPoolThreads), 0, st,
+    RPO_LAUNCH(pool_normalize_fwd_kernel<T>, dim3((unsigned)N), dim3(kPoolThreads), 0, st,
                        (const T*)h, sn, sl, mask, L, d, pool_mode, normalize, eps, (T*)out, idx_out, norm_out);
     return rpo_launch_status();
 }
@@ -182,7 +182,7 @@ int launch_bwd(const void* g, const void* y, const int32_t* idx, const float* no
         if (bx > cap) bx = cap;
         if (bx < 1) bx = 1;
     }
-    hipLaunchKernelGGL(pool_normalize_bwd_kernel<T>, dim3((unsigned)bx, (unsigned)N), dim3(kPoolThreads), 0, st,
+    RPO_LAUNCH(pool_normalize_bwd_kernel<T>, dim3((unsigned)bx, (unsigned)N), dim3(kPoolThreads), 0, st,
                        (const T*)g, (const T*)y, idx, norm, L, d, normalize, eps, (T*)dh, (T*)drow,
                        vec_ok ? 1 : 0);
     return rpo_launch_status();

@@ -170,10 +170,10 @@ __global__ __launch_bounds__(kDotThreads) void rankpo_bwd_kernel(const T* __rest
 int rpo_launch_grouped_dots(const void* q, const void* p, int64_t B, int64_t G, int64_t d, int dtype, float* out,
                             hipStream_t st) {
     if (dtype == RPO_DT_F32)
-        hipLaunchKernelGGL(grouped_dots_kernel<float>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const float*)q,
+        RPO_LAUNCH(grouped_dots_kernel<float>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const float*)q,
                            (const float*)p, G, d, out);
     else
-        hipLaunchKernelGGL(grouped_dots_kernel<bf16_t>, dim3((unsigned)B), dim3(kDotThreads), 0, st,
+        RPO_LAUNCH(grouped_dots_kernel<bf16_t>, dim3((unsigned)B), dim3(kDotThreads), 0, st,
                            (const bf16_t*)q, (const bf16_t*)p, G, d, out);
     return rpo_launch_status();
 }
@@ -191,7 +191,7 @@ extern "C" int rpo_rankpo_fwd(const void* q, const void* p, const float* ref_cho
     hipStream_t st = (hipStream_t)stream;
     int rc = rpo_launch_grouped_dots(q, p, B, 2, d, dtype, scores_out, st);
     if (rc != RPO_OK) return rc;
-    hipLaunchKernelGGL(rankpo_finalize_kernel, dim3(1), dim3(kFinThreads), 0, st, scores_out, ref_chosen,
+    RPO_LAUNCH(rankpo_finalize_kernel, dim3(1), dim3(kFinThreads), 0, st, scores_out, ref_chosen,
                        ref_rejected, B, *params, losses_out, loss_out, metrics_out, dscores_out);
     return rpo_launch_status();
 }
@@ -202,10 +202,10 @@ extern "C" int rpo_rankpo_bwd(const void* q, const void* p, const float* dscores
     if (B <= 0 || d <= 0 || B > INT32_MAX) return RPO_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RPO_DT_F32)
-        hipLaunchKernelGGL(rankpo_bwd_kernel<float>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const float*)q,
+        RPO_LAUNCH(rankpo_bwd_kernel<float>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const float*)q,
                            (const float*)p, dscores, grad_loss, d, (float*)dq_out, (float*)dp_out);
     else if (dtype == RPO_DT_BF16)
-        hipLaunchKernelGGL(rankpo_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const bf16_t*)q,
+        RPO_LAUNCH(rankpo_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const bf16_t*)q,
                            (const bf16_t*)p, dscores, grad_loss, d, (bf16_t*)dq_out, (bf16_t*)dp_out);
     else
         return RPO_ERR_INVALID_ARG;

@@ -1,0 +1,143 @@
+"""Cross-device pieces of the hot path: one process per GPU, `torch.distributed` (backend "nccl" == RCCL over xGMI
+on ROCm; "gloo" in the CPU tests).
+
+* `all_gather_with_local_grad`  -- reference `distributed_gather` semantics (modeling.py:331-404): rank-major
+  concatenation; backward hands each rank the gradient of ITS OWN slice, no backward collective.
+* `EmbeddingGather` / `gather_embeddings` -- what `ModelForTraining.forward` uses: the gathered matrices are
+  constants for autograd (the InfoNCE kernel produces gradients for the local rows directly), so the gather is a
+  plain asynchronous collective that can be in flight while the other tower is still being encoded.
+* `FlatGradAllReducer` -- data-parallel gradient mean over flat buckets (replaces DeepSpeed ZeRO-1's reduction;
+  SURVEY.md §8e): buckets are all-reduced asynchronously as soon as backward has produced them.
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def _all_gather_into(out: torch.Tensor, x: torch.Tensor, async_op=False):
+    """out: [W, *x.shape] contiguous."""
+    if dist.get_backend() == "nccl":
+        return dist.all_gather_into_tensor(out.view(-1), x.reshape(-1), async_op=async_op)
+    return dist.all_gather(list(out.unbind(0)), x, async_op=async_op)
+
+
+class _AllGatherLocalGrad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        W = dist.get_world_size()
+        out = torch.empty((W,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        _all_gather_into(out, x.contiguous())
+        ctx.n0 = x.shape[0]
+        return out.view((W * x.shape[0],) + tuple(x.shape[1:]))
+
+    @staticmethod
+    def backward(ctx, g):
+        r = dist.get_rank()
+        return g[r * ctx.n0:(r + 1) * ctx.n0].contiguous()
+
+
+def all_gather_with_local_grad(x: torch.Tensor) -> torch.Tensor:
+    return _AllGatherLocalGrad.apply(x)
+
+
+class EmbeddingGather:
+    """Asynchronous rank-major all-gather of a [n, d] embedding block (no autograd)."""
+
+    def __init__(self, x: torch.Tensor):
+        W = dist.get_world_size()
+        self.x = x.detach().contiguous()
+        self.out = torch.empty((W,) + tuple(self.x.shape), dtype=x.dtype, device=x.device)
+        self.work = _all_gather_into(self.out, self.x, async_op=True)
+
+    def wait(self) -> torch.Tensor:
+        if self.work is not None:
+            self.work.wait()          # NCCL: makes the current stream wait for the collective; no host sync
+            self.work = None
+        return self.out.view((-1,) + tuple(self.x.shape[1:]))
+
+
+def gather_embeddings(q: torch.Tensor, p: torch.Tensor):
+    """Gather q and p across ranks; returns (q_all [W*B, d], p_all [W*BG, d]) as autograd constants."""
+    gq, gp = EmbeddingGather(q), EmbeddingGather(p)
+    return gq.wait(), gp.wait()
+
+
+class FlatGradAllReducer:
+    """Parameters' .grad tensors are views into ONE flat buffer per dtype; the buffer is cut into buckets of
+    ~`bucket_mb` MiB (large: xGMI is point-to-point, few big collectives beat many small ones) that are
+    all-reduced (mean) on RCCL's stream as soon as every gradient inside has been accumulated."""
+
+    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 512.0, world_size: Optional[int] = None):
+        self.params = [p for p in params if p.requires_grad]
+        self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        assert self.params, "no trainable parameters"
+        dtype, device = self.params[0].dtype, self.params[0].device
+        assert all(p.dtype == dtype and p.device == device for p in self.params), "one dtype/device per reducer"
+        # backward produces gradients roughly in reverse registration order: lay the flat buffer out that way
+        order = list(reversed(self.params))
+        offs, n = [], 0
+        for p in order:
+            offs.append(n)
+            n += (p.numel() + 7) // 8 * 8            # keep every view 16-byte aligned
+        self.numel = n
+        self.flat = torch.zeros(n, dtype=dtype, device=device)
+        self.order, self.offsets = order, offs
+        for p, o in zip(order, offs):
+            p.grad = self.flat[o:o + p.numel()].view_as(p)
+        per = max(1, int(bucket_mb * 2 ** 20 / self.flat.element_size()))
+        self.buckets = []                              # (start, end, [param indices])
+        start, idxs = 0, []
+        for i, (p, o) in enumerate(zip(order, offs)):
+            idxs.append(i)
+            end = o + (p.numel() + 7) // 8 * 8
+            if end - start >= per or i == len(order) - 1:
+                self.buckets.append((start, end, idxs))
+                start, idxs = end, []
+        self._bucket_of = {}
+        for b, (_, _, ids) in enumerate(self.buckets):
+            for i in ids:
+                self._bucket_of[i] = b
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        self._armed = False
+        if self.world > 1:
+            for i, p in enumerate(order):
+                p.register_post_accumulate_grad_hook(self._make_hook(i))
+
+    def _make_hook(self, i):
+        def hook(param):
+            # autograd may have replaced .grad; keep the flat view authoritative
+            o = self.offsets[i]
+            view = self.flat[o:o + param.numel()].view_as(param)
+            if param.grad is not None and param.grad.data_ptr() != view.data_ptr():
+                view.copy_(param.grad)
+                param.grad = view
+            if not self._armed:
+                return
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                s, e, _ = self.buckets[b]
+                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        return hook
+
+    def arm(self):
+        """Call before the LAST backward of an accumulation window: buckets then reduce as they complete."""
+        self._armed = self.world > 1
+        self._pending = [len(ids) for _, _, ids in self.buckets]
+        self._works = []
+
+    def finish(self):
+        """Wait for the bucket all-reduces (stream wait, no host sync).  The 1/world mean factor is folded into
+        the optimizer's grad scale (returned)."""
+        for w in self._works:
+            w.wait()
+        self._works = []
+        self._armed = False
+        return 1.0 / self.world
+
+    def zero_(self):
+        self.flat.zero_()

@@ -1,0 +1,420 @@
+"""From-scratch transformer encoders that run under PyTorch-ROCm (the north star keeps the encoder there; the
+hand-written HIP starts at the pooled embedding).  They stand where the reference calls HF `AutoModel`
+(modeling.py:175-178, 219; rankpo_trainer.py:402; run_rankpo.py:120): same call signature
+`model(input_ids=..., attention_mask=..., return_dict=True).last_hidden_state`, same `config.architectures`,
+same parameter names as HF `LlamaModel` / `BertModel`, so checkpoints in HF safetensors layout load and save.
+
+MI355X notes
+  * Llama + right padding (what both reference collators produce, data_utils.py:64-70, 205-212): a causal model
+    never lets a real token see the pad tokens behind it, so the padding mask is dropped and attention runs as
+    pure causal flash attention; only pad positions (never pooled) differ from a masked run.
+  * `forward_pooled` skips the final RMSNorm on every position but the pooled one.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+from types import SimpleNamespace
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.utils.checkpoint import checkpoint
+
+
+class EncoderConfig(SimpleNamespace):
+    """Minimal stand-in for a HF PretrainedConfig (attribute access + to_dict)."""
+
+    def to_dict(self):
+        return dict(self.__dict__)
+
+    @classmethod
+    def from_json_file(cls, path):
+        with open(path) as f:
+            return cls(**json.load(f))
+
+
+def llama_config(**kw) -> EncoderConfig:
+    d = dict(architectures=["LlamaModel"], model_type="llama", vocab_size=128256, hidden_size=2048,
+             intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32, num_key_value_heads=8,
+             head_dim=None, rms_norm_eps=1e-5, rope_theta=500000.0, rope_scaling=None,
+             max_position_embeddings=131072, pad_token_id=None, attention_bias=False, mlp_bias=False,
+             initializer_range=0.02, hidden_act="silu", padding_side="right")
+    d.update(kw)
+    if d["head_dim"] is None:
+        d["head_dim"] = d["hidden_size"] // d["num_attention_heads"]
+    return EncoderConfig(**d)
+
+
+LLAMA3_ROPE = dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                   original_max_position_embeddings=8192)
+
+
+def llama_3_2_1b_config(**kw):
+    """Llama-3.2-1B architecture (BASELINE.json configs[1]); +7 special tokens as run_contrastive.py:132-142."""
+    base = dict(vocab_size=128256 + 7, hidden_size=2048, intermediate_size=8192, num_hidden_layers=16,
+                num_attention_heads=32, num_key_value_heads=8, head_dim=64, rope_theta=500000.0,
+                rope_scaling=dict(LLAMA3_ROPE), rms_norm_eps=1e-5, pad_token_id=128004)
+    base.update(kw)
+    return llama_config(**base)
+
+
+def llama_3_8b_config(**kw):
+    base = dict(vocab_size=128256 + 7, hidden_size=4096, intermediate_size=14336, num_hidden_layers=32,
+                num_attention_heads=32, num_key_value_heads=8, head_dim=128, rope_theta=500000.0,
+                rope_scaling=None, rms_norm_eps=1e-5, max_position_embeddings=8192, pad_token_id=128004)
+    base.update(kw)
+    return llama_config(**base)
+
+
+def bert_config(**kw) -> EncoderConfig:
+    d = dict(architectures=["BertModel"], model_type="bert", vocab_size=30522, hidden_size=384,
+             intermediate_size=1536, num_hidden_layers=12, num_attention_heads=12, max_position_embeddings=512,
+             type_vocab_size=2, layer_norm_eps=1e-12, pad_token_id=0, hidden_act="gelu", initializer_range=0.02,
+             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+    d.update(kw)
+    return EncoderConfig(**d)
+
+
+def bge_small_config(**kw):
+    """BAAI/bge-small-en architecture (BASELINE.json configs[0])."""
+    return bert_config(**kw)
+
+
+class EncoderOutput(dict):
+    """`.last_hidden_state` + dict access, like transformers' ModelOutput."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+# ----------------------------------------------------------------------------------------------------
+# Llama
+# ----------------------------------------------------------------------------------------------------
+def _rope_inv_freq(cfg) -> torch.Tensor:
+    dim = cfg.head_dim
+    inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.float64) / dim))
+    rs = getattr(cfg, "rope_scaling", None)
+    if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+        factor, lo, hi = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"]
+        old = rs["original_max_position_embeddings"]
+        wavelen = 2 * math.pi / inv
+        low_wl, high_wl = old / lo, old / hi
+        scaled = torch.where(wavelen > low_wl, inv / factor, inv)
+        smooth = (old / wavelen - lo) / (hi - lo)
+        mid = (1 - smooth) * inv / factor + smooth * inv
+        is_mid = (wavelen <= low_wl) & (wavelen >= high_wl)
+        inv = torch.where(is_mid, mid, scaled)
+    return inv.to(torch.float32)
+
+
+class RMSNorm(nn.Module):
+    def __init__(self, dim, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.eps = eps
+
+    def forward(self, x):
+        return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
+
+
+def _rotate_half(x):
+    x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
+    return torch.cat((-x2, x1), dim=-1)
+
+
+class LlamaAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.nh, self.nkv, self.hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        b = bool(cfg.attention_bias)
+        self.q_proj = nn.Linear(cfg.hidden_size, self.nh * self.hd, bias=b)
+        self.k_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, bias=b)
+        self.v_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, bias=b)
+        self.o_proj = nn.Linear(self.nh * self.hd, cfg.hidden_size, bias=b)
+
+    def forward(self, x, cos, sin, attn_mask):
+        N, L, _ = x.shape
+        q = self.q_proj(x).view(N, L, self.nh, self.hd).transpose(1, 2)
+        k = self.k_proj(x).view(N, L, self.nkv, self.hd).transpose(1, 2)
+        v = self.v_proj(x).view(N, L, self.nkv, self.hd).transpose(1, 2)
+        q = q * cos + _rotate_half(q) * sin
+        k = k * cos + _rotate_half(k) * sin
+        if attn_mask is None:
+            o = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=self.nkv != self.nh)
+        else:
+            o = F.scaled_dot_product_attention(q, k, v, attn_mask=attn_mask, enable_gqa=self.nkv != self.nh)
+        return self.o_proj(o.transpose(1, 2).reshape(N, L, self.nh * self.hd))
+
+
+class LlamaMLP(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        b = bool(getattr(cfg, "mlp_bias", False))
+        self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=b)
+        self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=b)
+        self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=b)
+
+    def forward(self, x):
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+
+
+class LlamaLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self_attn = LlamaAttention(cfg)
+        self.mlp = LlamaMLP(cfg)
+        self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+        self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
+
+    def forward(self, x, cos, sin, attn_mask):
+        x = x + self.self_attn(self.input_layernorm(x), cos, sin, attn_mask)
+        return x + self.mlp(self.post_attention_layernorm(x))
+
+
+class LlamaEncoder(nn.Module):
+    """Decoder-only Llama stack without lm_head (== HF `LlamaModel`)."""
+
+    def __init__(self, config: EncoderConfig):
+        super().__init__()
+        self.config = config
+        self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
+        self.layers = nn.ModuleList(LlamaLayer(config) for _ in range(config.num_hidden_layers))
+        self.norm = RMSNorm(config.hidden_size, config.rms_norm_eps)
+        self.register_buffer("inv_freq", _rope_inv_freq(config), persistent=False)
+        self.gradient_checkpointing = False
+        self.checkpoint_layers = None      # None = all layers when gradient_checkpointing, else the first k
+        self.apply(self._init)
+
+    def _init(self, m):
+        std = self.config.initializer_range
+        if isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, 0.0, std)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, 0.0, std)
+
+    def gradient_checkpointing_enable(self, layers: Optional[int] = None, **_):
+        """`layers`: checkpoint only the first `layers` blocks (288 GB of HBM lets the rest keep activations)."""
+        self.gradient_checkpointing = True
+        self.checkpoint_layers = layers
+
+    def gradient_checkpointing_disable(self):
+        self.gradient_checkpointing = False
+
+    def resize_token_embeddings(self, n):
+        old = self.embed_tokens
+        if n == old.num_embeddings:
+            return old
+        new = nn.Embedding(n, old.embedding_dim, device=old.weight.device, dtype=old.weight.dtype)
+        nn.init.normal_(new.weight, 0.0, self.config.initializer_range)
+        k = min(n, old.num_embeddings)
+        with torch.no_grad():
+            new.weight[:k] = old.weight[:k]
+        self.embed_tokens = new
+        self.config.vocab_size = n
+        return new
+
+    def _rope(self, L, device, dtype):
+        # same op order as HF LlamaRotaryEmbedding: f32 outer product, cat, cos/sin, cast
+        pos = torch.arange(L, device=device, dtype=torch.float32)
+        freqs = torch.outer(pos, self.inv_freq.to(device=device, dtype=torch.float32))
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.cos().to(dtype)[None, None], emb.sin().to(dtype)[None, None]
+
+    def _mask(self, attention_mask, L, dtype):
+        if attention_mask is None or getattr(self.config, "padding_side", "right") == "right":
+            return None                                        # pure causal (module docstring)
+        keep = attention_mask.to(torch.bool)[:, None, None, :]
+        causal = torch.ones(L, L, dtype=torch.bool, device=attention_mask.device).tril()[None, None]
+        return keep & causal
+
+    def hidden_states(self, input_ids, attention_mask=None):
+        """Output of the last block, BEFORE the final RMSNorm."""
+        x = self.embed_tokens(input_ids)
+        N, L, _ = x.shape
+        cos, sin = self._rope(L, x.device, x.dtype)
+        mask = self._mask(attention_mask, L, x.dtype)
+        ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
+        nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
+        for i, layer in enumerate(self.layers):
+            if ck and i < nck:
+                x = checkpoint(layer, x, cos, sin, mask, use_reentrant=False)
+            else:
+                x = layer(x, cos, sin, mask)
+        return x
+
+    def forward(self, input_ids=None, attention_mask=None, return_dict=True, **_):
+        h = self.norm(self.hidden_states(input_ids, attention_mask))
+        return EncoderOutput(last_hidden_state=h) if return_dict else (h,)
+
+
+# ----------------------------------------------------------------------------------------------------
+# BERT (BGE / config 1)
+# ----------------------------------------------------------------------------------------------------
+class BertEmbeddings(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(cfg.vocab_size, cfg.hidden_size, padding_idx=cfg.pad_token_id)
+        self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, cfg.hidden_size)
+        self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+    def forward(self, input_ids, token_type_ids=None):
+        L = input_ids.shape[1]
+        pos = torch.arange(L, device=input_ids.device)
+        tt = self.token_type_embeddings.weight[0] if token_type_ids is None else self.token_type_embeddings(token_type_ids)
+        return self.LayerNorm(self.word_embeddings(input_ids) + tt + self.position_embeddings(pos)[None])
+
+
+class _BertSelf(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.nh = cfg.num_attention_heads
+        self.query = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.key = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.value = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+
+
+class _BertSelfOutput(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class BertAttention(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.self = _BertSelf(cfg)
+        self.output = _BertSelfOutput(cfg)
+
+    def forward(self, x, mask):
+        N, L, D = x.shape
+        nh = self.self.nh
+        q = self.self.query(x).view(N, L, nh, D // nh).transpose(1, 2)
+        k = self.self.key(x).view(N, L, nh, D // nh).transpose(1, 2)
+        v = self.self.value(x).view(N, L, nh, D // nh).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(N, L, D)
+        return self.output.LayerNorm(self.output.dense(o) + x)
+
+
+class _Dense(nn.Module):
+    def __init__(self, i, o):
+        super().__init__()
+        self.dense = nn.Linear(i, o)
+
+
+class _BertOutput(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.dense = nn.Linear(cfg.intermediate_size, cfg.hidden_size)
+        self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+
+
+class BertLayer(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.attention = BertAttention(cfg)
+        self.intermediate = _Dense(cfg.hidden_size, cfg.intermediate_size)
+        self.output = _BertOutput(cfg)
+
+    def forward(self, x, mask):
+        x = self.attention(x, mask)
+        h = F.gelu(self.intermediate.dense(x))
+        return self.output.LayerNorm(self.output.dense(h) + x)
+
+
+class _BertStack(nn.Module):
+    def __init__(self, cfg):
+        super().__init__()
+        self.layer = nn.ModuleList(BertLayer(cfg) for _ in range(cfg.num_hidden_layers))
+
+
+class BertEncoder(nn.Module):
+    """== HF `BertModel` without the pooler (the reference only reads last_hidden_state[:, 0], modeling.py:232)."""
+
+    def __init__(self, config: EncoderConfig):
+        super().__init__()
+        self.config = config
+        self.embeddings = BertEmbeddings(config)
+        self.encoder = _BertStack(config)
+        self.gradient_checkpointing = False
+        self.apply(self._init)
+
+    def _init(self, m):
+        std = self.config.initializer_range
+        if isinstance(m, nn.Linear):
+            nn.init.normal_(m.weight, 0.0, std)
+            nn.init.zeros_(m.bias)
+        elif isinstance(m, nn.Embedding):
+            nn.init.normal_(m.weight, 0.0, std)
+            if m.padding_idx is not None:
+                with torch.no_grad():
+                    m.weight[m.padding_idx].zero_()
+
+    def gradient_checkpointing_enable(self, **_):
+        self.gradient_checkpointing = True
+
+    def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, return_dict=True, **_):
+        x = self.embeddings(input_ids, token_type_ids)
+        mask = None
+        if attention_mask is not None:
+            mask = attention_mask.to(torch.bool)[:, None, None, :]
+        ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
+        for layer in self.encoder.layer:
+            x = checkpoint(layer, x, mask, use_reentrant=False) if ck else layer(x, mask)
+        return EncoderOutput(last_hidden_state=x) if return_dict else (x,)
+
+
+# ----------------------------------------------------------------------------------------------------
+# construction / HF-layout checkpoints
+# ----------------------------------------------------------------------------------------------------
+def build_encoder(config: EncoderConfig) -> nn.Module:
+    arch = config.architectures[0]
+    if "Llama" in arch:
+        return LlamaEncoder(config)
+    if "Bert" in arch or "XLMRoberta" in arch:
+        return BertEncoder(config)
+    raise ValueError(f"unsupported architecture {arch!r} (Llama* and Bert* encoders are implemented)")
+
+
+def load_encoder(path: str, torch_dtype=None) -> nn.Module:
+    """Load `config.json` + `model.safetensors` (HF layout, base-model key names) from a directory."""
+    from safetensors.torch import load_file
+    with open(os.path.join(path, "config.json")) as f:
+        raw = json.load(f)
+    arch = (raw.get("architectures") or ["LlamaModel" if raw.get("model_type") == "llama" else "BertModel"])[0]
+    raw["architectures"] = [arch]
+    cfg = llama_config(**raw) if "Llama" in arch else bert_config(**raw)
+    with torch.device("meta"):
+        enc = build_encoder(cfg)
+    sd = load_file(os.path.join(path, "model.safetensors"))
+    sd = {(k[len("model."):] if k.startswith("model.") and "Llama" in arch else k): v for k, v in sd.items()}
+    sd = {(k[len("bert."):] if k.startswith("bert.") else k): v for k, v in sd.items()}
+    enc = enc.to_empty(device="cpu")
+    missing, unexpected = enc.load_state_dict(sd, strict=False)
+    missing = [m for m in missing if "inv_freq" not in m]
+    unexpected = [u for u in unexpected if not (u.startswith("pooler.") or u.startswith("lm_head.") or
+                                               "position_ids" in u)]
+    if missing or unexpected:
+        raise RuntimeError(f"checkpoint {path} does not match the encoder: missing={missing} unexpected={unexpected}")
+    if "Llama" in arch:
+        enc.inv_freq = _rope_inv_freq(cfg)
+    return enc.to(torch_dtype) if torch_dtype is not None else enc
+
+
+def save_encoder(enc: nn.Module, path: str):
+    """Write the INNER encoder in HF layout (what the reference's save_model does: contrastive_trainer.py:964-1027)."""
+    from safetensors.torch import save_file
+    os.makedirs(path, exist_ok=True)
+    sd = {k: v.detach().contiguous().cpu() for k, v in enc.state_dict().items()}
+    save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    with open(os.path.join(path, "config.json"), "w") as f:
+        json.dump({k: v for k, v in enc.config.to_dict().items()}, f, indent=2, default=str)

@@ -1,0 +1,251 @@
+"""Drop-in for the reference's `src/modeling.py` surface: `ModelOutput`, `ModelForTraining`
+(`embed / compute_similarity / forward / distributed_gather`, modeling.py:116-404) and `ModelForInference.encode`
+(modeling.py:411-554), with the scoring path executed by librankpo_hip.so (see rankpo_amd/ops.py).
+
+Same constructor keywords, attribute names, `forward(query=..., passage=...)` keywords, return container and
+error behaviour as the reference.  Additions (keyword-only, default off): `encoder=` / `config=` to build from an
+in-memory encoder or an architecture config instead of a checkpoint directory (no network here), `torch_dtype=`.
+"""
+from __future__ import annotations
+
+import logging
+import os
+from typing import Dict, List, Optional, Union
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import Tensor, nn
+
+from . import ops
+from .distributed import EmbeddingGather, all_gather_with_local_grad
+from .encoder import build_encoder, load_encoder
+
+logger = logging.getLogger(__name__)
+
+
+class ModelOutput(dict):
+    """`q_reps, p_reps, loss, scores` (modeling.py:17-22).  Like transformers' ModelOutput it is a dict with
+    attribute access whose keys are the non-None fields; the trainer reads `outputs["loss"]`."""
+
+    _fields = ("q_reps", "p_reps", "loss", "scores")
+
+    def __init__(self, q_reps: Optional[Tensor] = None, p_reps: Optional[Tensor] = None,
+                 loss: Optional[Tensor] = None, scores: Optional[Tensor] = None):
+        super().__init__()
+        for k, v in (("q_reps", q_reps), ("p_reps", p_reps), ("loss", loss), ("scores", scores)):
+            object.__setattr__(self, k, v)
+            if v is not None:
+                self[k] = v
+
+    def to_tuple(self):
+        return tuple(self[k] for k in self.keys())
+
+
+def _load_or_build(model_name_or_path, encoder, config, torch_dtype):
+    if encoder is not None:
+        return encoder
+    if config is not None:
+        enc = build_encoder(config)
+        return enc.to(torch_dtype) if torch_dtype is not None else enc
+    if model_name_or_path is None or not os.path.isdir(str(model_name_or_path)):
+        raise ValueError(
+            f"model_name_or_path={model_name_or_path!r} is not a local directory; hub downloads are not available "
+            "here.  Pass a directory in HF layout (config.json + model.safetensors), or encoder= / config=.")
+    return load_encoder(model_name_or_path, torch_dtype)
+
+
+class ModelForTraining(nn.Module):
+    """modeling.py:116-404."""
+
+    def __init__(
+        self,
+        model_name_or_path: str = None,
+        *,
+        attn_implementation: str = None,
+        use_cache: bool = True,
+        cache_dir: str = None,
+        token: str = None,
+        trust_remote_code: bool = False,
+        normalize_embeddings: bool = True,
+        use_inbatch_neg: bool = True,
+        negatives_cross_device: bool = False,
+        temperature: float = 1.0,
+        encoder: nn.Module = None,
+        config=None,
+        torch_dtype=None,
+    ):
+        super().__init__()
+        # attn_implementation / use_cache / cache_dir / token / trust_remote_code are accepted for signature
+        # compatibility; attention always runs through torch SDPA (flash on ROCm) and there is no KV cache.
+        self.model = _load_or_build(model_name_or_path, encoder, config, torch_dtype)
+        self.criterion = nn.CrossEntropyLoss(reduction="mean")     # kept for attribute parity (modeling.py:179)
+
+        self.normalize_embeddings = normalize_embeddings
+        self.temperature = temperature
+        self.use_inbatch_neg = use_inbatch_neg
+        self.config = self.model.config
+
+        if not normalize_embeddings:                                # modeling.py:186-188
+            self.temperature = 1.0
+            logger.info("reset temperature = 1.0 due to using inner product to compute similarity")
+        if normalize_embeddings:                                    # modeling.py:189-191
+            if self.temperature > 0.5:
+                raise ValueError("Temperature should be smaller than 1.0 when use cosine similarity (i.e., "
+                                 "normalize_embeddings=True). Recommend to set it 0.01-0.1")
+
+        self.negatives_cross_device = negatives_cross_device
+        if self.negatives_cross_device:                             # modeling.py:194-201
+            if not dist.is_initialized():
+                raise ValueError("Distributed training has not been initialized for representation all gather.")
+            self.process_rank = dist.get_rank()
+            self.world_size = dist.get_world_size()
+
+    def gradient_checkpointing_enable(self, **kwargs):
+        self.model.gradient_checkpointing_enable(**kwargs)
+
+    @property
+    def pooling_mode(self) -> str:
+        return "last" if "Llama" in self.config.architectures[0] else "cls"   # modeling.py:224 / 231
+
+    def embed(self, inputs):
+        """modeling.py:206-238: encoder -> last-token / CLS pooling -> (normalize) -> contiguous [N, d]."""
+        if inputs is None:
+            return None
+        outputs = self.model(**inputs, return_dict=True)
+        last_hidden_state = outputs.last_hidden_state
+        attention_mask = inputs["attention_mask"]
+        return ops.pool_normalize(last_hidden_state, attention_mask, self.pooling_mode, self.normalize_embeddings)
+
+    def compute_similarity(self, q_reps, p_reps):
+        """modeling.py:240-252: `q @ p.transpose(-2, -1)`; 2-D inputs use the MFMA similarity kernel."""
+        if q_reps.dim() == 2 and p_reps.dim() == 2 and q_reps.is_cuda and not (
+                torch.is_grad_enabled() and (q_reps.requires_grad or p_reps.requires_grad)):
+            return ops.similarity(q_reps, p_reps)
+        return torch.matmul(q_reps, p_reps.transpose(-2, -1))
+
+    def forward(self, query: Dict[str, Tensor] = None, passage: Dict[str, Tensor] = None):
+        """modeling.py:254-328.  Keyword names `query` / `passage` are the collator's keys."""
+        gathers = None
+        if self.training and self.negatives_cross_device and self.use_inbatch_neg and passage is not None:
+            # The passage tower is the big one: encode it first and let its RCCL all-gather run over xGMI
+            # while the query tower is being encoded (results do not depend on the encode order).
+            p_reps = self.embed(passage)
+            gp = EmbeddingGather(p_reps)
+            q_reps = self.embed(query)
+            gathers = (EmbeddingGather(q_reps), gp)
+        else:
+            q_reps = self.embed(query)
+            p_reps = self.embed(passage)
+
+        if self.training:
+            q_all = p_all = None
+            q_row0 = p_row0 = 0
+            if gathers is not None:                                           # modeling.py:287-290
+                # rank-major order; only this rank's rows receive gradients (modeling.py:374-377)
+                q_all, p_all = gathers[0].wait(), gathers[1].wait()
+                q_row0 = self.process_rank * q_reps.shape[0]
+                p_row0 = self.process_rank * p_reps.shape[0]
+            loss, scores = ops.infonce_loss(q_reps, p_reps, self.temperature, self.use_inbatch_neg,
+                                            q_all=q_all, p_all=p_all, q_row0=q_row0, p_row0=p_row0)
+            if q_all is not None:       # the reference returns the gathered representations (modeling.py:289-290, 326-327)
+                q_reps, p_reps = q_all, p_all
+        else:
+            scores = self.compute_similarity(q_reps, p_reps)                  # modeling.py:321
+            loss = None
+        return ModelOutput(loss=loss, scores=scores, q_reps=q_reps, p_reps=p_reps)
+
+    def distributed_gather(self, tensor: Optional[torch.Tensor], use_method: int = 1):
+        """modeling.py:331-404: rank-major gather along dim 0; gradient flows to this rank's slice only.
+        The three `use_method`s of the reference are mathematically identical; one implementation serves all."""
+        if tensor.ndim == 0:
+            tensor = tensor.clone()[None]
+        if not tensor.is_contiguous():
+            tensor = tensor.contiguous()
+        if use_method not in (1, 2, 3):
+            return None
+        return all_gather_with_local_grad(tensor)
+
+
+class ModelForInference(nn.Module):
+    """modeling.py:411-554."""
+
+    def __init__(
+        self,
+        model_name_or_path: str = None,
+        attn_implementation: str = None,
+        normalize_embeddings: bool = True,
+        use_fp16: bool = False,
+        use_bf16: bool = False,
+        device: int = 0,
+        *,
+        encoder: nn.Module = None,
+        config=None,
+        tokenizer=None,
+    ) -> None:
+        super().__init__()
+        if use_bf16 and use_fp16:                                     # modeling.py:443-444
+            raise ValueError("Cannot use fp16 and bf16 in the same time!")
+        if torch.cuda.is_available():
+            self.device = torch.device(device)
+        else:
+            self.device = torch.device("cpu")
+            use_fp16 = False
+        torch_dtype = torch.float32
+        if use_fp16:
+            torch_dtype = torch.float16
+        elif use_bf16:
+            torch_dtype = torch.bfloat16
+        self.model = _load_or_build(model_name_or_path, encoder, config, torch_dtype)
+        if tokenizer is None:
+            from transformers import AutoTokenizer
+            tokenizer = AutoTokenizer.from_pretrained(model_name_or_path)
+        self.tokenizer = tokenizer
+        self.normalize_embeddings = normalize_embeddings
+        self.config = self.model.config
+        if not getattr(self.tokenizer, "pad_token", None):            # modeling.py:467-468
+            raise ValueError("pad_token is not specified!")
+        side = getattr(self.tokenizer, "padding_side", "right")
+        if side != "right" and hasattr(self.config, "padding_side"):
+            self.config.padding_side = side        # left padding: the Llama encoder must honour the mask
+        self.model = self.model.to(self.device)
+
+    @torch.inference_mode()
+    def encode(
+        self,
+        sentences: Union[List[str], str],
+        batch_size: int = 256,
+        max_length: int = 512,
+        convert_to_numpy: bool = True,
+        description: str = "Encoding",
+    ) -> Union[np.ndarray, torch.Tensor]:
+        """modeling.py:473-554.  Differences that do not change results: no per-batch `empty_cache()` (a device
+        sync per batch, modeling.py:543-544); numpy conversion happens once at the end."""
+        self.model.eval()
+        input_was_string = False
+        if isinstance(sentences, str):
+            sentences = [sentences]
+            input_was_string = True
+        if not isinstance(sentences[0], str):
+            raise ValueError("Input items should be text.")
+        mode = "last" if "Llama" in self.config.architectures[0] else "cls"
+        all_embeddings = []
+        for i in range(0, len(sentences), batch_size):
+            batch_sentences = sentences[i:i + batch_size]
+            inputs = self.tokenizer(batch_sentences, padding=True, truncation=True, max_length=max_length,
+                                    return_tensors="pt")
+            inputs = {k: v.to(self.device) for k, v in inputs.items()}
+            h = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                           return_dict=True).last_hidden_state
+            if h.dtype == torch.float16:        # the HIP kernels take f32 / bf16
+                h = h.float()
+            emb = ops.pool_normalize(h, inputs["attention_mask"], mode, self.normalize_embeddings)
+            all_embeddings.append(emb)
+        out = torch.cat(all_embeddings, dim=0)
+        if convert_to_numpy:
+            if out.dtype == torch.bfloat16:      # modeling.py:537-538
+                out = out.float()
+            out = out.cpu().numpy()
+        if input_was_string:
+            return out[0]
+        return out

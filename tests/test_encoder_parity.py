@@ -1,0 +1,149 @@
+"""Encoder parity on CPU: (i) the oracle encoder vs the installed transformers' LlamaModel / BertModel,
+(ii) the product encoders (rankpo_amd/encoder.py, plain PyTorch) vs the oracle, (iii) the oracle's full
+contrastive step vs what the reference's ModelForTraining produced on tiny HF models (golden end_to_end)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import encoder_ref as E
+from rankpo_amd import encoder as PE
+
+
+def _batch(rs, N, L, vocab, lens=None, left=False):
+    ids = rs.randint(1, vocab, size=(N, L))
+    lens = rs.randint(1, L + 1, size=N) if lens is None else np.asarray(lens)
+    lens[0] = L
+    if left:
+        m = (np.arange(L)[None, :] >= (L - lens)[:, None]).astype(np.int64)
+    else:
+        m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    return torch.tensor(ids * m), torch.tensor(m)
+
+
+LLAMA_CFGS = [
+    dict(vocab_size=96, hidden_size=64, intermediate_size=112, num_hidden_layers=2, num_attention_heads=4,
+         num_key_value_heads=2, rms_norm_eps=1e-5, rope_theta=10000.0, max_position_embeddings=128),
+    dict(vocab_size=96, hidden_size=64, intermediate_size=112, num_hidden_layers=2, num_attention_heads=4,
+         num_key_value_heads=4, rms_norm_eps=1e-6, rope_theta=500000.0, max_position_embeddings=256,
+         rope_scaling=dict(rope_type="llama3", factor=32.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                           original_max_position_embeddings=16)),
+]
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+@pytest.mark.parametrize("left", [False, True])
+def test_oracle_llama_vs_transformers(ci, left):
+    from transformers import LlamaConfig, LlamaModel
+    torch.manual_seed(ci)
+    kw = dict(LLAMA_CFGS[ci])
+    hf = LlamaModel(LlamaConfig(pad_token_id=0, attention_bias=False, attn_implementation="eager", **kw)).eval()
+    ids, m = _batch(np.random.RandomState(ci), 5, 24, 96, left=left)
+    with torch.no_grad():
+        ref = hf(input_ids=ids, attention_mask=m).last_hidden_state
+        cfg = dict(kw, head_dim=16, architectures=["LlamaModel"])
+        got = E.llama_forward(E.state_dict_to_f32(hf), cfg, ids, m)
+    real = m.bool()
+    assert (got - ref)[real].abs().max() < 2e-5
+
+
+def test_oracle_bert_vs_transformers():
+    from transformers import BertConfig, BertModel
+    torch.manual_seed(0)
+    kw = dict(vocab_size=96, hidden_size=48, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4,
+              max_position_embeddings=64, layer_norm_eps=1e-12)
+    hf = BertModel(BertConfig(pad_token_id=0, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                              attn_implementation="eager", **kw)).eval()
+    ids, m = _batch(np.random.RandomState(1), 4, 20, 96)
+    with torch.no_grad():
+        ref = hf(input_ids=ids, attention_mask=m).last_hidden_state
+        got = E.bert_forward(E.state_dict_to_f32(hf), dict(kw, architectures=["BertModel"]), ids, m)
+    assert (got - ref)[m.bool()].abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+@pytest.mark.parametrize("side", ["right", "left"])
+def test_product_llama_vs_oracle(ci, side):
+    torch.manual_seed(10 + ci)
+    cfg = PE.llama_config(pad_token_id=0, padding_side=side, **LLAMA_CFGS[ci])
+    enc = PE.LlamaEncoder(cfg).eval()
+    ids, m = _batch(np.random.RandomState(ci + 5), 6, 33, 96, left=(side == "left"))
+    with torch.no_grad():
+        got = enc(input_ids=ids, attention_mask=m).last_hidden_state
+        ref = E.llama_forward(E.state_dict_to_f32(enc), cfg.to_dict(), ids, m)
+    # right padding runs WITHOUT the padding mask (pure causal): identical on every real token
+    assert (got - ref)[m.bool()].abs().max() < 3e-5
+
+
+def test_product_bert_vs_oracle_and_grads():
+    torch.manual_seed(3)
+    cfg = PE.bert_config(vocab_size=96, hidden_size=48, intermediate_size=96, num_hidden_layers=2,
+                         num_attention_heads=4, max_position_embeddings=64)
+    enc = PE.BertEncoder(cfg).eval()
+    ids, m = _batch(np.random.RandomState(2), 4, 20, 96)
+    got = enc(input_ids=ids, attention_mask=m).last_hidden_state
+    ref = E.bert_forward(E.state_dict_to_f32(enc), cfg.to_dict(), ids, m)
+    assert (got - ref)[m.bool()].abs().max() < 3e-5
+
+
+def test_gradient_checkpointing_is_exact():
+    torch.manual_seed(4)
+    cfg = PE.llama_config(pad_token_id=0, **LLAMA_CFGS[0])
+    enc = PE.LlamaEncoder(cfg).train()
+    ids, m = _batch(np.random.RandomState(4), 3, 17, 96)
+    enc(input_ids=ids, attention_mask=m).last_hidden_state[:, -1].sum().backward()
+    g0 = enc.layers[0].mlp.up_proj.weight.grad.clone()
+    enc.zero_grad()
+    enc.gradient_checkpointing_enable(layers=1)
+    enc(input_ids=ids, attention_mask=m).last_hidden_state[:, -1].sum().backward()
+    assert torch.allclose(g0, enc.layers[0].mlp.up_proj.weight.grad, atol=1e-6)
+
+
+@pytest.mark.parametrize("arch", ["llama", "bert"])
+@pytest.mark.parametrize("mode", ["inbatch", "noinbatch"])
+def test_oracle_step_vs_reference_end_to_end(golden, arch, mode):
+    """Reference ModelForTraining (HF encoder, eager) on a tiny model: loss / scores / embeddings / embedding
+    gradient, reproduced by the oracle from the stored weights."""
+    g = golden("end_to_end")
+    cfg = json.loads(str(g[f"{arch}_config"]))
+    cfg["architectures"] = ["LlamaModel" if arch == "llama" else "BertModel"]
+    if arch == "llama":
+        cfg.setdefault("head_dim", cfg["hidden_size"] // cfg["num_attention_heads"])
+        rp = cfg.get("rope_parameters") or {}
+        cfg["rope_theta"] = cfg.get("rope_theta") or rp.get("rope_theta", 10000.0)
+        cfg["rope_scaling"] = None
+    w = {k[len(arch) + 3:]: torch.tensor(g[k]).double().requires_grad_(True) for k in g.files
+         if k.startswith(f"{arch}_w_")}
+    batch = {"query": {"input_ids": torch.tensor(g[f"{arch}_q_ids"]), "attention_mask": torch.tensor(g[f"{arch}_q_mask"])},
+             "passage": {"input_ids": torch.tensor(g[f"{arch}_p_ids"]), "attention_mask": torch.tensor(g[f"{arch}_p_mask"])}}
+    loss, s, q, p = E.contrastive_step(w, cfg, batch, 0.02, use_inbatch_neg=(mode == "inbatch"), dtype=torch.float64)
+    loss.backward()
+    key = f"{arch}_{mode}"
+    np.testing.assert_allclose(q.detach().numpy(), g[key + "_q_reps"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(p.detach().numpy(), g[key + "_p_reps"], rtol=0, atol=3e-6)
+    np.testing.assert_allclose(s.detach().numpy(), g[key + "_scores"], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(loss.item(), float(g[key + "_loss"]), rtol=2e-5, atol=2e-5)
+    gname = "embed_tokens.weight" if arch == "llama" else "embeddings.word_embeddings.weight"
+    ref = g[key + "_grad_embed"]
+    got = w[gname].grad.numpy()
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-4
+
+
+def test_hf_layout_save_load_roundtrip(tmp_path):
+    torch.manual_seed(5)
+    cfg = PE.llama_config(pad_token_id=0, **LLAMA_CFGS[1])
+    enc = PE.LlamaEncoder(cfg)
+    PE.save_encoder(enc, str(tmp_path / "m"))
+    enc2 = PE.load_encoder(str(tmp_path / "m"))
+    ids, m = _batch(np.random.RandomState(6), 2, 9, 96)
+    with torch.no_grad():
+        a = enc.eval()(input_ids=ids, attention_mask=m).last_hidden_state
+        b = enc2.eval()(input_ids=ids, attention_mask=m).last_hidden_state
+    assert torch.equal(a, b)
+    # and the installed transformers can read the same directory (HF layout)
+    from transformers import LlamaModel
+    hf = LlamaModel.from_pretrained(str(tmp_path / "m"), attn_implementation="eager").eval()
+    with torch.no_grad():
+        c = hf(input_ids=ids, attention_mask=m).last_hidden_state
+    assert (a - c)[m.bool()].abs().max() < 3e-5

@@ -1,0 +1,187 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol of include/rankpo_hip.h, collators
+reproduce the reference's output (golden), argument validation mirrors the reference's errors, the N > 1 gather and
+gradient-reduction paths work on 2 gloo ranks.  No compute call into the HIP library happens here."""
+import ctypes
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_library_exports_every_declared_symbol():
+    from rankpo_amd import _lib
+    lib = _lib.load()
+    hdr = open(os.path.join(ROOT, "include", "rankpo_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(rpo_[a-z0-9_]+)\s*\(", hdr))
+    assert {"rpo_pool_normalize_fwd", "rpo_pool_normalize_bwd", "rpo_infonce_fwd", "rpo_infonce_bwd",
+            "rpo_rankpo_fwd", "rpo_rankpo_bwd", "rpo_adamw_step", "rpo_infonce_workspace_bytes"} <= declared
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in include/rankpo_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), "ctypes SIGNATURES and the header disagree"
+    assert lib.rpo_version() >= 100
+    assert lib.rpo_status_string(0) == b"ok"
+    assert lib.rpo_infonce_workspace_bytes(8, 48, 2048, 1) >= 256
+    assert ctypes.sizeof(_lib.RankPOParams) == 32
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from rankpo_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/librankpo_hip.so")
+    with pytest.raises(ImportError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_ops_refuse_cpu_tensors():
+    from rankpo_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.infonce_loss(torch.randn(2, 8), torch.randn(4, 8), 0.02)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.rankpo_loss_metrics(torch.randn(2, 8), torch.randn(4, 8), ops.RankPOConfig())
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "rankpo_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("oracle/", ""), f"{fn} mentions the oracle"
+
+
+def test_collators_match_reference(golden):
+    from rankpo_amd.data_utils import ContrastiveDataCollatorWithPadding, RankPODataCollatorWithPadding
+    g = golden("collators")
+    meta = json.loads(str(g["meta"]))
+    o = RankPODataCollatorWithPadding(pad_token_id=128004)(meta["rankpo_examples"])
+    for a in ("query", "passage"):
+        for b in ("input_ids", "attention_mask"):
+            np.testing.assert_array_equal(o[a][b].numpy(), g[f"rankpo_{a}_{b}"])
+            assert o[a][b].dtype == torch.int64
+    # the docstring example of the reference (data_utils.py:144-172)
+    np.testing.assert_array_equal(o["passage"]["input_ids"].numpy(),
+                                  [[4, 5, 128004], [6, 128004, 128004], [9, 128004, 128004], [10, 11, 12]])
+    random.seed(meta["python_random_seed"])
+    o = ContrastiveDataCollatorWithPadding(pad_token_id=meta["pad_token_id"],
+                                           num_negatives=meta["num_negatives"])(meta["contrastive_features"])
+    for a in ("query", "passage"):
+        for b in ("input_ids", "attention_mask"):
+            np.testing.assert_array_equal(o[a][b].numpy(), g[f"contrastive_{a}_{b}"])
+    with pytest.raises(AssertionError, match="key: 'chosen' is missing"):
+        RankPODataCollatorWithPadding()([{"query": {}, "rejected": {}}])
+
+
+def test_model_for_training_argument_errors():
+    """Same ValueErrors as modeling.py:189-196."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    cfg = PE.llama_config(vocab_size=32, hidden_size=16, intermediate_size=32, num_hidden_layers=1,
+                          num_attention_heads=2, num_key_value_heads=1)
+    with pytest.raises(ValueError, match="Temperature should be smaller than 1.0"):
+        rankpo_amd.ModelForTraining(config=cfg, temperature=1.0)
+    m = rankpo_amd.ModelForTraining(config=cfg, temperature=0.7, normalize_embeddings=False)
+    assert m.temperature == 1.0                                   # reset when not normalizing (modeling.py:186-188)
+    with pytest.raises(ValueError, match="Distributed training has not been initialized"):
+        rankpo_amd.ModelForTraining(config=cfg, temperature=0.02, negatives_cross_device=True)
+    with pytest.raises(ValueError, match="Cannot use fp16 and bf16"):
+        rankpo_amd.ModelForInference(config=cfg, use_fp16=True, use_bf16=True)
+    m = rankpo_amd.ModelForTraining(config=cfg, temperature=0.02)
+    assert m.pooling_mode == "last" and m.embed(None) is None
+    out = rankpo_amd.ModelOutput(loss=torch.tensor(1.0))
+    assert list(out.keys()) == ["loss"] and out["loss"] == out.loss and out.scores is None
+
+
+def test_rankpo_trainer_knobs_and_errors():
+    import rankpo_amd
+    tr = rankpo_amd.RankPOTrainer(None, None, beta=2.0, temperature=0.1, reference_free=True)
+    c, r = torch.tensor([.8, .2, .5]), torch.tensor([.3, .6, .5])
+    np.testing.assert_allclose(tr.rankpo_loss(c, r).numpy(), [4.5399e-05, 8.000335, 0.693147], rtol=1e-4)
+    tr.loss_type = "hinge"
+    np.testing.assert_allclose(tr.rankpo_loss(c, r).numpy(), [0, 9, 1], atol=1e-5)
+    tr.loss_type = "bogus"
+    with pytest.raises(ValueError, match="Unknown loss type: bogus"):
+        tr.rankpo_loss(c, r)
+    with pytest.raises(ValueError, match="Unknown loss type: bogus"):
+        tr._cfg().to_c()
+    tr.store_metrics({"rewards/chosen": 1.0})
+    tr.store_metrics({"rewards/chosen": 3.0})
+    assert tr.log({"loss": 0.5})["rewards/chosen"] == 2.0
+
+
+def test_cosine_schedule_matches_transformers():
+    from transformers import get_cosine_schedule_with_warmup
+    from rankpo_amd.train_step import cosine_with_warmup
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=1.0)
+    sch = get_cosine_schedule_with_warmup(opt, num_warmup_steps=3, num_training_steps=20)
+    for s in range(20):
+        assert abs(sch.get_last_lr()[0] - cosine_with_warmup(s, 20, 3)) < 1e-9
+        opt.step()
+        sch.step()
+
+
+# ------------------------------------------------------------------------------------------- 2-rank gloo
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rankpo_amd.distributed import EmbeddingGather, FlatGradAllReducer, all_gather_with_local_grad
+        g = np.load(os.path.join(ROOT, "tests", "golden", "crossdevice.npz"))
+        q = torch.tensor(g[f"w{world}_r{rank}_q"], requires_grad=True)
+        p = torch.tensor(g[f"w{world}_r{rank}_p"], requires_grad=True)
+        # reference distributed_gather semantics: rank-major cat, gradient only to the own slice
+        qa, pa = all_gather_with_local_grad(q), all_gather_with_local_grad(p)
+        assert np.array_equal(qa.detach().numpy(), g[f"w{world}_r{rank}_q_reps"])
+        assert np.array_equal(pa.detach().numpy(), g[f"w{world}_r{rank}_p_reps"])
+        s = qa @ pa.T / 0.02
+        G = pa.shape[0] // qa.shape[0]
+        loss = torch.nn.functional.cross_entropy(s, torch.arange(qa.shape[0]) * G)
+        loss.backward()
+        ok = (abs(loss.item() - float(g[f"w{world}_r{rank}_loss"])) < 1e-9
+              and np.allclose(q.grad.numpy(), g[f"w{world}_r{rank}_dq"], rtol=1e-8, atol=1e-12)
+              and np.allclose(p.grad.numpy(), g[f"w{world}_r{rank}_dp"], rtol=1e-8, atol=1e-12))
+        # the asynchronous, autograd-free gather used by ModelForTraining.forward
+        eg = EmbeddingGather(p)
+        ok = ok and np.array_equal(eg.wait().numpy(), g[f"w{world}_r{rank}_p_reps"])
+        # bucketed gradient mean
+        torch.manual_seed(0)
+        lin = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+        red = FlatGradAllReducer(list(lin.parameters()), bucket_mb=1e-4)
+        assert len(red.buckets) >= 2
+        x = torch.full((4, 7), float(rank + 1))
+        red.arm()
+        lin(x).sum().backward()
+        scale = red.finish()
+        got = red.flat.clone() * scale
+        # expectation: mean over ranks of the per-rank gradients
+        exp = torch.zeros_like(red.flat)
+        for r in range(world):
+            l2 = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Linear(5, 3))
+            l2.load_state_dict(lin.state_dict())
+            l2(torch.full((4, 7), float(r + 1))).sum().backward()
+            for prm, o in zip(reversed(list(l2.parameters())), red.offsets):
+                exp[o:o + prm.numel()] += prm.grad.reshape(-1) / world
+        ok = ok and torch.allclose(got, exp, rtol=1e-5, atol=1e-6)
+        ok = ok and all(prm.grad.data_ptr() == red.flat[o:o + prm.numel()].data_ptr()
+                        for prm, o in zip(red.order, red.offsets))
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gloo_gather_and_grad_reduce(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, 29711, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
