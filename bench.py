@@ -77,6 +77,13 @@ def _algo(name, a):
     if name == "rpo_sumsq_partial":
         n, dt = a[1], a[2]
         return n * _es(dt), 2 * n
+    if name == "rpo_swiglu_fwd":
+        return 3 * a[3] * _es(a[4]), 5 * a[3]
+    if name == "rpo_swiglu_bwd":
+        return 5 * a[5] * _es(a[6]), 12 * a[5]
+    if name == "rpo_rope":
+        rows, H, hd, dt = a[5], a[6], a[7], a[9]
+        return 2 * rows * H * hd * _es(dt) + rows * hd * 4, 3 * rows * H * hd
     if name == "rpo_rankpo_fwd":
         B, d, dt = a[4], a[5], a[6]
         return 3 * B * d * _es(dt), 4 * B * d
@@ -223,7 +230,9 @@ def main():
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
-    ap.add_argument("--ckpt-layers", type=int, default=-1, help="checkpoint the first k blocks (-1 = all, 0 = none)")
+    ap.add_argument("--ckpt-layers", type=int, default=-2,
+                    help="checkpoint the first k blocks (-2 = as few as fit in 72%% of HBM, -1 = all, 0 = none)")
+    ap.add_argument("--padded", action="store_true", help="run the encoder on padded batches (reference behaviour)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -254,10 +263,30 @@ def main():
         enc = build_encoder(cfg)
     enc = enc.to(dtype)
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
-                                        negatives_cross_device=(world > 1)).train()
-    if args.ckpt_layers != 0 and hasattr(enc, "layers"):
-        model.gradient_checkpointing_enable(layers=None if args.ckpt_layers < 0 else args.ckpt_layers)
-    elif args.ckpt_layers != 0:
+                                        negatives_cross_device=(world > 1), unpad=not args.padded).train()
+    nb = args.steps + args.warmup
+    batches = [synth_batch(cfg, B, K, Lq, Lp, 1234 + rank * 1000 + i, device) for i in range(nb)]
+    tok_real = [int(b["query"]["attention_mask"].sum()) + int(b["passage"]["attention_mask"].sum()) for b in batches]
+    tok_pad = B * Lq + B * (1 + K) * Lp
+    ckpt = args.ckpt_layers
+    if ckpt == -2:
+        ckpt = -1
+        if hasattr(enc, "layers"):
+            # activation bytes kept per token per un-checkpointed block: x, norm(x), q, k, v, attn out, x', norm(x'),
+            # gate, up (the SwiGLU product is recomputed) = s (6.5 d + 2 ff) upper bound; measured 44 KB for
+            # Llama-3.2-1B bf16 (0.75 of the bound).  States: 16 B/param.
+            es = 2 if dtype == torch.bfloat16 else 4
+            per_tok = int(0.8 * es * (6.5 * cfg.hidden_size + 2 * cfg.intermediate_size))
+            toks = tok_pad     # budget for the worst case (every row at full length), also in packed mode
+            per_layer = toks * per_tok
+            nparam = sum(p.numel() for p in enc.parameters())
+            total = torch.cuda.get_device_properties(device).total_memory
+            budget = 0.72 * total - nparam * (es * 2 + 12) - toks * cfg.hidden_size * es * len(enc.layers) - 2 * per_layer
+            free_layers = max(0, min(len(enc.layers), int(budget // per_layer)))
+            ckpt = len(enc.layers) - free_layers
+    if ckpt != 0 and hasattr(enc, "layers"):
+        model.gradient_checkpointing_enable(layers=None if ckpt < 0 else ckpt)
+    elif ckpt != 0:
         model.gradient_checkpointing_enable()
 
     timed = TimedLib(_lib.load())
@@ -274,6 +303,15 @@ def main():
 
     note(f"model + {nb} synthetic batches ready ({arch}, world {world}); warmup {args.warmup} steps")
     losses = []
+    if not args.padded and args.warmup > 0:
+        # Packed mode changes the activation sizes every step.  One untimed step on a full-length batch first sizes
+        # the caching allocator for the worst case (later, smaller steps reuse/split those blocks instead of
+        # calling hipMalloc inside the timed region) and proves that the worst case fits in HBM.
+        full = {k: {"input_ids": v["input_ids"], "attention_mask": torch.ones_like(v["attention_mask"])}
+                for k, v in batches[0].items()}
+        ts.step(full)
+        torch.cuda.synchronize()
+        note(f"allocator pre-sized on a full-length batch, peak mem {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB")
     for i in range(args.warmup):
         losses.append(ts.step(batches[i]))
         torch.cuda.synchronize()
@@ -311,7 +349,9 @@ def main():
                                    f"T={temperature}, in-batch negs" + (", cross-device negs" if world > 1 else ""),
                        "global_batch": world * B, "pairs_per_step": world * B * (1 + K),
                        "parallelism": f"dp{world}", "optimizer": "AdamW(flat, HIP) + clip 1.0, GAS=1",
-                       "grad_checkpointing": "all" if args.ckpt_layers < 0 else f"first {args.ckpt_layers}",
+                       "grad_checkpointing": "all blocks" if ckpt < 0 else f"first {ckpt} blocks",
+                       "padding": "padded batches" if args.padded else "pad tokens skipped (packed varlen encoder)",
+                       "tokens_per_step_per_gpu": {"padded": tok_pad, "real_mean": int(sum(tok_real) / len(tok_real))},
                        "weights": "random init (seed 0)"},
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
             "peak_mem_GiB": round(peak_mem, 2),

@@ -23,6 +23,8 @@ import torch.nn.functional as F
 from torch import nn
 from torch.utils.checkpoint import checkpoint
 
+from . import ops as _ops
+
 
 class EncoderConfig(SimpleNamespace):
     """Minimal stand-in for a HF PretrainedConfig (attribute access + to_dict)."""
@@ -128,6 +130,41 @@ def _rotate_half(x):
     return torch.cat((-x2, x1), dim=-1)
 
 
+class RopeTables:
+    """cos / sin of the rotary angles, f32 [P, head_dim/2] (P = positions or packed tokens)."""
+
+    def __init__(self, freqs: torch.Tensor):
+        self.cos32, self.sin32 = freqs.cos().contiguous(), freqs.sin().contiguous()
+
+    def full(self, dtype, packed: bool):
+        # HF LlamaRotaryEmbedding: emb = cat(freqs, freqs); cos(emb).to(dtype)
+        cos = torch.cat((self.cos32, self.cos32), -1).to(dtype)
+        sin = torch.cat((self.sin32, self.sin32), -1).to(dtype)
+        return (cos[:, None, :], sin[:, None, :]) if packed else (cos[None, None], sin[None, None])
+
+
+class VarlenCtx:
+    """cu_seqlens (int32, device), the host copy of the lengths and the longest length of a packed batch."""
+
+    def __init__(self, cu, lens, max_len):
+        self.cu, self.lens, self.max_len = cu, lens, max_len
+
+
+def _varlen_causal_attention(q, k, v, ctx: VarlenCtx):
+    """q [T, nh, hd], k/v [T, nkv, hd] packed; causal attention inside each sequence."""
+    if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16):
+        return torch.ops.aten._flash_attention_forward(q, k, v, ctx.cu, ctx.cu, ctx.max_len, ctx.max_len, 0.0, True,
+                                                       False)[0]
+    outs, o0 = [], 0                      # f32 or CPU (tests, config 1): one SDPA call per sequence
+    for n in ctx.lens:
+        a = F.scaled_dot_product_attention(q[o0:o0 + n].transpose(0, 1)[None], k[o0:o0 + n].transpose(0, 1)[None],
+                                           v[o0:o0 + n].transpose(0, 1)[None], is_causal=True,
+                                           enable_gqa=k.shape[1] != q.shape[1])
+        outs.append(a[0].transpose(0, 1))
+        o0 += n
+    return torch.cat(outs, 0)
+
+
 class LlamaAttention(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -138,13 +175,29 @@ class LlamaAttention(nn.Module):
         self.v_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, bias=b)
         self.o_proj = nn.Linear(self.nh * self.hd, cfg.hidden_size, bias=b)
 
-    def forward(self, x, cos, sin, attn_mask):
+    def forward(self, x, rope, attn_mask):
         N, L, _ = x.shape
-        q = self.q_proj(x).view(N, L, self.nh, self.hd).transpose(1, 2)
-        k = self.k_proj(x).view(N, L, self.nkv, self.hd).transpose(1, 2)
-        v = self.v_proj(x).view(N, L, self.nkv, self.hd).transpose(1, 2)
-        q = q * cos + _rotate_half(q) * sin
-        k = k * cos + _rotate_half(k) * sin
+        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        fused = _ops.fused_encoder_ops_ok(x, self.hd)
+        if fused:       # one in-place HIP pass per projection instead of neg / cat / 2 mul / add
+            q = _ops.rope_(q, rope.cos32, rope.sin32, self.nh, self.hd)
+            k = _ops.rope_(k, rope.cos32, rope.sin32, self.nkv, self.hd)
+        if isinstance(attn_mask, VarlenCtx):
+            # packed tokens [1, T, d]: variable-length causal flash attention, no pad tokens anywhere
+            q, k, v = q.view(L, self.nh, self.hd), k.view(L, self.nkv, self.hd), v.view(L, self.nkv, self.hd)
+            if not fused:
+                cos, sin = rope.full(x.dtype, packed=True)
+                q = q * cos + _rotate_half(q) * sin
+                k = k * cos + _rotate_half(k) * sin
+            o = _varlen_causal_attention(q, k, v, attn_mask)
+            return self.o_proj(o.reshape(1, L, self.nh * self.hd))
+        q = q.view(N, L, self.nh, self.hd).transpose(1, 2)
+        k = k.view(N, L, self.nkv, self.hd).transpose(1, 2)
+        v = v.view(N, L, self.nkv, self.hd).transpose(1, 2)
+        if not fused:
+            cos, sin = rope.full(x.dtype, packed=False)
+            q = q * cos + _rotate_half(q) * sin
+            k = k * cos + _rotate_half(k) * sin
         if attn_mask is None:
             o = F.scaled_dot_product_attention(q, k, v, is_causal=True, enable_gqa=self.nkv != self.nh)
         else:
@@ -161,7 +214,10 @@ class LlamaMLP(nn.Module):
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=b)
 
     def forward(self, x):
-        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
+        g, u = self.gate_proj(x), self.up_proj(x)
+        if self.down_proj.bias is None and _ops.fused_encoder_ops_ok(g):
+            return _ops.swiglu_down(g, u, self.down_proj.weight)       # fused HIP silu*mul, product not kept alive
+        return self.down_proj(F.silu(g) * u)
 
 
 class LlamaLayer(nn.Module):
@@ -172,8 +228,8 @@ class LlamaLayer(nn.Module):
         self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
 
-    def forward(self, x, cos, sin, attn_mask):
-        x = x + self.self_attn(self.input_layernorm(x), cos, sin, attn_mask)
+    def forward(self, x, rope, attn_mask):
+        x = x + self.self_attn(self.input_layernorm(x), rope, attn_mask)
         return x + self.mlp(self.post_attention_layernorm(x))
 
 
@@ -221,12 +277,9 @@ class LlamaEncoder(nn.Module):
         self.config.vocab_size = n
         return new
 
-    def _rope(self, L, device, dtype):
-        # same op order as HF LlamaRotaryEmbedding: f32 outer product, cat, cos/sin, cast
-        pos = torch.arange(L, device=device, dtype=torch.float32)
-        freqs = torch.outer(pos, self.inv_freq.to(device=device, dtype=torch.float32))
-        emb = torch.cat((freqs, freqs), dim=-1)
-        return emb.cos().to(dtype)[None, None], emb.sin().to(dtype)[None, None]
+    def _rope(self, pos):
+        # same op order as HF LlamaRotaryEmbedding: f32 outer product of positions and inverse frequencies
+        return RopeTables(torch.outer(pos.to(torch.float32), self.inv_freq.to(device=pos.device, dtype=torch.float32)))
 
     def _mask(self, attention_mask, L, dtype):
         if attention_mask is None or getattr(self.config, "padding_side", "right") == "right":
@@ -239,20 +292,50 @@ class LlamaEncoder(nn.Module):
         """Output of the last block, BEFORE the final RMSNorm."""
         x = self.embed_tokens(input_ids)
         N, L, _ = x.shape
-        cos, sin = self._rope(L, x.device, x.dtype)
+        rope = self._rope(torch.arange(L, device=x.device))
         mask = self._mask(attention_mask, L, x.dtype)
-        ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
-        nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
-        for i, layer in enumerate(self.layers):
-            if ck and i < nck:
-                x = checkpoint(layer, x, cos, sin, mask, use_reentrant=False)
-            else:
-                x = layer(x, cos, sin, mask)
-        return x
+        return self._run_layers(x, rope, mask)
 
     def forward(self, input_ids=None, attention_mask=None, return_dict=True, **_):
         h = self.norm(self.hidden_states(input_ids, attention_mask))
         return EncoderOutput(last_hidden_state=h) if return_dict else (h,)
+
+    def _run_layers(self, x, rope, ctx):
+        ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
+        nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
+        for i, layer in enumerate(self.layers):
+            if ck and i < nck:
+                x = checkpoint(layer, x, rope, ctx, use_reentrant=False)
+            else:
+                x = layer(x, rope, ctx)
+        return x
+
+    def pooled_last_token(self, input_ids, attention_mask):
+        """== forward(...).last_hidden_state[n, last real token] for RIGHT-padded 0/1 masks, computed without ever
+        touching a pad token: tokens are packed to [T, d], attention is variable-length causal flash attention, and
+        the final RMSNorm runs on the N pooled rows only.  Returns None when the mask is not a right-padded 0/1
+        mask with at least one token per row (the caller then takes the general padded path).
+        One host sync per call (sequence lengths), none per layer."""
+        m = attention_mask
+        N, L = m.shape
+        lens_d = m.sum(-1)
+        ok = (m[:, 1:] <= m[:, :-1]).all() & (lens_d > 0).all() & ((m == 0) | (m == 1)).all()
+        info = torch.cat([lens_d.to(torch.int64), ok.to(torch.int64)[None]]).tolist()      # the one sync
+        if not info[-1] or getattr(self.config, "padding_side", "right") != "right":
+            return None
+        lens = info[:-1]
+        T = sum(lens)
+        keep = m.reshape(-1).to(torch.bool)
+        flat = torch.nonzero(keep, as_tuple=False).squeeze(1)                              # [T] (size known: no surprise)
+        ids = input_ids.reshape(-1)[flat]
+        x = self.embed_tokens(ids)[None]                                                   # [1, T, d]
+        rope = self._rope(flat % L)                                                        # per-token angles [T, hd/2]
+        cu = torch.zeros(N + 1, dtype=torch.int32, device=x.device)
+        cu[1:] = lens_d.cumsum(0).to(torch.int32)
+        ctx = VarlenCtx(cu, lens, max(lens))
+        x = self._run_layers(x, rope, ctx)
+        last = x[0].index_select(0, (cu[1:] - 1).to(torch.int64))                          # [N, d]
+        return self.norm(last)
 
 
 # ----------------------------------------------------------------------------------------------------

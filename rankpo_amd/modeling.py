@@ -74,8 +74,10 @@ class ModelForTraining(nn.Module):
         encoder: nn.Module = None,
         config=None,
         torch_dtype=None,
+        unpad: bool = True,
     ):
         super().__init__()
+        self.unpad = unpad
         # attn_implementation / use_cache / cache_dir / token / trust_remote_code are accepted for signature
         # compatibility; attention always runs through torch SDPA (flash on ROCm) and there is no KV cache.
         self.model = _load_or_build(model_name_or_path, encoder, config, torch_dtype)
@@ -112,6 +114,12 @@ class ModelForTraining(nn.Module):
         """modeling.py:206-238: encoder -> last-token / CLS pooling -> (normalize) -> contiguous [N, d]."""
         if inputs is None:
             return None
+        if self.unpad and self.pooling_mode == "last" and hasattr(self.model, "pooled_last_token"):
+            # right-padded batches (what both collators produce): run the encoder on the real tokens only and
+            # normalise the N pooled rows; identical to the padded path on every pooled row.
+            pooled = self.model.pooled_last_token(inputs["input_ids"], inputs["attention_mask"])
+            if pooled is not None:
+                return ops.pool_normalize(pooled[:, None, :], None, "cls", self.normalize_embeddings)
         outputs = self.model(**inputs, return_dict=True)
         last_hidden_state = outputs.last_hidden_state
         attention_mask = inputs["attention_mask"]

@@ -246,4 +246,90 @@ def rankpo_loss_metrics(q, p, cfg: RankPOConfig, ref_chosen=None, ref_rejected=N
     return _RankPO.apply(q, p, ref_chosen, ref_rejected, cfg)
 
 
-__all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS"]
+# ------------------------------------------------------------------------------------------------
+# (5) fused elementwise pieces of the Llama block (used by rankpo_amd/encoder.py on HIP tensors)
+# ------------------------------------------------------------------------------------------------
+def _swiglu_fwd(lib, g, u, out):
+    with torch.cuda.device(g.device):
+        check(lib.rpo_swiglu_fwd(g.data_ptr(), u.data_ptr(), out.data_ptr(), g.numel(), _dt(g), _stream(g)),
+              "rpo_swiglu_fwd")
+    return out
+
+
+class _SwiGLUDown(torch.autograd.Function):
+    """y = (silu(g) * u) @ W^T.  Saves g, u, W only: the [tokens, ff] product (the largest activation of the block)
+    is recomputed by one fused pass in backward instead of being kept alive."""
+
+    @staticmethod
+    def forward(ctx, g, u, weight):
+        lib = _lib.load()
+        g, u = g.contiguous(), u.contiguous()
+        prod = _swiglu_fwd(lib, g, u, torch.empty_like(g))
+        ctx.save_for_backward(g, u, weight)
+        return torch.nn.functional.linear(prod, weight)
+
+    @staticmethod
+    def backward(ctx, dy):
+        g, u, weight = ctx.saved_tensors
+        lib = _lib.load()
+        dy = dy.contiguous()
+        prod = _swiglu_fwd(lib, g, u, torch.empty_like(g))
+        dW = None
+        if ctx.needs_input_grad[2]:
+            dW = dy.reshape(-1, dy.shape[-1]).t() @ prod.reshape(-1, prod.shape[-1])
+        dprod = dy @ weight                                   # [..., ff]
+        with torch.cuda.device(g.device):                     # dg -> prod's buffer, du -> dprod's buffer
+            check(lib.rpo_swiglu_bwd(g.data_ptr(), u.data_ptr(), dprod.data_ptr(), prod.data_ptr(), dprod.data_ptr(),
+                                     g.numel(), _dt(g), _stream(g)), "rpo_swiglu_bwd")
+        return prod, dprod, dW
+
+
+def swiglu_down(g, u, weight):
+    return _SwiGLUDown.apply(g, u, weight)
+
+
+def fused_encoder_ops_ok(x, head_dim=None) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    return head_dim is None or (head_dim % 2 == 0 and (head_dim // 2) % v == 0)
+
+
+class _Rope(torch.autograd.Function):
+    """In-place rotary embedding of a projection output x [..., heads * head_dim] (x is the fresh output of a Linear,
+    nothing else reads it).  cos / sin: f32 [period, head_dim / 2]; flat row r uses table row r % period."""
+
+    @staticmethod
+    def forward(ctx, x, cos, sin, heads, head_dim):
+        lib = _lib.load()
+        rows = x.numel() // (heads * head_dim)
+        with torch.cuda.device(x.device):
+            check(lib.rpo_rope(x.data_ptr(), x.data_ptr(), heads * head_dim, cos.data_ptr(), sin.data_ptr(), rows, heads,
+                               head_dim, cos.shape[0], _dt(x), 0, _stream(x)), "rpo_rope")
+        ctx.mark_dirty(x)
+        ctx.save_for_backward(cos, sin)
+        ctx.meta = (heads, head_dim)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        cos, sin = ctx.saved_tensors
+        heads, head_dim = ctx.meta
+        lib = _lib.load()
+        g = g.contiguous()
+        out = torch.empty_like(g)
+        rows = g.numel() // (heads * head_dim)
+        with torch.cuda.device(g.device):
+            check(lib.rpo_rope(g.data_ptr(), out.data_ptr(), heads * head_dim, cos.data_ptr(), sin.data_ptr(), rows,
+                               heads, head_dim, cos.shape[0], _dt(g), 1, _stream(g)), "rpo_rope(bwd)")
+        return out, None, None, None, None
+
+
+def rope_(x, cos, sin, heads, head_dim):
+    if not x.is_contiguous():
+        raise ValueError("rope_ needs the contiguous output of the projection")
+    return _Rope.apply(x, cos, sin, heads, head_dim)
+
+
+__all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
+           "swiglu_down", "rope_", "fused_encoder_ops_ok"]

@@ -70,6 +70,10 @@ class RankPOTrainer:
     # -- rankpo_trainer.py:392-418 --------------------------------------------------------------------
     def single_forward(self, model: nn.Module, inputs: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Encoder -> ALWAYS last-token pooling -> ALWAYS normalize (the reference ignores pooling/normalize flags)."""
+        if hasattr(model, "pooled_last_token"):       # unpadded fast path (right-padded batches), same pooled rows
+            pooled = model.pooled_last_token(inputs["input_ids"], inputs["attention_mask"])
+            if pooled is not None:
+                return ops.pool_normalize(pooled[:, None, :], None, "cls", True)
         outputs = model(**inputs, return_dict=True)
         return ops.pool_normalize(outputs.last_hidden_state, inputs["attention_mask"], "last", True)
 

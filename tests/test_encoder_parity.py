@@ -147,3 +147,34 @@ def test_hf_layout_save_load_roundtrip(tmp_path):
     with torch.no_grad():
         c = hf(input_ids=ids, attention_mask=m).last_hidden_state
     assert (a - c)[m.bool()].abs().max() < 3e-5
+
+
+@pytest.mark.parametrize("ci", [0, 1])
+def test_packed_pooled_path_equals_padded_path(ci):
+    """pooled_last_token (unpadded, varlen attention, final norm on pooled rows only) == padded forward + pooling."""
+    torch.manual_seed(20 + ci)
+    cfg = PE.llama_config(pad_token_id=0, **LLAMA_CFGS[ci])
+    enc = PE.LlamaEncoder(cfg).train()
+    ids, m = _batch(np.random.RandomState(ci + 9), 7, 29, 96)
+    h = enc(input_ids=ids, attention_mask=m).last_hidden_state
+    idx = (m.argmin(-1) - 1) % m.shape[-1]
+    ref = h[torch.arange(7), idx]
+    got = enc.pooled_last_token(ids, m)
+    assert (got - ref).abs().max() < 2e-5
+    # gradients agree too (with and without checkpointing)
+    gr = torch.randn_like(ref)
+    ref.backward(gr)
+    g0 = enc.layers[0].self_attn.q_proj.weight.grad.clone()
+    e0 = enc.embed_tokens.weight.grad.clone()
+    for ck in (False, True):
+        enc.zero_grad()
+        if ck:
+            enc.gradient_checkpointing_enable()
+        enc.pooled_last_token(ids, m).backward(gr)
+        assert (enc.layers[0].self_attn.q_proj.weight.grad - g0).abs().max() < 1e-5 * max(1.0, g0.abs().max().item())
+        assert (enc.embed_tokens.weight.grad - e0).abs().max() < 1e-5 * max(1.0, e0.abs().max().item())
+    # masks that are not right-padded 0/1 masks are refused (the caller falls back to the padded path)
+    ml = torch.flip(m, dims=[1])
+    assert enc.pooled_last_token(ids, ml) is None or bool((ml[:, 1:] <= ml[:, :-1]).all())
+    z = m.clone(); z[3] = 0
+    assert enc.pooled_last_token(ids, z) is None

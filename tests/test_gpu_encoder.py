@@ -1,0 +1,185 @@
+"""GPU tests of the encoder side: fused SwiGLU / RoPE HIP kernels vs their torch definitions (values + gradients),
+the GPU encoder (padded and packed paths, fused ops on) vs the CPU oracle, full ModelForTraining / RankPOTrainer
+steps vs the oracle, and the flat AdamW step vs torch.optim.AdamW."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import encoder_ref as E
+from oracle import scoring_ref as R
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _batch(rs, N, L, vocab):
+    lens = rs.randint(1, L + 1, size=N)
+    lens[0] = L
+    m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    ids = rs.randint(1, vocab, size=(N, L)) * m
+    return torch.tensor(ids), torch.tensor(m)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_swiglu_down_matches_torch(dtype):
+    from rankpo_amd import ops
+    torch.manual_seed(0)
+    T, ff, d = 300, 512, 128
+    g = torch.randn(T, ff, device=DEV).to(dtype).requires_grad_(True)
+    u = torch.randn(T, ff, device=DEV).to(dtype).requires_grad_(True)
+    W = (torch.randn(d, ff, device=DEV) * 0.05).to(dtype).requires_grad_(True)
+    y = ops.swiglu_down(g, u, W)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    g2, u2, W2 = (t.detach().double().requires_grad_(True) for t in (g, u, W))
+    y2 = (F.silu(g2) * u2) @ W2.T
+    y2.backward(gy.double())
+    tol = 2e-5 if dtype == torch.float32 else 2.0 ** -6
+    for a, b in ((y, y2), (g.grad, g2.grad), (u.grad, u2.grad), (W.grad, W2.grad)):
+        assert (a.double() - b).abs().max() <= tol * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("packed", [False, True])
+def test_rope_matches_hf_formula(dtype, packed):
+    from rankpo_amd import ops
+    torch.manual_seed(1)
+    N, L, H, hd = 3, 17, 5, 64
+    pos = torch.arange(L, device=DEV) if not packed else torch.randint(0, 50, (N * L,), device=DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=DEV, dtype=torch.float32) / hd))
+    fr = torch.outer(pos.float(), inv)
+    cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
+    x0 = torch.randn(N * L, H * hd, device=DEV).to(dtype)
+    x = x0.clone().requires_grad_(True)
+    y = ops.rope_(x * 1.0, cos, sin, H, hd)           # x*1.0: a fresh tensor, as the projection output is
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xr = x0.double().view(N * L, H, hd).requires_grad_(True)
+    c = torch.cat((fr, fr), -1).cos().double()
+    s = torch.cat((fr, fr), -1).sin().double()
+    if not packed:
+        c, s = c.repeat(N, 1), s.repeat(N, 1)
+    rot = torch.cat((-xr[..., hd // 2:], xr[..., : hd // 2]), -1)
+    yr = xr * c[:, None, :] + rot * s[:, None, :]
+    yr.backward(gy.double().view(N * L, H, hd))
+    tol = 2e-6 if dtype == torch.float32 else 2.0 ** -7
+    assert (y.double().view(N * L, H, hd) - yr).abs().max() <= tol * 8
+    assert (x.grad.double().view(N * L, H, hd) - xr.grad).abs().max() <= tol * 8
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 3e-4), (torch.bfloat16, 6e-2)])
+def test_gpu_encoder_vs_cpu_oracle(dtype, tol):
+    from rankpo_amd import encoder as PE
+    torch.manual_seed(2)
+    cfg = PE.llama_config(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=3,
+                          num_attention_heads=4, num_key_value_heads=2, pad_token_id=0,
+                          rope_scaling=dict(PE.LLAMA3_ROPE, original_max_position_embeddings=32))
+    enc = PE.LlamaEncoder(cfg)
+    w = E.state_dict_to_f32(enc)
+    ids, m = _batch(np.random.RandomState(3), 6, 80, 256)
+    with torch.no_grad():
+        ref = E.llama_forward(w, cfg.to_dict(), ids, m)
+    enc = enc.to(DEV).to(dtype).eval()
+    with torch.no_grad():
+        got = enc(input_ids=ids.to(DEV), attention_mask=m.to(DEV)).last_hidden_state.float().cpu()
+        idx = (m.argmin(-1) - 1) % m.shape[-1]
+        pooled = enc.pooled_last_token(ids.to(DEV), m.to(DEV)).float().cpu()
+    assert (got - ref)[m.bool()].abs().max() < tol
+    assert (pooled - ref[torch.arange(6), idx]).abs().max() < tol
+
+
+def test_packed_and_padded_training_steps_agree_on_gpu():
+    """Same loss and same gradients whether pad tokens are skipped (varlen attention) or not."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    torch.manual_seed(4)
+    cfg = PE.llama_config(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, pad_token_id=0)
+    enc = PE.LlamaEncoder(cfg).to(DEV)
+    rs = np.random.RandomState(5)
+    qi, qm = _batch(rs, 4, 24, 256)
+    pi, pm = _batch(rs, 12, 40, 256)
+    batch = {"query": {"input_ids": qi.to(DEV), "attention_mask": qm.to(DEV)},
+             "passage": {"input_ids": pi.to(DEV), "attention_mask": pm.to(DEV)}}
+    res = []
+    for unpad in (False, True):
+        enc.zero_grad()
+        model = rankpo_amd.ModelForTraining(encoder=enc, temperature=0.02, unpad=unpad).train()
+        out = model(**batch)
+        out.loss.backward()
+        res.append((out.loss.item(), out.scores.clone(), enc.layers[0].mlp.up_proj.weight.grad.clone()))
+    assert abs(res[0][0] - res[1][0]) < 1e-4 * max(1.0, abs(res[0][0]))
+    assert (res[0][1] - res[1][1]).abs().max() < 2e-3
+    assert (res[0][2] - res[1][2]).abs().max() < 1e-4 * max(1.0, res[0][2].abs().max().item())
+    # and against the CPU oracle's full step
+    w = E.state_dict_to_f32(enc)
+    cb = {"query": {"input_ids": qi, "attention_mask": qm}, "passage": {"input_ids": pi, "attention_mask": pm}}
+    ref_loss, ref_s, _, _ = E.contrastive_step(w, cfg.to_dict(), cb, 0.02)
+    assert abs(res[1][0] - ref_loss.item()) < 2e-3 * max(1.0, abs(ref_loss.item()))
+
+
+def test_rankpo_trainer_step_vs_oracle_with_ref_model():
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    torch.manual_seed(6)
+    cfg = PE.llama_config(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, pad_token_id=0)
+    pol, ref = PE.LlamaEncoder(cfg).to(DEV), PE.LlamaEncoder(cfg).to(DEV)
+    rs = np.random.RandomState(7)
+    B = 5
+    qi, qm = _batch(rs, B, 20, 256)
+    pi, pm = _batch(rs, 2 * B, 30, 256)
+    batch = {"query": {"input_ids": qi.to(DEV), "attention_mask": qm.to(DEV)},
+             "passage": {"input_ids": pi.to(DEV), "attention_mask": pm.to(DEV)}}
+    tr = rankpo_amd.RankPOTrainer(pol, ref, beta=2.0, temperature=0.1, sft_weight=0.5, label_smoothing=0.1,
+                                  gamma_beta_ratio=0.25, reference_free=False)
+    loss, metrics = tr.compute_loss(pol, batch, return_outputs=True)
+    loss.backward()
+    cb = {"query": {"input_ids": qi, "attention_mask": qm}, "passage": {"input_ids": pi, "attention_mask": pm}}
+    emb = lambda enc, side: E.embed(E.state_dict_to_f32(enc), cfg.to_dict(), cb[side], force_last=True).detach().numpy()
+    rsc = R.rankpo_scores(emb(ref, "query"), emb(ref, "passage"))
+    o = R.rankpo_batch_loss_metrics(emb(pol, "query"), emb(pol, "passage"), rsc[:, 0], rsc[:, 1], beta=2.0,
+                                    temperature=0.1, sft_weight=0.5, label_smoothing=0.1, gamma_beta_ratio=0.25,
+                                    reference_free=False)
+    assert abs(loss.item() - o["loss"]) < 2e-3 * max(1.0, abs(o["loss"]))
+    assert set(metrics) == set(o["metrics"])
+    for k, v in o["metrics"].items():
+        assert abs(metrics[k] - v) < 5e-3 * max(1.0, abs(v)), k
+    assert tr.log({"loss": loss.item()})["rewards/margins"] == pytest.approx(metrics["rewards/margins"])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_flat_adamw_matches_torch_adamw(dtype):
+    from rankpo_amd.train_step import FlatAdamW
+    torch.manual_seed(8)
+    net = torch.nn.Sequential(torch.nn.Linear(37, 29), torch.nn.Linear(29, 11)).to(DEV).to(dtype)
+    ref = torch.nn.Sequential(torch.nn.Linear(37, 29), torch.nn.Linear(29, 11)).to(DEV)
+    ref.load_state_dict({k: v.float() for k, v in net.state_dict().items()})
+    opt = FlatAdamW(net.parameters(), lr=1e-2, weight_decay=0.01, max_grad_norm=0.5)
+    ropt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.01, eps=1e-8)
+    for step in range(4):
+        x = torch.randn(16, 37, device=DEV)
+        net(x.to(dtype)).float().pow(2).sum().backward()
+        if dtype == torch.float32:
+            ref(x).pow(2).sum().backward()
+        else:   # feed the reference the same (bf16-rounded) gradients
+            for p, q in zip(net.parameters(), ref.parameters()):
+                q.grad = p.grad.float().clone()
+        torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+        ropt.step()
+        ropt.zero_grad()
+        opt.step()
+        master = opt.master if opt.master is not None else opt.flat_param
+        for p, q in zip(net.parameters(), ref.parameters()):
+            o = opt.reducer.offsets[[id(x) for x in opt.reducer.order].index(id(p))]
+            m = master[o:o + p.numel()].view_as(p)
+            assert (m - q).abs().max() < 2e-5 * max(1.0, q.abs().max().item()), step
+            assert p.grad.abs().sum() == 0
+        if dtype == torch.float32:   # keep both nets in lockstep
+            for p, q in zip(net.parameters(), ref.parameters()):
+                assert (p - q).abs().max() < 2e-5
+        else:
+            for p, q in zip(net.parameters(), ref.parameters()):
+                assert (p.float() - q).abs().max() <= 2.0 ** -7 * max(1.0, q.abs().max().item())
+                q.data.copy_(opt.master[opt.reducer.offsets[[id(x) for x in opt.reducer.order].index(id(p))]:][:p.numel()].view_as(p))

@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Condense a rocprofv3 `*_kernel_stats.csv` into a short, committed summary (profiles/*.md):
+top kernels by time with short names + every hand-written kernel of librankpo_hip.so."""
+import csv
+import re
+import sys
+
+OURS = ("pool_normalize", "sim_tile", "sim_skinny", "sim_rowwise", "ce_finalize", "first_finalize", "infonce_bwd",
+        "infonce_first_bwd", "grouped_dots", "rankpo_", "adamw_kernel", "sumsq_kernel", "zero_fill", "rms_", "swiglu",
+        "rope_")
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    if name.startswith("Cijk_") or name.startswith("Custom_Cijk_"):
+        m = re.search(r"MT\d+x\d+x\d+", name)
+        return ("hipBLASLt " + name.split("_BBS")[0] + " " + (m.group(0) if m else ""))[:70]
+    name = re.sub(r"at::native::", "", name)
+    return name[:110]
+
+
+def main(path, title):
+    rows = list(csv.DictReader(open(path)))
+    tot = sum(int(r["TotalDurationNs"]) for r in rows)
+    print(f"# {title}\n")
+    print(f"source: `{path.split('gpurun_out/')[-1]}` (rocprofv3 --kernel-trace --stats), total GPU kernel time "
+          f"{tot / 1e6:.1f} ms over {sum(int(r['Calls']) for r in rows)} dispatches\n")
+    print("| kernel | calls | total ms | avg us | % |\n|---|---:|---:|---:|---:|")
+    for r in rows[:22]:
+        print(f"| {short(r['Name'])} | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.2f} | "
+              f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.2f} |")
+    print("\n## hand-written kernels (librankpo_hip.so)\n")
+    print("| kernel | calls | total ms | avg us | min us | max us |\n|---|---:|---:|---:|---:|---:|")
+    for r in rows:
+        if any(k in r["Name"] for k in OURS):
+            print(f"| {short(r['Name'])} | {r['Calls']} | {int(r['TotalDurationNs']) / 1e6:.3f} | "
+                  f"{float(r['AverageNs']) / 1e3:.2f} | {int(r['MinNs']) / 1e3:.2f} | {int(r['MaxNs']) / 1e3:.2f} |")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "rocprofv3 kernel stats")
