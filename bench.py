@@ -224,6 +224,21 @@ def cpu_baseline(model, cfg, temperature, sample=(160, 512, 2)):
     return dt, Lq_s + G_s * Lp_s, cores
 
 
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout when the communicator is created; the driver wants ONE JSON line
+    there.  Route file descriptor 1 to stderr while the process group comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -236,6 +251,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="rehearsal: take the N > 1 code path (RCCL init, cross-device gather, grad all-reduce) at N = 1")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -246,9 +263,15 @@ def main():
                          f"--nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        with _StdoutToStderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            dist.barrier()                       # creates the RCCL communicator now (banner goes to stderr)
+            torch.cuda.synchronize()
 
     import rankpo_amd
     from rankpo_amd import _lib
@@ -263,7 +286,7 @@ def main():
         enc = build_encoder(cfg)
     enc = enc.to(dtype)
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
-                                        negatives_cross_device=(world > 1), unpad=not args.padded).train()
+                                        negatives_cross_device=multi, unpad=not args.padded).train()
     nb = args.steps + args.warmup
     batches = [synth_batch(cfg, B, K, Lq, Lp, 1234 + rank * 1000 + i, device) for i in range(nb)]
     tok_real = [int(b["query"]["attention_mask"].sum()) + int(b["passage"]["attention_mask"].sum()) for b in batches]
@@ -293,7 +316,8 @@ def main():
     if not args.no_kernel_timing:
         _lib._lib = timed
     ts = TrainStep(model.parameters(), lambda b: model(**b)["loss"], lr=1e-5, max_grad_norm=1.0,
-                   gradient_accumulation_steps=1, total_steps=max(10, args.steps + args.warmup), warmup_ratio=0.1)
+                   gradient_accumulation_steps=1, total_steps=max(10, args.steps + args.warmup), warmup_ratio=0.1,
+                   force_collectives=args.force_dist)
 
     nb = args.steps + args.warmup
     batches = [synth_batch(cfg, B, K, Lq, Lp, 1234 + rank * 1000 + i, device) for i in range(nb)]
@@ -317,7 +341,7 @@ def main():
         torch.cuda.synchronize()
         note(f"warmup step {i} done, loss {float(losses[-1]):.4f}, peak mem {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB")
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     timed.enabled = not args.no_kernel_timing
@@ -325,13 +349,13 @@ def main():
     for i in range(args.warmup, nb):
         losses.append(ts.step(batches[i]))
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timed.enabled = False
     note(f"timed {args.steps} steps in {elapsed:.3f} s")
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
@@ -346,7 +370,7 @@ def main():
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtn, "data": "synthetic",
             "config": {"workload": f"{args.workload}: {arch} contrastive, B={B}/GPU, K={K}, q_len={Lq}, p_len={Lp}, "
-                                   f"T={temperature}, in-batch negs" + (", cross-device negs" if world > 1 else ""),
+                                   f"T={temperature}, in-batch negs" + (", cross-device negs" if multi else ""),
                        "global_batch": world * B, "pairs_per_step": world * B * (1 + K),
                        "parallelism": f"dp{world}", "optimizer": "AdamW(flat, HIP) + clip 1.0, GAS=1",
                        "grad_checkpointing": "all blocks" if ckpt < 0 else f"first {ckpt} blocks",
@@ -376,7 +400,7 @@ def main():
                                              f"extrapolated linearly in tokens to {toks_per_pair:.0f} tokens per "
                                              f"full-length pair"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -70,7 +70,8 @@ class FlatGradAllReducer:
     ~`bucket_mb` MiB (large: xGMI is point-to-point, few big collectives beat many small ones) that are
     all-reduced (mean) on RCCL's stream as soon as every gradient inside has been accumulated."""
 
-    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 512.0, world_size: Optional[int] = None):
+    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 512.0, world_size: Optional[int] = None,
+                 force_collectives: bool = False):
         self.params = [p for p in params if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         assert self.params, "no trainable parameters"
@@ -103,7 +104,8 @@ class FlatGradAllReducer:
         self._pending = [0] * len(self.buckets)
         self._works = []
         self._armed = False
-        if self.world > 1:
+        self._reduce = self.world > 1 or (force_collectives and dist.is_initialized())   # force: 1-rank rehearsal
+        if self._reduce:
             for i, p in enumerate(order):
                 p.register_post_accumulate_grad_hook(self._make_hook(i))
 
@@ -126,7 +128,7 @@ class FlatGradAllReducer:
 
     def arm(self):
         """Call before the LAST backward of an accumulation window: buckets then reduce as they complete."""
-        self._armed = self.world > 1
+        self._armed = self._reduce
         self._pending = [len(ids) for _, _, ids in self.buckets]
         self._works = []
 

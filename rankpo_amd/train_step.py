@@ -35,8 +35,8 @@ class FlatAdamW:
     """AdamW over one flat parameter buffer; parameters and gradients are views into flat storage."""
 
     def __init__(self, params: Iterable[nn.Parameter], lr=1e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0,
-                 max_grad_norm: Optional[float] = 1.0, bucket_mb: float = 512.0):
-        self.reducer = FlatGradAllReducer(list(params), bucket_mb=bucket_mb)
+                 max_grad_norm: Optional[float] = 1.0, bucket_mb: float = 512.0, force_collectives: bool = False):
+        self.reducer = FlatGradAllReducer(list(params), bucket_mb=bucket_mb, force_collectives=force_collectives)
         r = self.reducer
         dev, dtype = r.flat.device, r.flat.dtype
         if not r.flat.is_cuda:
@@ -94,9 +94,9 @@ class TrainStep:
 
     def __init__(self, params, loss_fn: Callable[[Dict], torch.Tensor], *, lr=1e-5, weight_decay=0.0,
                  max_grad_norm=1.0, gradient_accumulation_steps=1, total_steps=1000, warmup_ratio=0.1,
-                 bucket_mb=512.0):
+                 bucket_mb=512.0, force_collectives=False):
         self.opt = FlatAdamW(params, lr=lr, weight_decay=weight_decay, max_grad_norm=max_grad_norm,
-                             bucket_mb=bucket_mb)
+                             bucket_mb=bucket_mb, force_collectives=force_collectives)
         self.loss_fn = loss_fn
         self.gas = gradient_accumulation_steps
         self.total_steps = total_steps
@@ -121,7 +121,7 @@ class TrainStep:
             l = self.micro_step(b, last=(i == self.gas - 1))
             tot = l if tot is None else tot + l
         inv_world = self.opt.reducer.finish()
-        mult = cosine_with_warmup(self.global_step + 1, self.total_steps, self.warmup_steps)
+        mult = cosine_with_warmup(self.global_step, self.total_steps, self.warmup_steps)   # HF: scheduler steps after the optimizer
         self.opt.step(grad_scale=inv_world / self.gas, lr_mult=mult)
         self.global_step += 1
         return tot / self.gas

@@ -1,0 +1,76 @@
+"""GPU rehearsal of the N > 1 code path with the RCCL backend at world_size 1 (one GPU box): process-group init as
+bench.py does it, asynchronous embedding all-gather, own-row gradient window, gradient-bucket hooks and the flat AdamW
+step.  With one rank the results must equal the non-distributed run exactly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def nccl_world1():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29633")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    yield
+    dist.destroy_process_group()
+
+
+def _batch(rs, N, L, vocab):
+    lens = rs.randint(L // 2, L + 1, size=N)
+    lens[0] = L
+    m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    return {"input_ids": torch.tensor(rs.randint(1, vocab, size=(N, L)) * m).to(DEV), "attention_mask": torch.tensor(m).to(DEV)}
+
+
+def test_cross_device_path_world1_equals_local(nccl_world1):
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    from rankpo_amd.train_step import TrainStep
+    cfg = PE.llama_config(vocab_size=256, hidden_size=128, intermediate_size=256, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, pad_token_id=0)
+    rs = np.random.RandomState(0)
+    batches = [{"query": _batch(rs, 4, 24, 256), "passage": _batch(rs, 12, 48, 256)} for _ in range(3)]
+    results = []
+    for xdev in (False, True):
+        torch.manual_seed(0)
+        enc = PE.LlamaEncoder(cfg).to(DEV).to(torch.bfloat16)
+        model = rankpo_amd.ModelForTraining(encoder=enc, temperature=0.02, negatives_cross_device=xdev).train()
+        ts = TrainStep(model.parameters(), lambda b: model(**b)["loss"], lr=1e-3, total_steps=10, warmup_ratio=0.0,
+                       bucket_mb=0.05, force_collectives=xdev)
+        assert len(ts.opt.reducer.buckets) > 1
+        assert ts.opt.reducer._reduce == xdev            # the bucketed async all-reduce hooks are live in the xdev run
+        losses = [ts.step(b).item() for b in batches]
+        out = model(**batches[0])
+        assert out.q_reps.shape[0] == 4 and out.p_reps.shape[0] == 12
+        results.append((losses, enc.layers[1].mlp.down_proj.weight.detach().float().clone()))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1])
+    assert results[0][0][0] != results[0][0][2]      # parameters really moved
+
+
+def test_distributed_gather_api_and_metrics_allreduce(nccl_world1):
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    cfg = PE.llama_config(vocab_size=64, hidden_size=64, intermediate_size=128, num_hidden_layers=1,
+                          num_attention_heads=2, num_key_value_heads=1, pad_token_id=0)
+    model = rankpo_amd.ModelForTraining(config=cfg, temperature=0.02, negatives_cross_device=True).to(DEV)
+    assert model.process_rank == 0 and model.world_size == 1
+    x = torch.randn(5, 64, device=DEV, requires_grad=True)
+    for method in (1, 2, 3):
+        y = model.distributed_gather(x, use_method=method)
+        assert torch.equal(y, x)
+        (y * 2).sum().backward()
+    assert torch.allclose(x.grad, torch.full_like(x, 6.0))
+    tr = rankpo_amd.RankPOTrainer(model.model, None, beta=2.0, temperature=0.1, reference_free=True)
+    rs = np.random.RandomState(1)
+    loss, metrics = tr.compute_loss(model.model, {"query": _batch(rs, 3, 10, 64), "passage": _batch(rs, 6, 12, 64)},
+                                    return_outputs=True)
+    assert np.isfinite(loss.item()) and "rewards/accuracies" in metrics and "sft_loss" not in metrics
