@@ -92,6 +92,15 @@ int rpo_infonce_bwd(const void* q, const void* p, const void* scores, const floa
                     int target_mode, int64_t q_row0, int64_t q_rows, int64_t p_row0, int64_t p_rows,
                     void* dq_out, void* dp_out, void* workspace, size_t workspace_bytes, rpo_stream_t stream);
 
+/* GEMM form of the backward for large Q*P (in-batch mode): writes the softmax gradient itself,
+ *   ds_out  [q_rows, P] = dS[q_row0 .. , :]      and      dst_out [p_rows, Q] = (dS[:, p_row0 ..])^T
+ * with dS[i,j] = grad_loss/(Q T) (exp(S[i,j] - lse_i) - [j == i (P/Q)]), in the storage dtype, so that
+ * dq = ds_out @ p and dp = dst_out @ q are two plain library GEMMs (hipBLASLt via the caller).  Either output
+ * may be NULL. */
+int rpo_infonce_ds(const void* scores, const float* lse, const float* grad_loss, int64_t Q, int64_t P, int dtype,
+                   float temperature, int64_t q_row0, int64_t q_rows, int64_t p_row0, int64_t p_rows,
+                   void* ds_out, void* dst_out, rpo_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (3) RankPO paired scoring + loss + metrics.
  * Replaces rankpo_trainer.py:436-443 (scores), 545-566 (rankpo_loss), 482-520 (loss mix + metrics).

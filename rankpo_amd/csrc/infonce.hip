@@ -535,6 +535,39 @@ __global__ __launch_bounds__(64) void infonce_bwd_scalar_kernel(
     }
 }
 
+// dS for the GEMM form of the backward (large Q*P): dS[i,j] = coef (exp(S[i,j] - lse_i) - [j == i*group]).
+//   ds  [q_rows, P] = dS[q_row0 + r, :]        (row-major: the A operand of dq = dS p)
+//   dst [p_rows, Q] = dS[:, p_row0 + r]^T      (row-major: the A operand of dp = dS^T q)
+// 64x64 tiles over the (row, col) range that is needed; the transposed copy goes through LDS so that both outputs
+// are written with coalesced rows.  grid = (ceil(P/64), ceil(Q/64)).
+template <typename T>
+__global__ __launch_bounds__(256) void infonce_ds_kernel(const T* __restrict__ scores, const float* __restrict__ lse,
+                                                         const float* __restrict__ grad_loss, int64_t Q, int64_t P,
+                                                         float temperature, int64_t group, int64_t q_row0,
+                                                         int64_t q_rows, int64_t p_row0, int64_t p_rows,
+                                                         T* __restrict__ ds, T* __restrict__ dst) {
+    __shared__ float tile[64][65];
+    const int64_t i0 = (int64_t)blockIdx.y * 64, j0 = (int64_t)blockIdx.x * 64;
+    const bool need_ds = ds && i0 < q_row0 + q_rows && i0 + 64 > q_row0;
+    const bool need_dst = dst && j0 < p_row0 + p_rows && j0 + 64 > p_row0;
+    if (!need_ds && !need_dst) return;
+    const float coef = grad_loss[0] / ((float)Q * temperature);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 4 row phases
+    for (int r = ty; r < 64; r += 4) {
+        const int64_t i = i0 + r, j = j0 + tx;
+        float w = 0.f;
+        if (i < Q && j < P) w = coef * (__expf(Elem<T>::ld(scores + i * P + j) - lse[i]) - (j == i * group ? 1.f : 0.f));
+        tile[r][tx] = w;
+        if (need_ds && i < Q && j < P && i >= q_row0 && i < q_row0 + q_rows) Elem<T>::st(ds + (i - q_row0) * P + j, w);
+    }
+    if (!need_dst) return;
+    __syncthreads();
+    for (int c = ty; c < 64; c += 4) {            // output row = passage column j0 + c, output col = query i0 + tx
+        const int64_t j = j0 + c, i = i0 + tx;
+        if (j < P && i < Q && j >= p_row0 && j < p_row0 + p_rows) Elem<T>::st(dst + (j - p_row0) * Q + i, tile[tx][c]);
+    }
+}
+
 // RPO_TARGET_FIRST backward: grid = own q rows (b) ; w[b,g] = coef (softmax(s_b)[g] - [g == 0]).
 //   dq_b = sum_g w[b,g] p_{bG+g}   ;   dp_{bG+g} = w[b,g] q_b   (only rows inside the own ranges are written)
 template <typename T>
@@ -760,6 +793,28 @@ extern "C" int rpo_infonce_bwd(const void* q, const void* p, const void* scores,
                                p_row0, p_rows, dq_out, dp_out, st);
     return bwd_impl<bf16_t>(q, p, scores, lse, grad_loss, Q, P, d, temperature, target_mode, q_row0, q_rows, p_row0,
                             p_rows, dq_out, dp_out, st);
+}
+
+extern "C" int rpo_infonce_ds(const void* scores, const float* lse, const float* grad_loss, int64_t Q, int64_t P,
+                              int dtype, float temperature, int64_t q_row0, int64_t q_rows, int64_t p_row0,
+                              int64_t p_rows, void* ds_out, void* dst_out, rpo_stream_t stream) {
+    if (!scores || !lse || !grad_loss || Q <= 0 || P < Q || !(temperature > 0.f)) return RPO_ERR_INVALID_ARG;
+    if (dtype != RPO_DT_F32 && dtype != RPO_DT_BF16) return RPO_ERR_INVALID_ARG;
+    if (q_row0 < 0 || q_rows < 0 || q_row0 + q_rows > Q || p_row0 < 0 || p_rows < 0 || p_row0 + p_rows > P)
+        return RPO_ERR_INVALID_ARG;
+    if (q_rows == 0) ds_out = nullptr;
+    if (p_rows == 0) dst_out = nullptr;
+    if (!ds_out && !dst_out) return RPO_OK;
+    if (rpo_cdiv(Q, 64) > 65535) return RPO_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)rpo_cdiv(P, 64), (unsigned)rpo_cdiv(Q, 64));
+    if (dtype == RPO_DT_F32)
+        RPO_LAUNCH(infonce_ds_kernel<float>, grid, dim3(256), 0, st, (const float*)scores, lse, grad_loss, Q, P,
+                   temperature, P / Q, q_row0, q_rows, p_row0, p_rows, (float*)ds_out, (float*)dst_out);
+    else
+        RPO_LAUNCH(infonce_ds_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)scores, lse, grad_loss, Q, P,
+                   temperature, P / Q, q_row0, q_rows, p_row0, p_rows, (bf16_t*)ds_out, (bf16_t*)dst_out);
+    return rpo_launch_status();
 }
 
 thread_local int rpo_tls_last_hip_error = 0;

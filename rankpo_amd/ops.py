@@ -99,6 +99,9 @@ def _workspace(lib, Q, P, d, dt, device):
     return torch.empty((max(n, 256),), dtype=torch.uint8, device=device), n
 
 
+_GEMM_BWD_MIN_PAIRS = 256 * 1024     # own-rows x columns above which the backward switches to dS + 2 GEMMs
+
+
 class _InfoNCE(torch.autograd.Function):
     """loss, scores = f(q_local, p_local ; q_all, p_all).  q_all / p_all are the (possibly gathered) matrices the
     loss is computed on; rows [q_row0, +len(q_local)) / [p_row0, +len(p_local)) of them are q_local / p_local.
@@ -137,6 +140,18 @@ class _InfoNCE(torch.autograd.Function):
         lib = _lib.load()
         need_q, need_p = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
         gl = grad_loss.to(torch.float32).contiguous()
+        if target_mode == RPO_TARGET_INBATCH and max(q_rows * P, p_rows * Q) >= _GEMM_BWD_MIN_PAIRS:
+            # large problems: the HIP kernel writes dS (and dS^T); dq = dS p and dp = dS^T q are then two plain
+            # GEMMs, which is what the vendor GEMM library is for (MFMA-bound, ~1.2 PFLOP/s through hipBLASLt)
+            ds = torch.empty((q_rows, P), dtype=q_all.dtype, device=q_all.device) if need_q else None
+            dst = torch.empty((p_rows, Q), dtype=q_all.dtype, device=q_all.device) if need_p else None
+            with torch.cuda.device(q_all.device):
+                check(lib.rpo_infonce_ds(scores.data_ptr(), lse.data_ptr(), gl.data_ptr(), Q, P, dt, temperature,
+                                         q_row0, q_rows if need_q else 0, p_row0, p_rows if need_p else 0, _p(ds),
+                                         _p(dst), _stream(q_all)), "rpo_infonce_ds")
+            dq = ds @ p_all if need_q else None
+            dp = dst @ q_all if need_p else None
+            return dq, dp, None, None, None, None, None, None
         dq = torch.empty((q_rows, d), dtype=q_all.dtype, device=q_all.device) if need_q else None
         dp = torch.empty((p_rows, d), dtype=q_all.dtype, device=q_all.device) if need_p else None
         if need_q or need_p:

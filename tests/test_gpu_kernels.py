@@ -372,3 +372,30 @@ def test_c_abi_argument_errors():
                                lse.data_ptr(), None, 0, None) == -3
     assert lib.rpo_pool_normalize_fwd(None, 0, 0, None, 1, 1, 1, 0, 0, 1, 1e-12, None, None, None, None) == -1
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Q,P,d,win", [(512, 1536, 128, None), (520, 1560, 192, None), (512, 2048, 64, (128, 200, 640, 600))])
+def test_infonce_backward_gemm_form(dtype, Q, P, d, win):
+    """Large problems take the dS-kernel + two-GEMM backward (ops._GEMM_BWD_MIN_PAIRS); same maths, same own-row
+    window semantics as the fused small-shape kernel."""
+    from rankpo_amd import ops as o
+    rs = np.random.RandomState(Q + P)
+    qn, pn = unit(rs.randn(Q, d)), unit(rs.randn(P, d))
+    qa, pa = t(qn, dtype), t(pn, dtype)
+    q0, qr, p0, pr = win if win else (0, Q, 0, P)
+    assert max(qr * P, pr * Q) >= o._GEMM_BWD_MIN_PAIRS
+    ql, pl = qa[q0:q0 + qr].clone().requires_grad_(True), pa[p0:p0 + pr].clone().requires_grad_(True)
+    loss, scores = o.infonce_loss(ql, pl, T, True, q_all=qa, p_all=pa, q_row0=q0, p_row0=p0)
+    (loss * 1.7).backward()
+    s = npf(scores)
+    G = P // Q
+    m = s.max(-1, keepdims=True)
+    lse = (m + np.log(np.exp(s - m).sum(-1, keepdims=True)))[:, 0]
+    ds = np.exp(s - lse[:, None])
+    ds[np.arange(Q), np.arange(Q) * G] -= 1
+    ds *= 1.7 / Q / T
+    dq_ref, dp_ref = (ds @ npf(pa))[q0:q0 + qr], (ds.T @ npf(qa))[p0:p0 + pr]
+    tol = 3e-4 if dtype == torch.float32 else 2.0 ** -6      # bf16: dS itself is rounded to bf16 before the GEMM
+    assert relmax(npf(ql.grad), dq_ref) < tol
+    assert relmax(npf(pl.grad), dp_ref) < tol
