@@ -46,6 +46,18 @@ template <> struct Vec16<float> {
     __device__ __forceinline__ void store(float* p) const {
         *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     }
+    // streaming (non-temporal) forms for data touched once
+    __device__ __forceinline__ void load_nt(const float* p) {
+        const uint4_t t = __builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(p));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __uint_as_float(t[i]);
+    }
+    __device__ __forceinline__ void store_nt(float* p) const {
+        uint4_t t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) t[i] = __float_as_uint(v[i]);
+        __builtin_nontemporal_store(t, reinterpret_cast<uint4_t*>(p));
+    }
 };
 template <> struct Vec16<bf16_t> {
     float v[8];
@@ -64,6 +76,21 @@ template <> struct Vec16<bf16_t> {
         for (int i = 0; i < 4; ++i)
             w[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ __forceinline__ void load_nt(const bf16_t* p) {
+        const uint4_t t = __builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(p));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(t[i] << 16);
+            v[2 * i + 1] = __uint_as_float(t[i] & 0xffff0000u);
+        }
+    }
+    __device__ __forceinline__ void store_nt(bf16_t* p) const {
+        uint4_t t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            t[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
+        __builtin_nontemporal_store(t, reinterpret_cast<uint4_t*>(p));
     }
 };
 

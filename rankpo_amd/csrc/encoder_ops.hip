@@ -15,36 +15,39 @@ __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __ex
 template <typename T>
 __global__ __launch_bounds__(kEwThreads) void swiglu_fwd_kernel(const T* __restrict__ g, const T* __restrict__ u,
                                                                 T* __restrict__ out, int64_t nvec) {
+    // ONE 16-byte vector per thread, block b owns the contiguous vectors [256 b, 256 b + 256), streaming
+    // (non-temporal) loads and stores: measured 6.6 TB/s on MI355X vs 4.6-4.9 TB/s for a capped grid-stride loop
+    // (tools/exp/exp_stream.hip).
     constexpr int V = Elem<T>::kVec;
-    for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kEwThreads) {
-        Vec16<T> a, b, o;
-        a.load(g + i * V);
-        b.load(u + i * V);
+    const int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
+    if (i >= nvec) return;
+    Vec16<T> a, b, o;
+    a.load_nt(g + i * V);
+    b.load_nt(u + i * V);
 #pragma unroll
-        for (int k = 0; k < V; ++k) o.v[k] = a.v[k] * sigmoid_f(a.v[k]) * b.v[k];
-        o.store(out + i * V);
-    }
+    for (int k = 0; k < V; ++k) o.v[k] = a.v[k] * sigmoid_f(a.v[k]) * b.v[k];
+    o.store_nt(out + i * V);
 }
 
 template <typename T>
 __global__ __launch_bounds__(kEwThreads) void swiglu_bwd_kernel(const T* g, const T* u, const T* dout, T* dg, T* du,
                                                                 int64_t nvec) {   // dg / du may alias g / u / dout
     constexpr int V = Elem<T>::kVec;
-    for (int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * kEwThreads) {
-        Vec16<T> a, b, d, og, ou;
-        a.load(g + i * V);
-        b.load(u + i * V);
-        d.load(dout + i * V);
+    const int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
+    if (i >= nvec) return;
+    Vec16<T> a, b, d, og, ou;
+    a.load_nt(g + i * V);
+    b.load_nt(u + i * V);
+    d.load_nt(dout + i * V);
 #pragma unroll
-        for (int k = 0; k < V; ++k) {
-            const float s = sigmoid_f(a.v[k]);
-            const float silu = a.v[k] * s;
-            og.v[k] = d.v[k] * b.v[k] * (s + silu * (1.0f - s));   // silu' = s (1 + g (1 - s))
-            ou.v[k] = d.v[k] * silu;
-        }
-        og.store(dg + i * V);
-        ou.store(du + i * V);
+    for (int k = 0; k < V; ++k) {
+        const float s = sigmoid_f(a.v[k]);
+        const float silu = a.v[k] * s;
+        og.v[k] = d.v[k] * b.v[k] * (s + silu * (1.0f - s));   // silu' = s (1 + g (1 - s))
+        ou.v[k] = d.v[k] * silu;
     }
+    og.store_nt(dg + i * V);
+    ou.store_nt(du + i * V);
 }
 
 // x: [rows, H, hd] (row stride = row_stride elements, heads contiguous), cos/sin: f32 [period, hd/2];
@@ -68,25 +71,21 @@ __global__ __launch_bounds__(kEwThreads) void rope_kernel(const T* xin, T* x, in
             T* lo = xr + h * hd + j;
             T* hi = lo + half;
             Vec16<T> a, b, oa, ob;
-            a.load(xi + h * hd + j);
-            b.load(xi + h * hd + j + half);
+            a.load_nt(xi + h * hd + j);
+            b.load_nt(xi + h * hd + j + half);
 #pragma unroll
             for (int k = 0; k < V; ++k) {
                 const float cc = c[j + k], ss = sign * s[j + k];
                 oa.v[k] = a.v[k] * cc - b.v[k] * ss;      // x1 cos - x2 sin
                 ob.v[k] = b.v[k] * cc + a.v[k] * ss;      // x2 cos + x1 sin
             }
-            oa.store(lo);
-            ob.store(hi);
+            oa.store_nt(lo);
+            ob.store_nt(hi);
         }
     }
 }
 
-inline unsigned ew_grid(int64_t nvec) {
-    int64_t b = rpo_cdiv(nvec, (int64_t)kEwThreads * 4);
-    if (b > 256 * 16) b = 256 * 16;
-    return (unsigned)(b < 1 ? 1 : b);
-}
+inline unsigned ew_grid(int64_t nvec) { return (unsigned)rpo_cdiv(nvec, kEwThreads); }
 
 }  // namespace
 
@@ -94,6 +93,7 @@ extern "C" int rpo_swiglu_fwd(const void* g, const void* u, void* out, int64_t n
     if (!g || !u || !out || n <= 0) return RPO_ERR_INVALID_ARG;
     const int V = dtype == RPO_DT_BF16 ? 8 : 4;
     if (n % V != 0 || !rpo_aligned16(g) || !rpo_aligned16(u) || !rpo_aligned16(out)) return RPO_ERR_UNSUPPORTED;
+    if (n / V / kEwThreads >= INT32_MAX) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RPO_DT_BF16)
         RPO_LAUNCH(swiglu_fwd_kernel<bf16_t>, dim3(ew_grid(n / V)), dim3(kEwThreads), 0, st, (const bf16_t*)g,
@@ -133,7 +133,7 @@ extern "C" int rpo_rope(const void* x_in, void* x, int64_t row_stride, const flo
     const int V = dtype == RPO_DT_BF16 ? 8 : 4;
     if ((head_dim / 2) % V != 0 || head_dim % 2 != 0 || row_stride % V != 0 || !rpo_aligned16(x) || !rpo_aligned16(x_in))
         return RPO_ERR_UNSUPPORTED;
-    int64_t grid = rows < 256 * 32 ? rows : 256 * 32;
+    int64_t grid = rows < INT32_MAX ? rows : INT32_MAX;   // one block per row: contiguous 2*heads*head_dim bytes
     hipStream_t st = (hipStream_t)stream;
     const float sign = backward ? -1.0f : 1.0f;
     if (dtype == RPO_DT_BF16)

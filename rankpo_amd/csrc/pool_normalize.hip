@@ -9,6 +9,7 @@ namespace {
 
 constexpr int kPoolThreads = 256;
 constexpr int kPoolWaves = kPoolThreads / RPO_WAVE;
+constexpr int kFillPerThread = 4;
 
 // First index of the minimum of mask[0..L) (torch.argmin semantics: ties -> smallest index).
 __device__ __forceinline__ int block_argmin_first(const int64_t* __restrict__ m, int64_t L, int64_t* s_val,
@@ -147,9 +148,11 @@ __global__ __launch_bounds__(kPoolThreads) void pool_normalize_bwd_kernel(
         const unsigned total = (unsigned)L * cpr;              // host guarantees < 2^31
         const uint4_t z = {0u, 0u, 0u, 0u};
         uint4_t* dst = reinterpret_cast<uint4_t*>(base);
-        for (unsigned i = blockIdx.x * kPoolThreads + threadIdx.x; i < total; i += gridDim.x * kPoolThreads) {
-            const unsigned l = i / cpr;
-            if ((int)l != my_idx) __builtin_nontemporal_store(z, dst + i);
+        // block b owns the contiguous chunks [b * 4 * 256, (b + 1) * 4 * 256): 4 streaming stores per thread
+#pragma unroll
+        for (int k = 0; k < kFillPerThread; ++k) {
+            const unsigned i = (blockIdx.x * kFillPerThread + k) * kPoolThreads + threadIdx.x;
+            if (i < total && (int)(i / cpr) != my_idx) __builtin_nontemporal_store(z, dst + i);
         }
     } else {
         const int64_t total = L * d;
@@ -177,9 +180,7 @@ int launch_bwd(const void* g, const void* y, const int32_t* idx, const float* no
     int64_t bx = 1;
     if (dh) {
         const int64_t per_sample = vec_ok ? L * (d / V) : L * d;
-        bx = rpo_cdiv(per_sample, (int64_t)kPoolThreads * 8);   // ~8 stores per thread
-        const int64_t cap = rpo_cdiv(256 * 16, N);               // ~16 blocks per CU in total
-        if (bx > cap) bx = cap;
+        bx = rpo_cdiv(per_sample, (int64_t)kPoolThreads * (vec_ok ? kFillPerThread : 8));
         if (bx < 1) bx = 1;
     }
     RPO_LAUNCH(pool_normalize_bwd_kernel<T>, dim3((unsigned)bx, (unsigned)N), dim3(kPoolThreads), 0, st,
