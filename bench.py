@@ -382,9 +382,25 @@ def main():
         }
         if kernels:
             top = kernels[0]
+            # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed
+            # rocprofv3 passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE over algorithmic bytes,
+            # measured per kernel at the same shapes) give the ratio that is applied to this run's bytes.
+            traffic, tsrc = None, None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                key = {"rpo_swiglu_fwd": "swiglu_fwd_kernel", "rpo_swiglu_bwd": "swiglu_bwd_kernel",
+                       "rpo_adamw_step": "adamw_kernel", "rpo_rope": "rope_kernel",
+                       "rpo_sumsq_partial": "sumsq_kernel"}.get(top["entry"])
+                if key in pmc:
+                    traffic = int(top["algo_bytes"] * pmc[key]["traffic_over_algorithmic"])
+                    tsrc = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                            "FETCH x2 gfx950 correction), ratio %.3f applied to this run's algorithmic bytes"
+                            % pmc[key]["traffic_over_algorithmic"])
+            except Exception:
+                pass
             out["roofline"] = {"kernel": top["entry"], "bound": "hbm", "achieved": top["achieved_GBs"],
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": None,
-                               "avg_us": top["avg_us"], "algo_bytes": top["algo_bytes"]}
+                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": traffic,
+                               "traffic_source": tsrc, "avg_us": top["avg_us"], "algo_bytes": top["algo_bytes"]}
             out["kernels"] = kernels
         if world == 1 and not args.no_sweep:
             out["roofline_sweep"] = sweep(timed, device)
