@@ -8,7 +8,8 @@ MI355X notes
   * Llama + right padding (what both reference collators produce, data_utils.py:64-70, 205-212): a causal model
     never lets a real token see the pad tokens behind it, so the padding mask is dropped and attention runs as
     pure causal flash attention; only pad positions (never pooled) differ from a masked run.
-  * `forward_pooled` skips the final RMSNorm on every position but the pooled one.
+  * `pooled_last_token`: tokens packed (no pad tokens), variable-length causal flash attention, the LAST block computes
+    only K/V for all tokens and everything else for the pooled rows, final RMSNorm on the pooled rows only.
 """
 from __future__ import annotations
 
@@ -136,6 +137,11 @@ class RopeTables:
     def __init__(self, freqs: torch.Tensor):
         self.cos32, self.sin32 = freqs.cos().contiguous(), freqs.sin().contiguous()
 
+    def select(self, idx):
+        out = RopeTables.__new__(RopeTables)
+        out.cos32, out.sin32 = self.cos32.index_select(0, idx).contiguous(), self.sin32.index_select(0, idx).contiguous()
+        return out
+
     def full(self, dtype, packed: bool):
         # HF LlamaRotaryEmbedding: emb = cat(freqs, freqs); cos(emb).to(dtype)
         cos = torch.cat((self.cos32, self.cos32), -1).to(dtype)
@@ -160,6 +166,22 @@ def _varlen_causal_attention(q, k, v, ctx: VarlenCtx):
         a = F.scaled_dot_product_attention(q[o0:o0 + n].transpose(0, 1)[None], k[o0:o0 + n].transpose(0, 1)[None],
                                            v[o0:o0 + n].transpose(0, 1)[None], is_causal=True,
                                            enable_gqa=k.shape[1] != q.shape[1])
+        outs.append(a[0].transpose(0, 1))
+        o0 += n
+    return torch.cat(outs, 0)
+
+
+def _varlen_last_query_attention(q, k, v, ctx: VarlenCtx):
+    """q [N, nh, hd]: ONE query per sequence (its last token); k/v [T, nkv, hd] packed.  The last token attends to
+    every key of its own sequence, so no causal mask is needed."""
+    N = q.shape[0]
+    if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16):
+        cu_q = torch.arange(N + 1, device=q.device, dtype=torch.int32)
+        return torch.ops.aten._flash_attention_forward(q, k, v, cu_q, ctx.cu, 1, ctx.max_len, 0.0, False, False)[0]
+    outs, o0 = [], 0
+    for i, n in enumerate(ctx.lens):
+        a = F.scaled_dot_product_attention(q[i:i + 1].transpose(0, 1)[None], k[o0:o0 + n].transpose(0, 1)[None],
+                                           v[o0:o0 + n].transpose(0, 1)[None], enable_gqa=k.shape[1] != q.shape[1])
         outs.append(a[0].transpose(0, 1))
         o0 += n
     return torch.cat(outs, 0)
@@ -232,6 +254,31 @@ class LlamaLayer(nn.Module):
         x = x + self.self_attn(self.input_layernorm(x), rope, attn_mask)
         return x + self.mlp(self.post_attention_layernorm(x))
 
+    def forward_last_rows(self, x, rope, ctx, last_idx):
+        """The LAST block of a last-token-pooled encoder: only the pooled rows are consumed downstream, so K and V
+        are computed for every token but Q, the attention output, o_proj and the whole MLP only for the N pooled
+        rows (saves ~1/num_layers of the GEMM and attention work, forward and backward).  x: packed [1, T, d];
+        returns [N, d]."""
+        att = self.self_attn
+        h = self.input_layernorm(x)
+        T = h.shape[1]
+        k, v = att.k_proj(h), att.v_proj(h)
+        q = att.q_proj(h[0].index_select(0, last_idx))                       # [N, nh*hd]
+        rope_last = rope.select(last_idx)
+        if _ops.fused_encoder_ops_ok(x, att.hd):
+            q = _ops.rope_(q, rope_last.cos32, rope_last.sin32, att.nh, att.hd)
+            k = _ops.rope_(k, rope.cos32, rope.sin32, att.nkv, att.hd)
+            q, k = q.view(-1, att.nh, att.hd), k.view(T, att.nkv, att.hd)
+        else:
+            q, k = q.view(-1, att.nh, att.hd), k.view(T, att.nkv, att.hd)
+            cq, sq = rope_last.full(x.dtype, packed=True)
+            ck, sk = rope.full(x.dtype, packed=True)
+            q = q * cq + _rotate_half(q) * sq
+            k = k * ck + _rotate_half(k) * sk
+        o = _varlen_last_query_attention(q, k, v.view(T, att.nkv, att.hd), ctx)
+        xl = x[0].index_select(0, last_idx) + att.o_proj(o.reshape(-1, att.nh * att.hd))
+        return xl + self.mlp(self.post_attention_layernorm(xl))
+
 
 class LlamaEncoder(nn.Module):
     """Decoder-only Llama stack without lm_head (== HF `LlamaModel`)."""
@@ -300,10 +347,10 @@ class LlamaEncoder(nn.Module):
         h = self.norm(self.hidden_states(input_ids, attention_mask))
         return EncoderOutput(last_hidden_state=h) if return_dict else (h,)
 
-    def _run_layers(self, x, rope, ctx):
+    def _run_layers(self, x, rope, ctx, upto=None):
         ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
         nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
-        for i, layer in enumerate(self.layers):
+        for i, layer in enumerate(self.layers if upto is None else self.layers[:upto]):
             if ck and i < nck:
                 x = checkpoint(layer, x, rope, ctx, use_reentrant=False)
             else:
@@ -333,8 +380,15 @@ class LlamaEncoder(nn.Module):
         cu = torch.zeros(N + 1, dtype=torch.int32, device=x.device)
         cu[1:] = lens_d.cumsum(0).to(torch.int32)
         ctx = VarlenCtx(cu, lens, max(lens))
-        x = self._run_layers(x, rope, ctx)
-        last = x[0].index_select(0, (cu[1:] - 1).to(torch.int64))                          # [N, d]
+        last_idx = (cu[1:] - 1).to(torch.int64)
+        x = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1)
+        li = len(self.layers) - 1
+        ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
+        nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
+        if ck and li < nck:
+            last = checkpoint(self.layers[li].forward_last_rows, x, rope, ctx, last_idx, use_reentrant=False)
+        else:
+            last = self.layers[li].forward_last_rows(x, rope, ctx, last_idx)                # [N, d]
         return self.norm(last)
 
 
