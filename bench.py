@@ -171,28 +171,42 @@ def synth_batch(cfg, B, K, Lq, Lp, seed, device):
 
 
 def sweep(lib_timed, device):
-    """Similarity + InfoNCE kernel on the scaled shapes where it is MFMA-bound."""
-    from rankpo_amd import ops
+    """Similarity + InfoNCE forward (rpo_infonce_fwd: tile kernel + finalize) on the scaled shapes where it is
+    MFMA-bound, called through the C ABI with preallocated buffers, 3 interleaved rounds."""
+    from rankpo_amd import _lib
+    lib = _lib.load()
     res = []
-    for Q, d in ((1024, 2048), (4096, 2048), (16384, 2048), (4096, 4096)):
+    st = torch.cuda.current_stream().cuda_stream
+    for Q, d in ((2048, 2048), (4096, 2048), (8192, 2048), (16384, 2048), (4096, 4096)):
         P = Q
-        q = torch.nn.functional.normalize(torch.randn(Q, d, device=device), dim=-1).to(torch.bfloat16).requires_grad_(True)
-        p = torch.nn.functional.normalize(torch.randn(P, d, device=device), dim=-1).to(torch.bfloat16).requires_grad_(True)
-        for _ in range(2):
-            loss, _ = ops.infonce_loss(q, p, 0.02)
+        q = torch.nn.functional.normalize(torch.randn(Q, d, device=device), dim=-1).to(torch.bfloat16)
+        p = torch.nn.functional.normalize(torch.randn(P, d, device=device), dim=-1).to(torch.bfloat16)
+        scores = torch.empty(Q, P, device=device, dtype=torch.bfloat16)
+        lse = torch.empty(Q, device=device)
+        loss = torch.empty((), device=device)
+        nws = lib.rpo_infonce_workspace_bytes(Q, P, d, 1)
+        ws = torch.empty(nws, dtype=torch.uint8, device=device)
+        call = lambda: lib.rpo_infonce_fwd(q.data_ptr(), p.data_ptr(), Q, P, d, 1, 0.02, 0, scores.data_ptr(),
+                                           lse.data_ptr(), loss.data_ptr(), ws.data_ptr(), nws, st)
+        for _ in range(5):
+            assert call() == 0
         torch.cuda.synchronize()
-        reps = 5
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            loss, _ = ops.infonce_loss(q, p, 0.02)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+        best = None
+        reps = 20 if Q <= 8192 else 8
+        for _ in range(3):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            best = ms if best is None else min(best, ms)
         fl = 2.0 * Q * P * d
-        res.append(dict(kernel="rpo_infonce_fwd", Q=Q, P=P, d=d, dtype="bf16", ms=round(ms, 4),
-                        achieved_TFLOPs=round(fl / ms / 1e9, 1), frac_mfma=round(fl / ms / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)))
-        del q, p, loss
+        res.append(dict(kernel="rpo_infonce_fwd", Q=Q, P=P, d=d, dtype="bf16", ms=round(best, 4),
+                        achieved_TFLOPs=round(fl / best / 1e9, 1),
+                        frac_mfma=round(fl / best / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)))
+        del q, p, scores, ws
     return res
 
 

@@ -16,6 +16,7 @@
 // Backward: dS = grad * (softmax(S) - onehot) / (Q T) is recomputed from the stored scores and lse;
 //   dq = dS p (own q rows), dp = dS^T q (own p rows).
 #include "common.hpp"
+#include <cstdlib>
 
 int rpo_launch_grouped_dots(const void* q, const void* p, int64_t B, int64_t G, int64_t d, int dtype, float* out,
                             hipStream_t st);
@@ -48,14 +49,25 @@ template <> struct Mma<float> {
     __device__ static __forceinline__ Frag zero() { return Frag{0.f, 0.f, 0.f, 0.f}; }
 };
 
-// scores = round(round(dot) / T) in the storage dtype (the reference's rounding points for bf16;
-// identity roundings for f32).  T == 1 (eval branch) skips the division.
+// scores = round(round(dot) / T) in the storage dtype (the reference's rounding points for bf16; identity roundings
+// for f32).  T == 1 (eval branch) skips the division.  The quotient is x * (1/T) refined by one FMA pair
+// (r = x - q T; q += r / T): correctly rounded except in rare last-bit cases, at 3 VALU slots instead of the ~10 of
+// the IEEE division sequence -- the epilogue is 128 elements per lane in the 256 x 256 kernel.
 template <typename T>
-__device__ __forceinline__ float finish_score(float acc, float temperature, bool scale) {
+__device__ __forceinline__ float finish_score(float acc, float temperature, float inv_temperature, bool scale) {
     float x = Elem<T>::round(acc);
-    if (scale) x = Elem<T>::round(x / temperature);
+    if (scale) {
+        float qv = x * inv_temperature;
+        const float r = fmaf(-qv, temperature, x);
+        qv = fmaf(r, inv_temperature, qv);
+        x = Elem<T>::round(qv);
+    }
     return x;
 }
+
+// exp(v - m) as one FMA + one v_exp_f32
+#define RPO_LOG2E 1.4426950408889634f
+__device__ __forceinline__ float exp_sub(float v, float m_log2e) { return __builtin_amdgcn_exp2f(fmaf(v, RPO_LOG2E, -m_log2e)); }
 
 __device__ __forceinline__ void softmax_merge(float& m, float& l, float om, float ol) {
     const float M = fmaxf(m, om);
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     const int64_t pbase = p0 + wp * 64 + g * 4;
     const int64_t qbase = q0 + wq * 64 + frow;
     const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
+    const float inv_t = 1.0f / temperature;
     float2* s_stat = reinterpret_cast<float2*>(smem);   // [wq][64] from the wp == 1 waves (LDS is free now)
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                v[m][j] = finish_score<T>(acc[m][n][j], temperature, scale);
+                v[m][j] = finish_score<T>(acc[m][n][j], temperature, inv_t, scale);
                 if (pbase + 16 * m + j < P) mx = fmaxf(mx, v[m][j]);
             }
             if (qv) store_scores4<T>(scores + qi * P, pbase + 16 * m, P, v[m], vec_ok);
@@ -206,7 +219,7 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (pbase + 16 * m + j < P) sum += __expf(v[m][j] - mx);
+                    if (pbase + 16 * m + j < P) sum += exp_sub(v[m][j], mx * RPO_LOG2E);
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
                 const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
@@ -214,6 +227,258 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
             }
             if (wp == 1 && g == 0) s_stat[wq * 64 + 16 * n + frow] = make_float2(mx, sum);
             acc[0][n][0] = mx;   // keep for the cross-wave merge below
+            acc[0][n][1] = sum;
+        }
+    }
+    if (do_stats) {
+        __syncthreads();
+        if (wp == 0 && g == 0) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const int64_t qi = qbase + 16 * n;
+                float mx = acc[0][n][0], sum = acc[0][n][1];
+                const float2 o = s_stat[wq * 64 + 16 * n + frow];
+                softmax_merge(mx, sum, o.x, o.y);
+                if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// 256 x 256 tile kernel (bf16, Q and P >= 512): 8 waves as 2 (passage halves) x 4 (query quarters), 128 x 64 scores^T
+// per wave = 32 accumulator fragments (128 VGPRs), K-step 64, ONE block per CU, LDS 128 KiB = 2 buffers x 4 units of
+// 16 KiB.  A K-step is cut into 4 phases; each phase issues the ds_reads of one operand sub-tile, the 16-byte
+// global_load_lds of ONE unit of the NEXT K-step, a COUNTED s_waitcnt vmcnt(4) (two units stay in flight across the
+// raw s_barrier), and 16 MFMAs (one quadrant of the wave's tile over the whole K-step); the two wave groups
+// (wp = 0 / 1, SIMD partners) run half a phase apart so that MFMAs of one overlap the loads of the other:
+//
+//   phase   ds_read (this K-step)            glds (next K-step)   MFMAs (acc quadrant)
+//     0     A rows sub0 (8) + B sub0 (4)     unit 0 = A sub0 rows  m 0-3 x n 0-1
+//     1     B sub1 (4)                       unit 1 = B sub0 rows  m 0-3 x n 2-3
+//     2     A rows sub1 (8)                  unit 2 = B sub1 rows  m 4-7 x n 2-3
+//     3     -                                unit 3 = A sub1 rows  m 4-7 x n 0-1
+//
+// Units are laid out by FIRST USE (unit 0/1 are needed in phase 0, unit 2 in phase 1, unit 3 in phase 2), so that the
+// wait that retires a unit always sits one full phase (one barrier) before its first read, and a unit is overwritten
+// four phases after its last read.  LDS rows are 128 bytes, lane-linear per 1 KiB DMA piece, XOR-swizzled
+// (chunk ^= row & 7) on the per-lane SOURCE address and on the ds_read_b128 address.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBigTile = 256, kBigThreads = 512, kBigUnitBytes = 128 * kTileRowBytes;   // 16 KiB
+constexpr int kBigBufBytes = 4 * kBigUnitBytes, kBigLdsBytes = 2 * kBigBufBytes;        // 64 KiB, 128 KiB
+
+// tile row (0..255) of unit-local row u (0..127)
+__device__ __forceinline__ int big_unit_row(int unit, int u) {
+    switch (unit) {
+        case 0: return (u & 63) + ((u >> 6) << 7);              // A: rows   0-63, 128-191
+        case 3: return 64 + (u & 63) + ((u >> 6) << 7);         // A: rows 64-127, 192-255
+        case 1: return ((u >> 5) << 6) + (u & 31);              // B: rows 64 wq + 0..31
+        default: return ((u >> 5) << 6) + 32 + (u & 31);        // B: rows 64 wq + 32..63
+    }
+}
+
+__global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
+    int scale, int do_stats, bf16_t* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt,
+    int stagger) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef short8_t Frag;
+    constexpr int KE = 64;   // bf16 elements per K-step
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave >> 2, wq = wave & 3;
+    const int g = lane >> 4, frow = lane & 15;
+
+    const int nwg = nPt * nQt;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
+    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+    constexpr int GROUP = 4;
+    const int width = GROUP * nQt;
+    const int group_id = wg / width;
+    const int first_p = group_id * GROUP;
+    const int gsz = min(nPt - first_p, GROUP);
+    const int pt = first_p + (wg % width) % gsz;
+    const int qt = (wg % width) / gsz;
+    const int64_t p0 = (int64_t)pt * kBigTile, q0 = (int64_t)qt * kBigTile;
+
+    // staging: a unit is 16 DMA pieces of 1 KiB (8 rows); wave w issues pieces w and 8 + w of every unit.
+    const int srow = lane >> 3;
+    const int lchunk = (lane & 7) ^ srow;
+    const bf16_t* src[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int ur = (8 * j + wave) * 8 + srow;           // unit-local row
+            const int tr = big_unit_row(u, ur);                 // tile row
+            const bool isA = (u == 0 || u == 3);
+            const int64_t gr = isA ? min(p0 + tr, P - 1) : min(q0 + tr, Q - 1);
+            src[u][j] = (isA ? p : q) + gr * d + lchunk * 8;
+        }
+#define RPO_BIG_STAGE(U, T, BUF)                                                                                   \
+    do {                                                                                                           \
+        _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                         \
+            char* dst_ = smem + (BUF) * kBigBufBytes + (U) * kBigUnitBytes + (8 * j_ + wave) * 1024;               \
+            __builtin_amdgcn_global_load_lds(                                                                      \
+                (const __attribute__((address_space(1))) void*)(src[U][j_] + (int64_t)(T) * KE),                   \
+                (__attribute__((address_space(3))) void*)dst_, 16, 0, 0);                                          \
+        }                                                                                                          \
+    } while (0)
+
+    float4_t acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (int)(d / KE);
+    // per-lane read offsets inside a unit (row part); the chunk part depends on the k-step
+    const int a_off = (wp * 64 + frow) * kTileRowBytes;         // + m*16 rows, units 0 / 3
+    const int b_off = (wq * 32 + frow) * kTileRowBytes;         // + n*16 rows, units 1 / 2
+    const int c0 = ((0 * 4 + g) ^ (lane & 7)) << 4, c1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
+
+    RPO_BIG_STAGE(0, 0, 0);
+    RPO_BIG_STAGE(1, 0, 0);
+    RPO_BIG_STAGE(2, 0, 0);
+    RPO_BIG_STAGE(3, 0, 0);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // units 0, 1 of K-step 0 have landed (this wave's pieces)
+    __builtin_amdgcn_s_barrier();
+
+    // Two barriers per phase (load part | MFMA part) and the two wave groups offset by ONE barrier: while waves 0-3
+    // (wp = 0) run their 16 MFMAs, waves 4-7 -- their SIMD partners -- issue ds_reads / LDS-DMA, and vice versa, so
+    // the matrix pipe of every SIMD always has one wave in its MFMA part.  A unit retired by the vmcnt of phase g is
+    // read in phase g + 1 at the earliest: by then both groups' waits and one more barrier have passed.
+    if (stagger && wp == 1) __builtin_amdgcn_s_barrier();
+    Frag a[4][2], b0[2][2], b1[2][2];                           // [rep][k-step half]
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1, nxt = cur ^ 1;
+        const bool more = t + 1 < nk;
+        const char* base = smem + cur * kBigBufBytes;
+        // ---------------- phase 0
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            b0[n][0] = *reinterpret_cast<const Frag*>(base + 1 * kBigUnitBytes + b_off + n * 16 * kTileRowBytes + c0);
+            b0[n][1] = *reinterpret_cast<const Frag*>(base + 1 * kBigUnitBytes + b_off + n * 16 * kTileRowBytes + c1);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            a[m][0] = *reinterpret_cast<const Frag*>(base + 0 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c0);
+            a[m][1] = *reinterpret_cast<const Frag*>(base + 0 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c1);
+        }
+        if (more) {
+            RPO_BIG_STAGE(0, t + 1, nxt);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // retires unit 2 of this K-step (read in phase 1)
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][h], b0[n][h], acc[m][n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 1
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            b1[n][0] = *reinterpret_cast<const Frag*>(base + 2 * kBigUnitBytes + b_off + n * 16 * kTileRowBytes + c0);
+            b1[n][1] = *reinterpret_cast<const Frag*>(base + 2 * kBigUnitBytes + b_off + n * 16 * kTileRowBytes + c1);
+        }
+        if (more) {
+            RPO_BIG_STAGE(1, t + 1, nxt);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // retires unit 3 of this K-step (read in phase 2)
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][h], b1[n][h], acc[m][2 + n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 2
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            a[m][0] = *reinterpret_cast<const Frag*>(base + 3 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c0);
+            a[m][1] = *reinterpret_cast<const Frag*>(base + 3 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c1);
+        }
+        if (more) RPO_BIG_STAGE(2, t + 1, nxt);                 // nothing to retire here: units 0', 1' are due in phase 3
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[4 + m][2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][h], b1[n][h], acc[4 + m][2 + n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+        // ---------------- phase 3
+        if (more) {
+            RPO_BIG_STAGE(3, t + 1, nxt);
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // retires units 0', 1' of the next K-step (read in its phase 0)
+        }
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[4 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][h], b0[n][h], acc[4 + m][n], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_barrier();
+    }
+#undef RPO_BIG_STAGE
+    if (stagger && wp == 0) __builtin_amdgcn_s_barrier();
+    __syncthreads();   // every wave is done with LDS before it is reused for the statistics exchange
+
+    // ---- epilogue: acc[m][n][j] = <p_{pbase + 16m + j}, q_{qbase + 16n}>
+    const int64_t pbase = p0 + wp * 128 + g * 4;
+    const int64_t qbase = q0 + wq * 64 + frow;
+    const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
+    const float inv_t = 1.0f / temperature;
+    float2* s_stat = reinterpret_cast<float2*>(smem);   // [wq][64] from the wp == 1 waves
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int64_t qi = qbase + 16 * n;
+        const bool qv = qi < Q;
+        float mx = RPO_NEG_INF, sum = 0.f;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[j] = finish_score<bf16_t>(acc[m][n][j], temperature, inv_t, scale);
+                acc[m][n][j] = v[j];
+                if (pbase + 16 * m + j < P) mx = fmaxf(mx, v[j]);
+            }
+            if (qv) store_scores4<bf16_t>(scores + qi * P, pbase + 16 * m, P, v, vec_ok);
+        }
+        if (do_stats) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (pbase + 16 * m + j < P) sum += exp_sub(acc[m][n][j], mx * RPO_LOG2E);
+#pragma unroll
+            for (int o = 16; o <= 32; o <<= 1) {
+                const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
+                softmax_merge(mx, sum, om, ol);
+            }
+            if (wp == 1 && g == 0) s_stat[wq * 64 + 16 * n + frow] = make_float2(mx, sum);
+            acc[0][n][0] = mx;
             acc[0][n][1] = sum;
         }
     }
@@ -284,6 +549,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
     if (wave != 0) return;
     const int64_t pbase = p0 + g * 4;
     const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
+    const float inv_t = 1.0f / temperature;
 #pragma unroll
     for (int n = 0; n < NQ; ++n) {
 #pragma unroll
@@ -296,7 +562,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
         float mx = RPO_NEG_INF;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[j] = finish_score<T>(acc[n][j], temperature, scale);
+            v[j] = finish_score<T>(acc[n][j], temperature, inv_t, scale);
             if (pbase + j < P) mx = fmaxf(mx, v[j]);
         }
         if (qi < Q) store_scores4<T>(scores + qi * P, pbase, P, v, vec_ok);
@@ -304,7 +570,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
             float sum = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (pbase + j < P) sum += __expf(v[j] - mx);
+                if (pbase + j < P) sum += exp_sub(v[j], mx * RPO_LOG2E);
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
                 const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
@@ -333,7 +599,7 @@ __global__ __launch_bounds__(256) void sim_rowwise_kernel(const T* __restrict__ 
         float a = 0.f;
         for (int64_t c = lane; c < d; c += 64) a = fmaf(Elem<T>::ld(qi + c), Elem<T>::ld(pj + c), a);
         a = wave_sum(a);
-        const float v = finish_score<T>(a, temperature, scale);
+        const float v = finish_score<T>(a, temperature, 1.0f / temperature, scale);
         if (lane == 0) Elem<T>::st(scores + i * P + j, v);
         softmax_merge(mx, sum, v, 1.0f);
     }
@@ -410,7 +676,7 @@ __global__ __launch_bounds__(kFinThreads) void first_finalize_kernel(const float
     for (int64_t b = threadIdx.x; b < B; b += kFinThreads) {
         float m = RPO_NEG_INF, l = 0.f, s0 = 0.f;
         for (int64_t gi = 0; gi < G; ++gi) {
-            const float v = finish_score<T>(raw[b * G + gi], temperature, scale);
+            const float v = finish_score<T>(raw[b * G + gi], temperature, 1.0f / temperature, scale);
             Elem<T>::st(scores + b * G + gi, v);
             if (gi == 0) s0 = v;
             softmax_merge(m, l, v, 1.0f);
@@ -595,7 +861,7 @@ __global__ __launch_bounds__(256) void infonce_first_bwd_kernel(
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-enum FwdPath { PATH_TILE = 0, PATH_SKINNY = 1, PATH_ROWWISE = 2 };
+enum FwdPath { PATH_TILE = 0, PATH_SKINNY = 1, PATH_ROWWISE = 2, PATH_TILE256 = 3 };
 
 struct Plan {
     int path;
@@ -606,6 +872,16 @@ struct Plan {
 };
 
 template <typename T> constexpr int row_elems() { return kTileRowBytes / (int)sizeof(T); }
+
+static bool force_small_tile() {   // RPO_SIM_TILE=128 keeps the 128x128 kernel (A/B comparisons, tests)
+    static const int v = [] { const char* e = getenv("RPO_SIM_TILE"); return e && atoi(e) == 128 ? 1 : 0; }();
+    return v != 0;
+}
+
+static int sim_stagger() {   // RPO_SIM_STAGGER=0/1 (experiments); default on
+    const char* e = getenv("RPO_SIM_STAGGER");
+    return e ? atoi(e) : 1;
+}
 
 static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) {
     Plan pl{};
@@ -624,9 +900,13 @@ static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) 
             pl.nPb = 1;
         }
     } else {
-        pl.path = PATH_TILE;
-        pl.nPt = (int)rpo_cdiv(P, kTileP);
-        pl.nQt = (int)rpo_cdiv(Q, kTileQ);
+        // the 256 x 256 kernel runs one block per CU: take it only when its grid can fill most of the 256 CUs
+        const bool big = dtype == RPO_DT_BF16 && !force_small_tile() &&
+                         rpo_cdiv(P, kBigTile) * rpo_cdiv(Q, kBigTile) >= 192;
+        const int tile = big ? kBigTile : kTileP;
+        pl.path = big ? PATH_TILE256 : PATH_TILE;
+        pl.nPt = (int)rpo_cdiv(P, tile);
+        pl.nQt = (int)rpo_cdiv(Q, tile);
         pl.nPb = pl.nPt;
     }
     pl.nFin = (int)rpo_cdiv(Q, kFinThreads);
@@ -675,6 +955,18 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         RPO_LAUNCH(sim_tile_kernel<T>, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kTileThreads), kTileLdsBytes,
                            st, (const T*)q, (const T*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
                            (T*)scores_out, partial, pl.nPt, pl.nQt);
+    } else if (pl.path == PATH_TILE256) {
+        if constexpr (sizeof(T) == 2) {
+            static bool attr_set256 = false;
+            if (!attr_set256) {
+                (void)hipFuncSetAttribute((const void*)sim_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kBigLdsBytes);
+                attr_set256 = true;
+            }
+            RPO_LAUNCH(sim_tile256_kernel, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kBigThreads), kBigLdsBytes, st,
+                       (const bf16_t*)q, (const bf16_t*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
+                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, sim_stagger());
+        }
     } else if (pl.path == PATH_SKINNY) {
         const dim3 grid((unsigned)pl.nPb), block(kSkinnyThreads);
         const int nq = (int)rpo_cdiv(Q, 16);

@@ -157,6 +157,9 @@ SHAPES = [
     (130, 390, 192),    # tile, ragged edges
     (128, 128, 64),     # tile, single K step (bf16)
     (100, 700, 96),     # Q > 64 with d % 64 != 0 -> rowwise (bf16) / tile (f32)
+    (512, 512, 64),     # 256x256 phased tile kernel (bf16), single K step
+    (512, 1536, 256),   # 256x256 kernel, 4 K steps
+    (600, 1800, 192),   # 256x256 kernel, ragged edges in both dimensions, odd K-step count
 ]
 
 
