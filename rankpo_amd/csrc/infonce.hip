@@ -265,7 +265,9 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
 // (chunk ^= row & 7) on the per-lane SOURCE address and on the ds_read_b128 address.
 // ------------------------------------------------------------------------------------------------
 constexpr int kBigTile = 256, kBigThreads = 512, kBigUnitBytes = 128 * kTileRowBytes;   // 16 KiB
-constexpr int kBigBufBytes = 4 * kBigUnitBytes, kBigLdsBytes = 2 * kBigBufBytes;        // 64 KiB, 128 KiB
+constexpr int kBigBufBytes = 4 * kBigUnitBytes;                                         // 64 KiB per buffer
+constexpr int kBigStageRowBytes = 272, kBigStageWaveBytes = 64 * kBigStageRowBytes;     // epilogue score staging
+constexpr int kBigLdsBytes = 8 * kBigStageWaveBytes + 4 * 64 * 8;                       // 141,312 B >= 2 buffers
 
 // tile row (0..255) of unit-local row u (0..127)
 __device__ __forceinline__ int big_unit_row(int unit, int u) {
@@ -280,7 +282,7 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
 __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
     int scale, int do_stats, bf16_t* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt,
-    int stagger) {
+    int stagger, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef short8_t Frag;
     constexpr int KE = 64;   // bf16 elements per K-step
@@ -449,7 +451,13 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     const int64_t qbase = q0 + wq * 64 + frow;
     const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
     const float inv_t = 1.0f / temperature;
-    float2* s_stat = reinterpret_cast<float2*>(smem);   // [wq][64] from the wp == 1 waves
+    // Scores leave through LDS: each wave parks its 64 (q) x 128 (p) bf16 sub-tile in its own 64 x 272-byte image
+    // (8-byte ds_writes of 4 consecutive p) and streams it out as whole 256-byte row segments with 16-byte stores,
+    // instead of 8-byte stores that touch a quarter of a 128-byte line each (measured: the direct stores cost 14 %
+    // of the kernel at Q = P = 16384).
+    const bool staged = (P % 8 == 0) && rpo_aligned16_dev(scores) && !(dbg & 2);
+    char* wstage = smem + wave * kBigStageWaveBytes;
+    float2* s_stat = reinterpret_cast<float2*>(smem + 8 * kBigStageWaveBytes);   // [wq][64] from the wp == 1 waves
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int64_t qi = qbase + 16 * n;
@@ -464,7 +472,14 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                 acc[m][n][j] = v[j];
                 if (pbase + 16 * m + j < P) mx = fmaxf(mx, v[j]);
             }
-            if (qv) store_scores4<bf16_t>(scores + qi * P, pbase + 16 * m, P, v, vec_ok);
+            if (staged) {
+                uint2 w;
+                w.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
+            } else if (qv && !(dbg & 1)) {
+                store_scores4<bf16_t>(scores + qi * P, pbase + 16 * m, P, v, vec_ok);
+            }
         }
         if (do_stats) {
 #pragma unroll
@@ -480,6 +495,26 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
             if (wp == 1 && g == 0) s_stat[wq * 64 + 16 * n + frow] = make_float2(mx, sum);
             acc[0][n][0] = mx;
             acc[0][n][1] = sum;
+        }
+    }
+    if (staged && !(dbg & 1)) {
+        const int64_t prow0 = p0 + wp * 128 + (lane & 15) * 8;          // first of this lane's 8 passage columns
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int r = 4 * i + (lane >> 4);
+            const int64_t qi = q0 + wq * 64 + r;
+            const uint4 w = *reinterpret_cast<const uint4*>(wstage + r * kBigStageRowBytes + (lane & 15) * 16);
+            if (qi < Q) {
+                bf16_t* dst = scores + qi * P + prow0;
+                if (prow0 + 7 < P) {
+                    *reinterpret_cast<uint4*>(dst) = w;
+                } else {
+                    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        if (prow0 + e < P) dst[e] = (bf16_t)(ww[e >> 1] >> ((e & 1) * 16));
+                }
+            }
         }
     }
     if (do_stats) {
@@ -883,6 +918,11 @@ static int sim_stagger() {   // RPO_SIM_STAGGER=0/1 (experiments); default on
     return e ? atoi(e) : 1;
 }
 
+static int sim_dbg() {   // RPO_SIM_DBG bit 0: skip the score stores (timing experiments only)
+    const char* e = getenv("RPO_SIM_DBG");
+    return e ? atoi(e) : 0;
+}
+
 static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) {
     Plan pl{};
     const int es = dtype == RPO_DT_BF16 ? 2 : 4;
@@ -965,7 +1005,7 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
             }
             RPO_LAUNCH(sim_tile256_kernel, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kBigThreads), kBigLdsBytes, st,
                        (const bf16_t*)q, (const bf16_t*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
-                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, sim_stagger());
+                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, sim_stagger(), sim_dbg());
         }
     } else if (pl.path == PATH_SKINNY) {
         const dim3 grid((unsigned)pl.nPb), block(kSkinnyThreads);
