@@ -183,3 +183,84 @@ def test_flat_adamw_matches_torch_adamw(dtype):
             for p, q in zip(net.parameters(), ref.parameters()):
                 assert (p.float() - q).abs().max() <= 2.0 ** -7 * max(1.0, q.abs().max().item())
                 q.data.copy_(opt.master[opt.reducer.offsets[[id(x) for x in opt.reducer.order].index(id(p))]:][:p.numel()].view_as(p))
+
+
+def test_bert_cls_model_step_vs_oracle_cfg1_arch():
+    """Config-1 architecture family (BERT / BGE, CLS pooling, f32): full ModelForTraining step vs the CPU oracle."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    torch.manual_seed(9)
+    cfg = PE.bert_config(vocab_size=300, hidden_size=96, intermediate_size=192, num_hidden_layers=2,
+                         num_attention_heads=4, max_position_embeddings=64)
+    enc = PE.BertEncoder(cfg)
+    w = E.state_dict_to_f32(enc)
+    rs = np.random.RandomState(10)
+    qi, qm = _batch(rs, 4, 16, 300)
+    pi, pm = _batch(rs, 24, 32, 300)
+    cb = {"query": {"input_ids": qi, "attention_mask": qm}, "passage": {"input_ids": pi, "attention_mask": pm}}
+    gb = {k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in cb.items()}
+    for inbatch in (True, False):
+        model = rankpo_amd.ModelForTraining(encoder=enc.to(DEV), temperature=0.02, use_inbatch_neg=inbatch).train()
+        assert model.pooling_mode == "cls"
+        out = model(**gb)
+        ref_loss, ref_s, ref_q, ref_p = E.contrastive_step(w, cfg.to_dict(), cb, 0.02, use_inbatch_neg=inbatch)
+        assert (out.q_reps.cpu() - ref_q).abs().max() < 2e-5
+        assert (out.scores.cpu() - ref_s).abs().max() < 3e-3
+        assert abs(out.loss.item() - ref_loss.item()) < 1e-3 * max(1.0, abs(ref_loss.item()))
+    model.eval()
+    with torch.no_grad():
+        ev = model(**gb)
+    assert ev.loss is None and tuple(ev.scores.shape) == (4, 24)
+    assert (ev.scores.cpu() - ref_q.detach() @ ref_p.detach().T).abs().max() < 2e-5
+
+
+def test_topk_search_exact():
+    from rankpo_amd.retrieval import create_faiss_index, faiss_search
+    rs = np.random.RandomState(11)
+    corpus = rs.randn(5000, 128).astype(np.float32)
+    corpus /= np.linalg.norm(corpus, axis=1, keepdims=True)
+    queries = corpus[rs.choice(5000, 70, replace=False)] + 0.05 * rs.randn(70, 128).astype(np.float32)
+    index = create_faiss_index(corpus, device=DEV)
+    scores, idx = faiss_search(index, queries, topk=20, batch_size=32)
+    full = queries.astype(np.float64) @ corpus.astype(np.float64).T
+    ref_idx = np.argsort(-full, axis=1)[:, :20]
+    assert scores.shape == (70, 20) and idx.dtype == np.int64
+    assert (idx == ref_idx).mean() > 0.999                    # identical up to f32 near-ties
+    np.testing.assert_allclose(scores, np.take_along_axis(full, idx, 1), rtol=1e-5, atol=1e-6)
+    assert np.all(np.diff(scores, axis=1) <= 1e-7)            # sorted, best first
+
+
+def test_model_for_inference_encode():
+    """ModelForInference.encode (modeling.py:473-554) with a stand-in tokenizer: batching, numpy / tensor output,
+    single-string input, padding side handling."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    torch.manual_seed(12)
+    cfg = PE.llama_config(vocab_size=128, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, pad_token_id=0)
+
+    class Tok:
+        pad_token = "<pad>"
+        padding_side = "right"
+
+        def __call__(self, texts, padding=True, truncation=True, max_length=512, return_tensors="pt"):
+            ids = [[1 + (ord(c) % 120) for c in t][:max_length] for t in texts]
+            L = max(len(x) for x in ids)
+            m = [[1] * len(x) + [0] * (L - len(x)) for x in ids]
+            ids = [x + [0] * (L - len(x)) for x in ids]
+            return {"input_ids": torch.tensor(ids), "attention_mask": torch.tensor(m)}
+
+    enc = PE.LlamaEncoder(cfg)
+    w = E.state_dict_to_f32(enc)
+    inf = rankpo_amd.ModelForInference(encoder=enc, tokenizer=Tok(), device=0)
+    texts = ["retrieval on mi355x", "a", "hand written hip kernels for the scoring path", "xyz" * 9, "q"]
+    out = inf.encode(texts, batch_size=2, max_length=32)
+    assert isinstance(out, np.ndarray) and out.shape == (5, 64) and out.dtype == np.float32
+    tok = Tok()(texts, max_length=32)
+    ref = E.embed(w, cfg.to_dict(), tok).detach().numpy()
+    # batches of 2 are padded to their own max length; right padding does not change real-token outputs
+    assert np.abs(out - ref).max() < 2e-5
+    one = inf.encode("a", convert_to_numpy=False)
+    assert torch.is_tensor(one) and one.shape == (64,)
+    with pytest.raises(ValueError, match="Input items should be text"):
+        inf.encode([1, 2])

@@ -185,3 +185,13 @@ def test_gloo_gather_and_grad_reduce(world):
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, 29711, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_compute_metrics_matches_reference(golden):
+    from rankpo_amd.retrieval import compute_metrics
+    g = golden("metrics")
+    meta = json.loads(str(g["meta"]))
+    m = compute_metrics(g["preds"], g["scores"], meta["labels"], cutoffs=meta["cutoffs"])
+    assert list(m) == list(meta["metrics"])            # same keys, same order
+    for k, v in meta["metrics"].items():
+        assert (np.isnan(v) and np.isnan(m[k])) or abs(m[k] - v) < 1e-12, k      # AUC with one class is nan in both

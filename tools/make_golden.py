@@ -365,6 +365,22 @@ def gen_end_to_end(modeling, out, tmpdir):
     np.savez_compressed(os.path.join(out, "end_to_end.npz"), **rec)
 
 
+def gen_metrics(out):
+    """compute_metrics of the reference (utils.py:87-153; faiss itself is not installed and not needed for it)."""
+    if "faiss" not in sys.modules:
+        sys.modules["faiss"] = types.ModuleType("faiss")
+    import utils as ref_utils
+    rs = np.random.RandomState(3)
+    nq, ncorpus, k = 12, 60, 20
+    scores = np.sort(rs.rand(nq, k))[:, ::-1].copy()
+    preds = np.stack([rs.permutation(ncorpus)[:k] for _ in range(nq)])
+    labels = [sorted(set(int(x) for x in rs.choice(ncorpus, size=int(rs.randint(1, 6)), replace=False)) | {int(preds[i, int(rs.randint(0, k))])})
+              for i in range(nq)]
+    m = ref_utils.compute_metrics(preds, scores, labels, cutoffs=[1, 5, 10, 20])
+    np.savez_compressed(os.path.join(out, "metrics.npz"), preds=preds, scores=scores,
+                        meta=json.dumps(dict(labels=labels, cutoffs=[1, 5, 10, 20], metrics={k_: float(v) for k_, v in m.items()})))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
@@ -382,6 +398,7 @@ def main():
             rankpo=lambda: (gen_rankpo(rankpo_trainer, out), gen_rankpo_single_forward(rankpo_trainer, out)),
             collators=lambda: gen_collators(data_utils, out),
             end_to_end=lambda: gen_end_to_end(modeling, out, tmpdir),
+            metrics=lambda: gen_metrics(out),
         )
         for name, fn in steps.items():
             if only and name not in only:
