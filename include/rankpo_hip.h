@@ -177,6 +177,19 @@ int rpo_rope(const void* x_in, void* x_out, int64_t row_stride, const float* cos
              int64_t rows, int64_t heads, int64_t head_dim, int64_t period, int dtype, int backward,
              rpo_stream_t stream);
 
+/* Residual add + RMSNorm, fused (HF LlamaDecoderLayer: `h = residual + delta; y = rmsnorm(h) * w`).
+ *   fwd: x_new = x + delta (delta NULL: x_new = x, x_out unused); rstd_r = rsqrt(mean(x_new_r^2) + eps);
+ *        y = x_new * rstd * w.  x, delta, x_out, y: [rows, d]; rstd_out: f32 [rows].
+ *   bwd: g = dy * w; c_r = mean(g_r * xhat_r); dx = (g - xhat c) * rstd + dres (dres NULL: no residual gradient);
+ *        dw_partial: f32 [rpo_add_rmsnorm_waves(rows), d], one partial sum of dy * xhat per wave (every row of it is
+ *        written); the caller sums over the first dimension.
+ * d % (16 / sizeof(elem)) == 0, d <= 8192 (bf16) / 4096 (f32) forward, half of that backward. */
+int rpo_add_rmsnorm_waves(int64_t rows);
+int rpo_add_rmsnorm_fwd(const void* x, const void* delta, const void* weight, float eps, void* x_out, void* y_out,
+                        float* rstd_out, int64_t rows, int64_t d, int dtype, rpo_stream_t stream);
+int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, const float* rstd, const void* dres,
+                        void* dx_out, float* dw_partial, int64_t rows, int64_t d, int dtype, rpo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

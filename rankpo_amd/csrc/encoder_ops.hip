@@ -146,3 +146,234 @@ extern "C" int rpo_rope(const void* x_in, void* x, int64_t row_stride, const flo
         return RPO_ERR_INVALID_ARG;
     return rpo_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Residual add + RMSNorm, fused (replaces `x = x + delta; y = rms_norm(x) * w` = 2-3 PyTorch kernels forward and
+// cuComputeGradInput + cuComputePartGradGammaBeta + an add kernel backward: ~7.5 % of the cfg-2 step).
+// One wave per row, lane l owns the 16-byte vectors l, l + 64, ... of the row; each wave walks a contiguous chunk
+// of rows.  forward:  x_new = x + delta (rounded to the storage dtype), rstd = rsqrt(mean(x_new^2) + eps),
+//                     y = x_new * rstd * w.
+// backward: g = dy * w; c = mean(g * xhat); dx = (g - xhat * c) * rstd + dres;  dw partial sums per wave (f32,
+//           fixed order) -> dw_partial[wave][d], summed by the caller.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kNormThreads = 256, kNormWaves = kNormThreads / 64;
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(kNormThreads) void add_rmsnorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ delta,
+                                                                       const T* __restrict__ w, float eps,
+                                                                       T* __restrict__ x_out, T* __restrict__ y,
+                                                                       float* __restrict__ rstd_out, int64_t rows,
+                                                                       int d, int64_t rows_per_wave) {
+    constexpr int V = Elem<T>::kVec;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * kNormWaves + (threadIdx.x >> 6);
+    const int nvec = d / V;
+    float wv[KMAX][V];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int vi = lane + 64 * k;
+        if (vi < nvec) {
+            Vec16<T> t;
+            t.load(w + vi * V);
+#pragma unroll
+            for (int e = 0; e < V; ++e) wv[k][e] = t.v[e];
+        }
+    }
+    const int64_t r0 = wave * rows_per_wave, r1 = r0 + rows_per_wave < rows ? r0 + rows_per_wave : rows;
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t r = r0; r < r1; ++r) {
+        Vec16<T> xv[KMAX];
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int vi = lane + 64 * k;
+            if (vi < nvec) {
+                xv[k].load_nt(x + r * d + vi * V);
+                if (delta) {
+                    Vec16<T> dv;
+                    dv.load_nt(delta + r * d + vi * V);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) xv[k].v[e] = Elem<T>::round(xv[k].v[e] + dv.v[e]);
+                    xv[k].store(x_out + r * d + vi * V);        // read again by the next kernels: keep it cacheable
+                }
+#pragma unroll
+                for (int e = 0; e < V; ++e) ss = fmaf(xv[k].v[e], xv[k].v[e], ss);
+            }
+        }
+        ss = wave_sum(ss);
+        const float rstd = rsqrtf(ss * inv_d + eps);
+        if (lane == 0) rstd_out[r] = rstd;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int vi = lane + 64 * k;
+            if (vi < nvec) {
+                Vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < V; ++e) o.v[e] = xv[k].v[e] * rstd * wv[k][e];
+                o.store(y + r * d + vi * V);
+            }
+        }
+    }
+}
+
+template <typename T, int KMAX>
+__global__ __launch_bounds__(kNormThreads) void add_rmsnorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ xn,
+                                                                       const T* __restrict__ w,
+                                                                       const float* __restrict__ rstd_in,
+                                                                       const T* __restrict__ dres, T* __restrict__ dx,
+                                                                       float* __restrict__ dw_partial, int64_t rows,
+                                                                       int d, int64_t rows_per_wave) {
+    constexpr int V = Elem<T>::kVec;
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (int64_t)blockIdx.x * kNormWaves + (threadIdx.x >> 6);
+    const int nvec = d / V;
+    float wv[KMAX][V], dwa[KMAX][V];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int vi = lane + 64 * k;
+#pragma unroll
+        for (int e = 0; e < V; ++e) dwa[k][e] = 0.f;
+        if (vi < nvec) {
+            Vec16<T> t;
+            t.load(w + vi * V);
+#pragma unroll
+            for (int e = 0; e < V; ++e) wv[k][e] = t.v[e];
+        }
+    }
+    const int64_t r0 = wave * rows_per_wave, r1 = r0 + rows_per_wave < rows ? r0 + rows_per_wave : rows;
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t r = r0; r < r1; ++r) {
+        const float rstd = rstd_in[r];
+        Vec16<T> gv[KMAX], xh[KMAX];
+        float c = 0.f;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int vi = lane + 64 * k;
+            if (vi < nvec) {
+                gv[k].load_nt(dy + r * d + vi * V);
+                xh[k].load_nt(xn + r * d + vi * V);
+#pragma unroll
+                for (int e = 0; e < V; ++e) {
+                    xh[k].v[e] *= rstd;                               // xhat
+                    dwa[k][e] = fmaf(gv[k].v[e], xh[k].v[e], dwa[k][e]);
+                    gv[k].v[e] *= wv[k][e];                           // g = dy * w
+                    c = fmaf(gv[k].v[e], xh[k].v[e], c);
+                }
+            }
+        }
+        c = wave_sum(c) * inv_d;
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int vi = lane + 64 * k;
+            if (vi < nvec) {
+                Vec16<T> o;
+#pragma unroll
+                for (int e = 0; e < V; ++e) o.v[e] = (gv[k].v[e] - xh[k].v[e] * c) * rstd;
+                if (dres) {
+                    Vec16<T> rv;
+                    rv.load_nt(dres + r * d + vi * V);
+#pragma unroll
+                    for (int e = 0; e < V; ++e) o.v[e] += rv.v[e];
+                }
+                o.store(dx + r * d + vi * V);
+            }
+        }
+    }
+    if (r0 < rows || true) {
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int vi = lane + 64 * k;
+            if (vi < nvec) {
+                Vec16<float> o;
+                // V floats = V/4 16-byte stores
+#pragma unroll
+                for (int h = 0; h < V / 4; ++h) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o.v[e] = dwa[k][4 * h + e];
+                    o.store(dw_partial + wave * d + vi * V + 4 * h);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_norm_fwd(const void* x, const void* delta, const void* w, float eps, void* x_out, void* y, float* rstd,
+                    int64_t rows, int64_t d, int nwaves, hipStream_t st) {
+    constexpr int V = Elem<T>::kVec;
+    const int kk = (int)rpo_cdiv(d / V, 64);
+    const int64_t rpw = rpo_cdiv(rows, nwaves);
+    const dim3 grid((unsigned)rpo_cdiv(nwaves, kNormWaves)), block(kNormThreads);
+#define RPO_NF(K)                                                                                               \
+    RPO_LAUNCH((add_rmsnorm_fwd_kernel<T, K>), grid, block, 0, st, (const T*)x, (const T*)delta, (const T*)w, eps, \
+               (T*)x_out, (T*)y, rstd, rows, (int)d, rpw)
+    if (kk <= 1) RPO_NF(1);
+    else if (kk <= 2) RPO_NF(2);
+    else if (kk <= 4) RPO_NF(4);
+    else if (kk <= 8) RPO_NF(8);
+    else if (kk <= 16) RPO_NF(16);
+    else return RPO_ERR_UNSUPPORTED;
+#undef RPO_NF
+    return rpo_launch_status();
+}
+
+template <typename T>
+int launch_norm_bwd(const void* dy, const void* xn, const void* w, const float* rstd, const void* dres, void* dx,
+                    float* dwp, int64_t rows, int64_t d, int nwaves, hipStream_t st) {
+    constexpr int V = Elem<T>::kVec;
+    const int kk = (int)rpo_cdiv(d / V, 64);
+    const int64_t rpw = rpo_cdiv(rows, nwaves);
+    const dim3 grid((unsigned)rpo_cdiv(nwaves, kNormWaves)), block(kNormThreads);
+#define RPO_NB(K)                                                                                                \
+    RPO_LAUNCH((add_rmsnorm_bwd_kernel<T, K>), grid, block, 0, st, (const T*)dy, (const T*)xn, (const T*)w, rstd,  \
+               (const T*)dres, (T*)dx, dwp, rows, (int)d, rpw)
+    if (kk <= 1) RPO_NB(1);
+    else if (kk <= 2) RPO_NB(2);
+    else if (kk <= 4) RPO_NB(4);
+    else if (kk <= 8) RPO_NB(8);
+    else return RPO_ERR_UNSUPPORTED;
+#undef RPO_NB
+    return rpo_launch_status();
+}
+
+}  // namespace
+
+extern "C" int rpo_add_rmsnorm_waves(int64_t rows) {
+    // number of waves (= rows of dw_partial) the two kernels below use for `rows` rows: a multiple of 4, <= 8192
+    int64_t w = rows < 8192 ? rows : 8192;
+    w = (w + 3) / 4 * 4;
+    return (int)(w < 4 ? 4 : w);
+}
+
+extern "C" int rpo_add_rmsnorm_fwd(const void* x, const void* delta, const void* weight, float eps, void* x_out,
+                                   void* y_out, float* rstd_out, int64_t rows, int64_t d, int dtype,
+                                   rpo_stream_t stream) {
+    if (!x || !weight || !y_out || !rstd_out || rows <= 0 || d <= 0) return RPO_ERR_INVALID_ARG;
+    if (delta && !x_out) return RPO_ERR_INVALID_ARG;
+    const int V = dtype == RPO_DT_BF16 ? 8 : 4;
+    if (d % V != 0 || !rpo_aligned16(x) || !rpo_aligned16(y_out) || !rpo_aligned16(weight) ||
+        (delta && (!rpo_aligned16(delta) || !rpo_aligned16(x_out))))
+        return RPO_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = rpo_add_rmsnorm_waves(rows);
+    if (dtype == RPO_DT_BF16) return launch_norm_fwd<bf16_t>(x, delta, weight, eps, x_out, y_out, rstd_out, rows, d, nw, st);
+    if (dtype == RPO_DT_F32) return launch_norm_fwd<float>(x, delta, weight, eps, x_out, y_out, rstd_out, rows, d, nw, st);
+    return RPO_ERR_INVALID_ARG;
+}
+
+extern "C" int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, const float* rstd,
+                                   const void* dres, void* dx_out, float* dw_partial, int64_t rows, int64_t d,
+                                   int dtype, rpo_stream_t stream) {
+    if (!dy || !x_new || !weight || !rstd || !dx_out || !dw_partial || rows <= 0 || d <= 0) return RPO_ERR_INVALID_ARG;
+    const int V = dtype == RPO_DT_BF16 ? 8 : 4;
+    if (d % V != 0 || !rpo_aligned16(dy) || !rpo_aligned16(x_new) || !rpo_aligned16(dx_out) || !rpo_aligned16(weight) ||
+        !rpo_aligned16(dw_partial) || (dres && !rpo_aligned16(dres)))
+        return RPO_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const int nw = rpo_add_rmsnorm_waves(rows);
+    if (dtype == RPO_DT_BF16) return launch_norm_bwd<bf16_t>(dy, x_new, weight, rstd, dres, dx_out, dw_partial, rows, d, nw, st);
+    if (dtype == RPO_DT_F32) return launch_norm_bwd<float>(dy, x_new, weight, rstd, dres, dx_out, dw_partial, rows, d, nw, st);
+    return RPO_ERR_INVALID_ARG;
+}

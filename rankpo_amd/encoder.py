@@ -126,6 +126,15 @@ class RMSNorm(nn.Module):
         return F.rms_norm(x, (x.shape[-1],), self.weight, self.eps)
 
 
+def _add_norm(x, delta, norm: "RMSNorm"):
+    """(x + delta, norm(x + delta)); one fused HIP pass on HIP tensors, plain PyTorch otherwise."""
+    if _ops.fused_norm_ok(x):
+        return _ops.add_rmsnorm(x, delta, norm.weight, norm.eps)
+    if delta is not None:
+        x = x + delta
+    return x, norm(x)
+
+
 def _rotate_half(x):
     x1, x2 = x[..., : x.shape[-1] // 2], x[..., x.shape[-1] // 2:]
     return torch.cat((-x2, x1), dim=-1)
@@ -250,17 +259,21 @@ class LlamaLayer(nn.Module):
         self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_eps)
 
-    def forward(self, x, rope, attn_mask):
-        x = x + self.self_attn(self.input_layernorm(x), rope, attn_mask)
-        return x + self.mlp(self.post_attention_layernorm(x))
+    def forward(self, x, delta, rope, attn_mask):
+        """Residual stream as a pair: the block receives the stream `x` and the not-yet-added output `delta` of the
+        previous block (None for the first), and returns (stream, its own MLP output): every `x + delta` is fused
+        into the RMSNorm that follows it."""
+        x, h = _add_norm(x, delta, self.input_layernorm)
+        x, h = _add_norm(x, self.self_attn(h, rope, attn_mask), self.post_attention_layernorm)
+        return x, self.mlp(h)
 
-    def forward_last_rows(self, x, rope, ctx, last_idx):
+    def forward_last_rows(self, x, delta, rope, ctx, last_idx):
         """The LAST block of a last-token-pooled encoder: only the pooled rows are consumed downstream, so K and V
         are computed for every token but Q, the attention output, o_proj and the whole MLP only for the N pooled
         rows (saves ~1/num_layers of the GEMM and attention work, forward and backward).  x: packed [1, T, d];
         returns [N, d]."""
         att = self.self_attn
-        h = self.input_layernorm(x)
+        x, h = _add_norm(x, delta, self.input_layernorm)
         T = h.shape[1]
         k, v = att.k_proj(h), att.v_proj(h)
         q = att.q_proj(h[0].index_select(0, last_idx))                       # [N, nh*hd]
@@ -337,6 +350,10 @@ class LlamaEncoder(nn.Module):
 
     def hidden_states(self, input_ids, attention_mask=None):
         """Output of the last block, BEFORE the final RMSNorm."""
+        x, delta = self._stack(input_ids, attention_mask)
+        return x if delta is None else x + delta
+
+    def _stack(self, input_ids, attention_mask):
         x = self.embed_tokens(input_ids)
         N, L, _ = x.shape
         rope = self._rope(torch.arange(L, device=x.device))
@@ -344,18 +361,20 @@ class LlamaEncoder(nn.Module):
         return self._run_layers(x, rope, mask)
 
     def forward(self, input_ids=None, attention_mask=None, return_dict=True, **_):
-        h = self.norm(self.hidden_states(input_ids, attention_mask))
+        x, delta = self._stack(input_ids, attention_mask)
+        h = _add_norm(x, delta, self.norm)[1]
         return EncoderOutput(last_hidden_state=h) if return_dict else (h,)
 
     def _run_layers(self, x, rope, ctx, upto=None):
         ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
         nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
+        delta = None
         for i, layer in enumerate(self.layers if upto is None else self.layers[:upto]):
             if ck and i < nck:
-                x = checkpoint(layer, x, rope, ctx, use_reentrant=False)
+                x, delta = checkpoint(layer, x, delta, rope, ctx, use_reentrant=False)
             else:
-                x = layer(x, rope, ctx)
-        return x
+                x, delta = layer(x, delta, rope, ctx)
+        return x, delta
 
     def pooled_last_token(self, input_ids, attention_mask):
         """== forward(...).last_hidden_state[n, last real token] for RIGHT-padded 0/1 masks, computed without ever
@@ -381,14 +400,14 @@ class LlamaEncoder(nn.Module):
         cu[1:] = lens_d.cumsum(0).to(torch.int32)
         ctx = VarlenCtx(cu, lens, max(lens))
         last_idx = (cu[1:] - 1).to(torch.int64)
-        x = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1)
+        x, delta = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1)
         li = len(self.layers) - 1
         ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
         nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
         if ck and li < nck:
-            last = checkpoint(self.layers[li].forward_last_rows, x, rope, ctx, last_idx, use_reentrant=False)
+            last = checkpoint(self.layers[li].forward_last_rows, x, delta, rope, ctx, last_idx, use_reentrant=False)
         else:
-            last = self.layers[li].forward_last_rows(x, rope, ctx, last_idx)                # [N, d]
+            last = self.layers[li].forward_last_rows(x, delta, rope, ctx, last_idx)         # [N, d]
         return self.norm(last)
 
 

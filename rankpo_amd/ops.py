@@ -310,6 +310,70 @@ def fused_encoder_ops_ok(x, head_dim=None) -> bool:
     return head_dim is None or (head_dim % 2 == 0 and (head_dim // 2) % v == 0)
 
 
+class _AddRMSNorm(torch.autograd.Function):
+    """(x, delta, w) -> (x_new, y) with x_new = x + delta, y = rmsnorm(x_new) * w; delta may be None (then only y is
+    returned).  One HIP pass forward, one backward (which also folds in the gradient arriving on x_new)."""
+
+    @staticmethod
+    def forward(ctx, x, delta, weight, eps):
+        lib = _lib.load()
+        x = x.contiguous()
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        rstd = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        x_new = torch.empty_like(x) if delta is not None else x
+        if delta is not None:
+            delta = delta.contiguous()
+        with torch.cuda.device(x.device):
+            check(lib.rpo_add_rmsnorm_fwd(x.data_ptr(), _p(delta), weight.data_ptr(), eps, _p(x_new if delta is not None else None),
+                                          y.data_ptr(), rstd.data_ptr(), rows, d, _dt(x), _stream(x)), "rpo_add_rmsnorm_fwd")
+        ctx.save_for_backward(x_new, weight, rstd)
+        ctx.has_delta = delta is not None
+        if delta is None:
+            return y
+        return x_new, y
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x_new, weight, rstd = ctx.saved_tensors
+        lib = _lib.load()
+        if ctx.has_delta:
+            dres, dy = grads
+        else:
+            dres, dy = None, grads[0]
+        d = x_new.shape[-1]
+        rows = x_new.numel() // d
+        if dy is None:                      # only the residual output was used
+            return dres, (dres if ctx.has_delta else None), None, None
+        dy = dy.contiguous()
+        dres = None if dres is None else dres.contiguous()
+        dx = torch.empty_like(x_new)
+        nw = lib.rpo_add_rmsnorm_waves(rows)
+        dwp = torch.empty((nw, d), dtype=torch.float32, device=x_new.device)
+        with torch.cuda.device(x_new.device):
+            check(lib.rpo_add_rmsnorm_bwd(dy.data_ptr(), x_new.data_ptr(), weight.data_ptr(), rstd.data_ptr(), _p(dres),
+                                          dx.data_ptr(), dwp.data_ptr(), rows, d, _dt(x_new), _stream(x_new)),
+                  "rpo_add_rmsnorm_bwd")
+        dw = dwp.sum(0).to(weight.dtype) if ctx.needs_input_grad[2] else None
+        return dx, (dx if ctx.has_delta else None), dw, None
+
+
+def add_rmsnorm(x, delta, weight, eps):
+    """Returns (x + delta, rmsnorm(x + delta) * weight); with delta None returns (x, rmsnorm(x) * weight)."""
+    if delta is None:
+        return x, _AddRMSNorm.apply(x, None, weight, eps)
+    return _AddRMSNorm.apply(x, delta, weight, eps)
+
+
+def fused_norm_ok(x) -> bool:
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16):
+        return False
+    v = 8 if x.dtype == torch.bfloat16 else 4
+    d = x.shape[-1]
+    return d % v == 0 and d // v <= 64 * 8
+
+
 class _Rope(torch.autograd.Function):
     """In-place rotary embedding of a projection output x [..., heads * head_dim] (x is the fresh output of a Linear,
     nothing else reads it).  cos / sin: f32 [period, head_dim / 2]; flat row r uses table row r % period."""
@@ -347,4 +411,4 @@ def rope_(x, cos, sin, heads, head_dim):
 
 
 __all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
-           "swiglu_down", "rope_", "fused_encoder_ops_ok"]
+           "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok"]

@@ -264,3 +264,37 @@ def test_model_for_inference_encode():
     assert torch.is_tensor(one) and one.shape == (64,)
     with pytest.raises(ValueError, match="Input items should be text"):
         inf.encode([1, 2])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,d", [(1000, 2048), (37, 128), (5, 4096), (300, 520)])
+@pytest.mark.parametrize("with_delta", [True, False])
+def test_add_rmsnorm_matches_torch(dtype, rows, d, with_delta):
+    from rankpo_amd import ops
+    if not ops.fused_norm_ok(torch.empty(1, d, device=DEV, dtype=dtype)):
+        pytest.skip("shape handled by the PyTorch path")
+    torch.manual_seed(rows + d)
+    x = torch.randn(rows, d, device=DEV).to(dtype).requires_grad_(True)
+    dl = (0.5 * torch.randn(rows, d, device=DEV)).to(dtype).requires_grad_(True) if with_delta else None
+    w = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype).requires_grad_(True)
+    xn, y = ops.add_rmsnorm(x, dl, w, 1e-5)
+    gy, gx = torch.randn_like(y), torch.randn_like(y)
+    (y * gy).sum().backward(retain_graph=with_delta)
+    if with_delta:
+        x.grad = dl.grad = w.grad = None
+        ((y * gy).sum() + (xn * gx).sum()).backward()
+    x2 = x.detach().double().requires_grad_(True)
+    d2 = dl.detach().double().requires_grad_(True) if with_delta else None
+    w2 = w.detach().double().requires_grad_(True)
+    xr = x2 + d2 if with_delta else x2
+    if with_delta and dtype == torch.bfloat16:
+        xr = xr + (xn.detach().double() - xr.detach())      # the kernel rounds x + delta to bf16 before normalising
+    yr = xr * torch.rsqrt(xr.pow(2).mean(-1, keepdim=True) + 1e-5) * w2
+    ((yr * gy.double()).sum() + ((xr * gx.double()).sum() if with_delta else 0)).backward()
+    tol = 3e-5 if dtype == torch.float32 else 2.0 ** -6
+    rel = lambda a, b: (a.double() - b).abs().max().item() / max(1.0, b.abs().max().item())
+    assert rel(y, yr) < tol
+    assert rel(x.grad, x2.grad) < tol
+    if with_delta:
+        assert rel(xn, xr) < tol and rel(dl.grad, d2.grad) < tol
+    assert rel(w.grad, w2.grad) < (tol if dtype == torch.float32 else 2.0 ** -5)
