@@ -78,12 +78,20 @@ def _algo(name, a):
         n, dt = a[1], a[2]
         return n * _es(dt), 2 * n
     if name == "rpo_swiglu_fwd":
-        return 3 * a[3] * _es(a[4]), 5 * a[3]
+        n = a[3] * a[4]
+        return 3 * n * _es(a[7]), 5 * n
     if name == "rpo_swiglu_bwd":
-        return 5 * a[5] * _es(a[6]), 12 * a[5]
+        n = a[5] * a[6]
+        return 5 * n * _es(a[10]), 12 * n
     if name == "rpo_rope":
         rows, H, hd, dt = a[5], a[6], a[7], a[9]
         return 2 * rows * H * hd * _es(dt) + rows * hd * 4, 3 * rows * H * hd
+    if name == "rpo_add_rmsnorm_fwd":
+        rows, d, dt = a[7], a[8], a[9]
+        return rows * d * _es(dt) * (4 if a[1] is not None else 2) + rows * 4, 4 * rows * d
+    if name == "rpo_add_rmsnorm_bwd":
+        rows, d, dt = a[7], a[8], a[9]
+        return rows * d * _es(dt) * (4 if a[4] is not None else 3) + rows * 4, 8 * rows * d
     if name == "rpo_rankpo_fwd":
         B, d, dt = a[4], a[5], a[6]
         return 3 * B * d * _es(dt), 4 * B * d

@@ -12,33 +12,41 @@ constexpr int kEwThreads = 256;
 
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.0f / (1.0f + __expf(-x)); }
 
+// 2-D form: g, u: [rows, cols] with row stride ld_gu (they may be the two halves of one fused gate|up projection
+// output), out: [rows, cols] with row stride ld_out.  Block (bx, row-group): one 16-byte vector per thread.
 template <typename T>
 __global__ __launch_bounds__(kEwThreads) void swiglu_fwd_kernel(const T* __restrict__ g, const T* __restrict__ u,
-                                                                T* __restrict__ out, int64_t nvec) {
-    // ONE 16-byte vector per thread, block b owns the contiguous vectors [256 b, 256 b + 256), streaming
-    // (non-temporal) loads and stores: measured 6.6 TB/s on MI355X vs 4.6-4.9 TB/s for a capped grid-stride loop
+                                                                T* __restrict__ out, int64_t rows, int vec_per_row,
+                                                                int64_t ld_gu, int64_t ld_out) {
+    // ONE 16-byte vector per thread, consecutive blocks own consecutive vectors, streaming (non-temporal) loads and
+    // stores: measured 6.6 TB/s on MI355X vs 4.6-4.9 TB/s for a capped grid-stride loop
     // (tools/exp/exp_stream.hip).
     constexpr int V = Elem<T>::kVec;
     const int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
-    if (i >= nvec) return;
+    const int64_t r = i / vec_per_row;
+    if (r >= rows) return;
+    const int c = (int)(i - r * vec_per_row) * V;
     Vec16<T> a, b, o;
-    a.load_nt(g + i * V);
-    b.load_nt(u + i * V);
+    a.load_nt(g + r * ld_gu + c);
+    b.load_nt(u + r * ld_gu + c);
 #pragma unroll
     for (int k = 0; k < V; ++k) o.v[k] = a.v[k] * sigmoid_f(a.v[k]) * b.v[k];
-    o.store_nt(out + i * V);
+    o.store_nt(out + r * ld_out + c);
 }
 
 template <typename T>
 __global__ __launch_bounds__(kEwThreads) void swiglu_bwd_kernel(const T* g, const T* u, const T* dout, T* dg, T* du,
-                                                                int64_t nvec) {   // dg / du may alias g / u / dout
+                                                                int64_t rows, int vec_per_row, int64_t ld_gu,
+                                                                int64_t ld_dout, int64_t ld_dgu) {   // outputs may alias inputs
     constexpr int V = Elem<T>::kVec;
     const int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
-    if (i >= nvec) return;
+    const int64_t r = i / vec_per_row;
+    if (r >= rows) return;
+    const int c = (int)(i - r * vec_per_row) * V;
     Vec16<T> a, b, d, og, ou;
-    a.load_nt(g + i * V);
-    b.load_nt(u + i * V);
-    d.load_nt(dout + i * V);
+    a.load_nt(g + r * ld_gu + c);
+    b.load_nt(u + r * ld_gu + c);
+    d.load_nt(dout + r * ld_dout + c);
 #pragma unroll
     for (int k = 0; k < V; ++k) {
         const float s = sigmoid_f(a.v[k]);
@@ -46,8 +54,8 @@ __global__ __launch_bounds__(kEwThreads) void swiglu_bwd_kernel(const T* g, cons
         og.v[k] = d.v[k] * b.v[k] * (s + silu * (1.0f - s));   // silu' = s (1 + g (1 - s))
         ou.v[k] = d.v[k] * silu;
     }
-    og.store_nt(dg + i * V);
-    ou.store_nt(du + i * V);
+    og.store_nt(dg + r * ld_dgu + c);
+    ou.store_nt(du + r * ld_dgu + c);
 }
 
 // x: [rows, H, hd] (row stride = row_stride elements, heads contiguous), cos/sin: f32 [period, hd/2];
@@ -89,37 +97,46 @@ inline unsigned ew_grid(int64_t nvec) { return (unsigned)rpo_cdiv(nvec, kEwThrea
 
 }  // namespace
 
-extern "C" int rpo_swiglu_fwd(const void* g, const void* u, void* out, int64_t n, int dtype, rpo_stream_t stream) {
-    if (!g || !u || !out || n <= 0) return RPO_ERR_INVALID_ARG;
+extern "C" int rpo_swiglu_fwd(const void* g, const void* u, void* out, int64_t rows, int64_t cols, int64_t ld_gu,
+                              int64_t ld_out, int dtype, rpo_stream_t stream) {
+    if (!g || !u || !out || rows <= 0 || cols <= 0) return RPO_ERR_INVALID_ARG;
     const int V = dtype == RPO_DT_BF16 ? 8 : 4;
-    if (n % V != 0 || !rpo_aligned16(g) || !rpo_aligned16(u) || !rpo_aligned16(out)) return RPO_ERR_UNSUPPORTED;
-    if (n / V / kEwThreads >= INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    if (cols % V != 0 || ld_gu % V != 0 || ld_out % V != 0 || ld_gu < cols || ld_out < cols || !rpo_aligned16(g) ||
+        !rpo_aligned16(u) || !rpo_aligned16(out))
+        return RPO_ERR_UNSUPPORTED;
+    const int64_t nvec = rows * (cols / V);
+    if (nvec / kEwThreads >= INT32_MAX) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RPO_DT_BF16)
-        RPO_LAUNCH(swiglu_fwd_kernel<bf16_t>, dim3(ew_grid(n / V)), dim3(kEwThreads), 0, st, (const bf16_t*)g,
-                   (const bf16_t*)u, (bf16_t*)out, n / V);
+        RPO_LAUNCH(swiglu_fwd_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(kEwThreads), 0, st, (const bf16_t*)g,
+                   (const bf16_t*)u, (bf16_t*)out, rows, (int)(cols / V), ld_gu, ld_out);
     else if (dtype == RPO_DT_F32)
-        RPO_LAUNCH(swiglu_fwd_kernel<float>, dim3(ew_grid(n / V)), dim3(kEwThreads), 0, st, (const float*)g,
-                   (const float*)u, (float*)out, n / V);
+        RPO_LAUNCH(swiglu_fwd_kernel<float>, dim3(ew_grid(nvec)), dim3(kEwThreads), 0, st, (const float*)g,
+                   (const float*)u, (float*)out, rows, (int)(cols / V), ld_gu, ld_out);
     else
         return RPO_ERR_INVALID_ARG;
     return rpo_launch_status();
 }
 
-extern "C" int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, void* dg, void* du, int64_t n,
-                              int dtype, rpo_stream_t stream) {
-    if (!g || !u || !dout || !dg || !du || n <= 0) return RPO_ERR_INVALID_ARG;
+extern "C" int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, void* dg, void* du, int64_t rows,
+                              int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int dtype,
+                              rpo_stream_t stream) {
+    if (!g || !u || !dout || !dg || !du || rows <= 0 || cols <= 0) return RPO_ERR_INVALID_ARG;
     const int V = dtype == RPO_DT_BF16 ? 8 : 4;
-    if (n % V != 0 || !rpo_aligned16(g) || !rpo_aligned16(u) || !rpo_aligned16(dout) || !rpo_aligned16(dg) ||
-        !rpo_aligned16(du))
+    if (cols % V != 0 || ld_gu % V != 0 || ld_dout % V != 0 || ld_dgu % V != 0 || !rpo_aligned16(g) ||
+        !rpo_aligned16(u) || !rpo_aligned16(dout) || !rpo_aligned16(dg) || !rpo_aligned16(du))
         return RPO_ERR_UNSUPPORTED;
+    const int64_t nvec = rows * (cols / V);
+    if (nvec / kEwThreads >= INT32_MAX) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RPO_DT_BF16)
-        RPO_LAUNCH(swiglu_bwd_kernel<bf16_t>, dim3(ew_grid(n / V)), dim3(kEwThreads), 0, st, (const bf16_t*)g,
-                   (const bf16_t*)u, (const bf16_t*)dout, (bf16_t*)dg, (bf16_t*)du, n / V);
+        RPO_LAUNCH(swiglu_bwd_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(kEwThreads), 0, st, (const bf16_t*)g,
+                   (const bf16_t*)u, (const bf16_t*)dout, (bf16_t*)dg, (bf16_t*)du, rows, (int)(cols / V), ld_gu, ld_dout,
+                   ld_dgu);
     else if (dtype == RPO_DT_F32)
-        RPO_LAUNCH(swiglu_bwd_kernel<float>, dim3(ew_grid(n / V)), dim3(kEwThreads), 0, st, (const float*)g,
-                   (const float*)u, (const float*)dout, (float*)dg, (float*)du, n / V);
+        RPO_LAUNCH(swiglu_bwd_kernel<float>, dim3(ew_grid(nvec)), dim3(kEwThreads), 0, st, (const float*)g,
+                   (const float*)u, (const float*)dout, (float*)dg, (float*)du, rows, (int)(cols / V), ld_gu, ld_dout,
+                   ld_dgu);
     else
         return RPO_ERR_INVALID_ARG;
     return rpo_launch_status();

@@ -206,13 +206,22 @@ class LlamaAttention(nn.Module):
         self.v_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, bias=b)
         self.o_proj = nn.Linear(self.nh * self.hd, cfg.hidden_size, bias=b)
 
+    def _fused(self, x, mods):
+        """ONE projection GEMM for several Linear modules that read the same input (q|k|v, k|v): better GEMM shapes
+        than the narrow k / v projections alone and ONE input-gradient GEMM instead of a GEMM + add per branch.  The
+        weights stay separate parameters (HF names); concatenating them costs ~13 MB of traffic per block."""
+        w = torch.cat([m.weight for m in mods], 0)
+        b = torch.cat([m.bias for m in mods], 0) if mods[0].bias is not None else None
+        return F.linear(x, w, b)
+
     def forward(self, x, rope, attn_mask):
         N, L, _ = x.shape
-        q, k, v = self.q_proj(x), self.k_proj(x), self.v_proj(x)
+        nq, nk = self.nh * self.hd, self.nkv * self.hd
+        qkv = self._fused(x, (self.q_proj, self.k_proj, self.v_proj))            # [N, L, nq + 2 nk]
         fused = _ops.fused_encoder_ops_ok(x, self.hd)
-        if fused:       # one in-place HIP pass per projection instead of neg / cat / 2 mul / add
-            q = _ops.rope_(q, rope.cos32, rope.sin32, self.nh, self.hd)
-            k = _ops.rope_(k, rope.cos32, rope.sin32, self.nkv, self.hd)
+        if fused:       # one in-place HIP pass over the q and k heads instead of neg / cat / 2 mul / add per tensor
+            qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd)
+        q, k, v = qkv.split([nq, nk, nk], dim=-1)
         if isinstance(attn_mask, VarlenCtx):
             # packed tokens [1, T, d]: variable-length causal flash attention, no pad tokens anywhere
             q, k, v = q.view(L, self.nh, self.hd), k.view(L, self.nkv, self.hd), v.view(L, self.nkv, self.hd)
@@ -245,10 +254,11 @@ class LlamaMLP(nn.Module):
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=b)
 
     def forward(self, x):
-        g, u = self.gate_proj(x), self.up_proj(x)
-        if self.down_proj.bias is None and _ops.fused_encoder_ops_ok(g):
-            return _ops.swiglu_down(g, u, self.down_proj.weight)       # fused HIP silu*mul, product not kept alive
-        return self.down_proj(F.silu(g) * u)
+        if self.down_proj.bias is None and self.gate_proj.bias is None and _ops.fused_encoder_ops_ok(x):
+            # ONE gate|up projection GEMM; fused HIP silu*mul on its two halves, product not kept alive
+            gu = F.linear(x, torch.cat([self.gate_proj.weight, self.up_proj.weight], 0))
+            return _ops.swiglu_down(gu, self.down_proj.weight)
+        return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
 class LlamaLayer(nn.Module):
@@ -275,14 +285,17 @@ class LlamaLayer(nn.Module):
         att = self.self_attn
         x, h = _add_norm(x, delta, self.input_layernorm)
         T = h.shape[1]
-        k, v = att.k_proj(h), att.v_proj(h)
+        nk = att.nkv * att.hd
+        kv = att._fused(h, (att.k_proj, att.v_proj))                         # [1, T, 2 nk]
         q = att.q_proj(h[0].index_select(0, last_idx))                       # [N, nh*hd]
         rope_last = rope.select(last_idx)
         if _ops.fused_encoder_ops_ok(x, att.hd):
             q = _ops.rope_(q, rope_last.cos32, rope_last.sin32, att.nh, att.hd)
-            k = _ops.rope_(k, rope.cos32, rope.sin32, att.nkv, att.hd)
+            kv = _ops.rope_(kv, rope.cos32, rope.sin32, att.nkv, att.hd)     # rotates the k heads only
+            k, v = kv.split([nk, nk], dim=-1)
             q, k = q.view(-1, att.nh, att.hd), k.view(T, att.nkv, att.hd)
         else:
+            k, v = kv.split([nk, nk], dim=-1)
             q, k = q.view(-1, att.nh, att.hd), k.view(T, att.nkv, att.hd)
             cq, sq = rope_last.full(x.dtype, packed=True)
             ck, sk = rope.full(x.dtype, packed=True)

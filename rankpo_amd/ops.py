@@ -264,43 +264,52 @@ def rankpo_loss_metrics(q, p, cfg: RankPOConfig, ref_chosen=None, ref_rejected=N
 # ------------------------------------------------------------------------------------------------
 # (5) fused elementwise pieces of the Llama block (used by rankpo_amd/encoder.py on HIP tensors)
 # ------------------------------------------------------------------------------------------------
-def _swiglu_fwd(lib, g, u, out):
-    with torch.cuda.device(g.device):
-        check(lib.rpo_swiglu_fwd(g.data_ptr(), u.data_ptr(), out.data_ptr(), g.numel(), _dt(g), _stream(g)),
-              "rpo_swiglu_fwd")
-    return out
+def _swiglu_fwd(lib, gu, prod, rows, ff):
+    es = gu.element_size()
+    with torch.cuda.device(gu.device):
+        check(lib.rpo_swiglu_fwd(gu.data_ptr(), gu.data_ptr() + ff * es, prod.data_ptr(), rows, ff, 2 * ff, ff, _dt(gu),
+                                 _stream(gu)), "rpo_swiglu_fwd")
+    return prod
 
 
 class _SwiGLUDown(torch.autograd.Function):
-    """y = (silu(g) * u) @ W^T.  Saves g, u, W only: the [tokens, ff] product (the largest activation of the block)
-    is recomputed by one fused pass in backward instead of being kept alive."""
+    """y = (silu(g) * u) @ W^T with gu = [g | u] the output of ONE fused gate|up projection.  Saves gu and W only: the
+    [tokens, ff] product (the largest activation of the block) is recomputed by one fused pass in backward."""
 
     @staticmethod
-    def forward(ctx, g, u, weight):
+    def forward(ctx, gu, weight):
         lib = _lib.load()
-        g, u = g.contiguous(), u.contiguous()
-        prod = _swiglu_fwd(lib, g, u, torch.empty_like(g))
-        ctx.save_for_backward(g, u, weight)
+        gu = gu.contiguous()
+        ff = gu.shape[-1] // 2
+        rows = gu.numel() // (2 * ff)
+        prod = _swiglu_fwd(lib, gu, torch.empty(gu.shape[:-1] + (ff,), dtype=gu.dtype, device=gu.device), rows, ff)
+        ctx.save_for_backward(gu, weight)
         return torch.nn.functional.linear(prod, weight)
 
     @staticmethod
     def backward(ctx, dy):
-        g, u, weight = ctx.saved_tensors
+        gu, weight = ctx.saved_tensors
         lib = _lib.load()
         dy = dy.contiguous()
-        prod = _swiglu_fwd(lib, g, u, torch.empty_like(g))
+        ff = gu.shape[-1] // 2
+        rows = gu.numel() // (2 * ff)
+        es = gu.element_size()
+        prod = _swiglu_fwd(lib, gu, torch.empty(gu.shape[:-1] + (ff,), dtype=gu.dtype, device=gu.device), rows, ff)
         dW = None
-        if ctx.needs_input_grad[2]:
-            dW = dy.reshape(-1, dy.shape[-1]).t() @ prod.reshape(-1, prod.shape[-1])
+        if ctx.needs_input_grad[1]:
+            dW = dy.reshape(-1, dy.shape[-1]).t() @ prod.reshape(-1, ff)
+        del prod
         dprod = dy @ weight                                   # [..., ff]
-        with torch.cuda.device(g.device):                     # dg -> prod's buffer, du -> dprod's buffer
-            check(lib.rpo_swiglu_bwd(g.data_ptr(), u.data_ptr(), dprod.data_ptr(), prod.data_ptr(), dprod.data_ptr(),
-                                     g.numel(), _dt(g), _stream(g)), "rpo_swiglu_bwd")
-        return prod, dprod, dW
+        dgu = torch.empty_like(gu)                            # [dg | du]: the gradient of the fused projection output
+        with torch.cuda.device(gu.device):
+            check(lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),
+                                     dgu.data_ptr() + ff * es, rows, ff, 2 * ff, ff, 2 * ff, _dt(gu), _stream(gu)),
+                  "rpo_swiglu_bwd")
+        return dgu, dW
 
 
-def swiglu_down(g, u, weight):
-    return _SwiGLUDown.apply(g, u, weight)
+def swiglu_down(gu, weight):
+    return _SwiGLUDown.apply(gu, weight)
 
 
 def fused_encoder_ops_ok(x, head_dim=None) -> bool:
@@ -375,15 +384,17 @@ def fused_norm_ok(x) -> bool:
 
 
 class _Rope(torch.autograd.Function):
-    """In-place rotary embedding of a projection output x [..., heads * head_dim] (x is the fresh output of a Linear,
-    nothing else reads it).  cos / sin: f32 [period, head_dim / 2]; flat row r uses table row r % period."""
+    """In-place rotary embedding of the first `heads` heads of every row of a projection output x [..., row_len]
+    (x is the fresh output of a Linear -- e.g. the fused q|k|v projection with heads = n_q + n_kv -- nothing else reads
+    it).  cos / sin: f32 [period, head_dim / 2]; flat row r uses table row r % period."""
 
     @staticmethod
     def forward(ctx, x, cos, sin, heads, head_dim):
         lib = _lib.load()
-        rows = x.numel() // (heads * head_dim)
+        row_len = x.shape[-1]
+        rows = x.numel() // row_len
         with torch.cuda.device(x.device):
-            check(lib.rpo_rope(x.data_ptr(), x.data_ptr(), heads * head_dim, cos.data_ptr(), sin.data_ptr(), rows, heads,
+            check(lib.rpo_rope(x.data_ptr(), x.data_ptr(), row_len, cos.data_ptr(), sin.data_ptr(), rows, heads,
                                head_dim, cos.shape[0], _dt(x), 0, _stream(x)), "rpo_rope")
         ctx.mark_dirty(x)
         ctx.save_for_backward(cos, sin)
@@ -396,11 +407,13 @@ class _Rope(torch.autograd.Function):
         heads, head_dim = ctx.meta
         lib = _lib.load()
         g = g.contiguous()
-        out = torch.empty_like(g)
-        rows = g.numel() // (heads * head_dim)
+        row_len = g.shape[-1]
+        rows = g.numel() // row_len
+        # columns beyond the rotated heads (the v part of a fused projection) pass through unchanged
+        out = torch.empty_like(g) if heads * head_dim == row_len else g.clone()
         with torch.cuda.device(g.device):
-            check(lib.rpo_rope(g.data_ptr(), out.data_ptr(), heads * head_dim, cos.data_ptr(), sin.data_ptr(), rows,
-                               heads, head_dim, cos.shape[0], _dt(g), 1, _stream(g)), "rpo_rope(bwd)")
+            check(lib.rpo_rope(g.data_ptr(), out.data_ptr(), row_len, cos.data_ptr(), sin.data_ptr(), rows, heads,
+                               head_dim, cos.shape[0], _dt(g), 1, _stream(g)), "rpo_rope(bwd)")
         return out, None, None, None, None
 
 

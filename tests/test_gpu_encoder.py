@@ -29,9 +29,11 @@ def test_swiglu_down_matches_torch(dtype):
     g = torch.randn(T, ff, device=DEV).to(dtype).requires_grad_(True)
     u = torch.randn(T, ff, device=DEV).to(dtype).requires_grad_(True)
     W = (torch.randn(d, ff, device=DEV) * 0.05).to(dtype).requires_grad_(True)
-    y = ops.swiglu_down(g, u, W)
+    gu = torch.cat([g, u], -1).detach().requires_grad_(True)     # fused gate|up projection output
+    y = ops.swiglu_down(gu, W)
     gy = torch.randn_like(y)
     y.backward(gy)
+    g.grad, u.grad = gu.grad[:, :ff], gu.grad[:, ff:]
     g2, u2, W2 = (t.detach().double().requires_grad_(True) for t in (g, u, W))
     y2 = (F.silu(g2) * u2) @ W2.T
     y2.backward(gy.double())
@@ -52,7 +54,12 @@ def test_rope_matches_hf_formula(dtype, packed):
     cos, sin = fr.cos().contiguous(), fr.sin().contiguous()
     x0 = torch.randn(N * L, H * hd, device=DEV).to(dtype)
     x = x0.clone().requires_grad_(True)
-    y = ops.rope_(x * 1.0, cos, sin, H, hd)           # x*1.0: a fresh tensor, as the projection output is
+    # a fused q|k|v-like row: H rotated heads followed by 2 pass-through heads
+    extra = torch.randn(N * L, 2 * hd, device=DEV).to(dtype)
+    xin = torch.cat([x, extra], -1)
+    yfull = ops.rope_(xin * 1.0, cos, sin, H, hd)     # *1.0: a fresh tensor, as the projection output is
+    assert torch.equal(yfull[:, H * hd:], extra)
+    y = yfull[:, : H * hd]
     gy = torch.randn_like(y)
     y.backward(gy)
     xr = x0.double().view(N * L, H, hd).requires_grad_(True)
