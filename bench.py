@@ -37,9 +37,11 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak
 MFMA_F32_PEAK_TFLOPS = 157.3
 
 WORKLOADS = {
-    # name: (arch, B, K, Lq, Lp, temperature, dtype)
+    # name: (arch, B, K, Lq, Lp, temperature, dtype).  K = 1 + "rankpo": chosen/rejected pairs (BASELINE configs[3]).
     "cfg2": ("llama-3.2-1b", 8, 5, 1280, 4096, 0.02, "bf16"),
     "cfg1": ("bge-small", 8, 5, 128, 256, 0.02, "f32"),
+    "cfg4": ("llama-3.2-1b", 8, 1, 1280, 4096, 0.1, "bf16"),      # RankPO: reference_free, sigmoid, beta 2.0
+    "cfg5": ("llama-3-8b", 8, 5, 1280, 4096, 0.02, "bf16"),       # 8B contrastive (per-GPU part of configs[4])
     "tiny": ("llama-tiny", 8, 5, 160, 512, 0.02, "bf16"),
 }
 
@@ -337,7 +339,15 @@ def main():
     timed = TimedLib(_lib.load())
     if not args.no_kernel_timing:
         _lib._lib = timed
-    ts = TrainStep(model.parameters(), lambda b: model(**b)["loss"], lr=1e-5, max_grad_norm=1.0,
+    if args.workload == "cfg4":
+        # RankPO stage (rankpo_trainer.py:570-587): policy = the bare encoder, no reference model (reference_free),
+        # metrics stay on the device (one host copy per LOG step, not per micro-step)
+        trainer = rankpo_amd.RankPOTrainer(enc, None, beta=2.0, temperature=temperature, loss_type="sigmoid",
+                                           reference_free=True, rankpo_weight=1.0, sft_weight=0.0)
+        loss_fn = lambda b: trainer.get_batch_loss_metrics(enc, b, "train", sync_metrics=False)[0]
+    else:
+        loss_fn = lambda b: model(**b)["loss"]
+    ts = TrainStep(model.parameters(), loss_fn, lr=1e-5, max_grad_norm=1.0,
                    gradient_accumulation_steps=1, total_steps=max(10, args.steps + args.warmup), warmup_ratio=0.1,
                    force_collectives=args.force_dist)
 
@@ -391,8 +401,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtn, "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {arch} contrastive, B={B}/GPU, K={K}, q_len={Lq}, p_len={Lp}, "
-                                   f"T={temperature}, in-batch negs" + (", cross-device negs" if multi else ""),
+            "config": {"workload": (f"{args.workload}: {arch} RankPO (reference_free, sigmoid, beta=2.0), B={B}/GPU, "
+                                    f"chosen+rejected, q_len={Lq}, p_len={Lp}, T={temperature}") if args.workload == "cfg4" else
+                                   (f"{args.workload}: {arch} contrastive, B={B}/GPU, K={K}, q_len={Lq}, p_len={Lp}, "
+                                    f"T={temperature}, in-batch negs" + (", cross-device negs" if multi else "")),
                        "global_batch": world * B, "pairs_per_step": world * B * (1 + K),
                        "parallelism": f"dp{world}", "optimizer": "AdamW(flat, HIP) + clip 1.0, GAS=1",
                        "grad_checkpointing": "all blocks" if ckpt < 0 else f"first {ckpt} blocks",
