@@ -305,3 +305,54 @@ def test_add_rmsnorm_matches_torch(dtype, rows, d, with_delta):
     if with_delta:
         assert rel(xn, xr) < tol and rel(dl.grad, d2.grad) < tol
     assert rel(w.grad, w2.grad) < (tol if dtype == torch.float32 else 2.0 ** -5)
+
+
+@pytest.mark.parametrize("gas", [1, 2])
+def test_multi_step_training_loss_parity_vs_oracle(gas):
+    """Step-loss parity over several optimizer steps (f2): TrainStep (HIP scoring + flat AdamW + clip + cosine schedule,
+    GAS micro-batches per step) against the CPU oracle model trained with torch.optim.AdamW, clip_grad_norm_ and
+    transformers' cosine schedule on the same batches (f32)."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    from rankpo_amd.train_step import TrainStep
+    from transformers import get_cosine_schedule_with_warmup
+    torch.manual_seed(13)
+    cfg = PE.llama_config(vocab_size=200, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, pad_token_id=0)
+    enc = PE.LlamaEncoder(cfg)
+    w = {k: v.detach().clone().requires_grad_(True) for k, v in enc.state_dict().items()}
+    rs = np.random.RandomState(14)
+    steps, lr = 4, 5e-3
+
+    def mk():
+        qi, qm = _batch(rs, 4, 12, 200)
+        pi, pm = _batch(rs, 12, 20, 200)
+        return {"query": {"input_ids": qi, "attention_mask": qm}, "passage": {"input_ids": pi, "attention_mask": pm}}
+    batches = [[mk() for _ in range(gas)] for _ in range(steps)]
+    # oracle trajectory
+    opt = torch.optim.AdamW(list(w.values()), lr=lr, weight_decay=0.0, eps=1e-8)
+    sch = get_cosine_schedule_with_warmup(opt, num_warmup_steps=1, num_training_steps=steps)
+    ref_losses = []
+    for mb in batches:
+        tot = 0.0
+        for b in mb:
+            loss = E.contrastive_step(w, cfg.to_dict(), b, 0.05)[0]
+            (loss / gas).backward()
+            tot += loss.item() / gas
+        torch.nn.utils.clip_grad_norm_(list(w.values()), 1.0)
+        opt.step(); sch.step(); opt.zero_grad()
+        ref_losses.append(tot)
+    # product trajectory
+    model = rankpo_amd.ModelForTraining(encoder=enc.to(DEV), temperature=0.05).train()
+    ts = TrainStep(model.parameters(), lambda b: model(**b)["loss"], lr=lr, max_grad_norm=1.0,
+                   gradient_accumulation_steps=gas, total_steps=steps, warmup_ratio=0.25)
+    assert ts.warmup_steps == 1
+    got = []
+    for mb in batches:
+        gb = [{k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in b.items()} for b in mb]
+        got.append(ts.step(gb).item())
+    np.testing.assert_allclose(got, ref_losses, rtol=2e-3, atol=2e-3)
+    assert abs(got[0] - got[-1]) > 1e-3          # the parameters really moved
+    # parameters after training agree too
+    wq = w["layers.0.self_attn.q_proj.weight"].detach()
+    assert (enc.layers[0].self_attn.q_proj.weight.detach().cpu() - wq).abs().max() < 5e-3 * wq.abs().max()
