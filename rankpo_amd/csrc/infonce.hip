@@ -496,23 +496,24 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
             acc[0][n][0] = mx;
             acc[0][n][1] = sum;
         }
-    }
-    if (staged && !(dbg & 1)) {
-        const int64_t prow0 = p0 + wp * 128 + (lane & 15) * 8;          // first of this lane's 8 passage columns
+        if (staged && !(dbg & 1)) {
+            // stream this quarter (16 query rows) out now: its stores drain while the next quarter is being computed
+            const int64_t prow0 = p0 + wp * 128 + (lane & 15) * 8;          // first of this lane's 8 passage columns
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int r = 4 * i + (lane >> 4);
-            const int64_t qi = q0 + wq * 64 + r;
-            const uint4 w = *reinterpret_cast<const uint4*>(wstage + r * kBigStageRowBytes + (lane & 15) * 16);
-            if (qi < Q) {
-                bf16_t* dst = scores + qi * P + prow0;
-                if (prow0 + 7 < P) {
-                    *reinterpret_cast<uint4*>(dst) = w;
-                } else {
-                    const unsigned ww[4] = {w.x, w.y, w.z, w.w};
+            for (int i = 0; i < 4; ++i) {
+                const int r = 16 * n + 4 * i + (lane >> 4);
+                const int64_t qi = q0 + wq * 64 + r;
+                const uint4_t w = *reinterpret_cast<const uint4_t*>(wstage + r * kBigStageRowBytes + (lane & 15) * 16);
+                if (qi < Q) {
+                    bf16_t* dst = scores + qi * P + prow0;
+                    if (prow0 + 7 < P) {
+                        if (dbg & 4) *reinterpret_cast<uint4_t*>(dst) = w;
+                        else __builtin_nontemporal_store(w, reinterpret_cast<uint4_t*>(dst));
+                    } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e)
-                        if (prow0 + e < P) dst[e] = (bf16_t)(ww[e >> 1] >> ((e & 1) * 16));
+                        for (int e = 0; e < 8; ++e)
+                            if (prow0 + e < P) dst[e] = (bf16_t)(w[e >> 1] >> ((e & 1) * 16));
+                    }
                 }
             }
         }
