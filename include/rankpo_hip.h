@@ -194,6 +194,17 @@ int rpo_add_rmsnorm_fwd(const void* x, const void* delta, const void* weight, fl
 int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, const float* rstd, const void* dres,
                         void* dx_out, float* dw_partial, int64_t rows, int64_t d, int dtype, rpo_stream_t stream);
 
+/* Causal variable-length flash attention, forward, head_dim 64, bf16, grouped-query heads (encoder side; the packed
+ * encoder path of rankpo_amd/encoder.py).  q: [T, num_heads, 64] with token stride q_stride elements (heads contiguous),
+ * k / v: [T, num_kv_heads, 64] likewise (all three may be views of one fused projection output).  cu_seqlens: int32
+ * [N + 1].  tiles: int32 [ntiles][2] = (sequence id, first query row inside the sequence), one entry per block of 128
+ * queries, heaviest first.  out: [T, num_heads * 64] (token stride out_stride), lse: f32 [num_heads][T] =
+ * log sum_j exp(scale * <q_i, k_j>) over the keys j <= i of the same sequence. */
+int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
+                       int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles, int64_t total_tokens,
+                       int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
+                       int64_t out_stride, float* lse, rpo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

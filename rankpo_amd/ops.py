@@ -423,5 +423,33 @@ def rope_(x, cos, sin, heads, head_dim):
     return _Rope.apply(x, cos, sin, heads, head_dim)
 
 
+# ------------------------------------------------------------------------------------------------
+# (6) causal variable-length flash attention, head_dim 64 (encoder side)
+# ------------------------------------------------------------------------------------------------
+def attn_tile_table(lens, device, block_m: int = 128):
+    """int32 [ntiles, 2] = (sequence id, first query row), heaviest (latest) tiles first: causal tiles late in a long
+    sequence have the most key tiles, scheduling them first evens out the tail."""
+    tiles = [(s, q0) for s, n in enumerate(lens) for q0 in range(0, n, block_m)]
+    tiles.sort(key=lambda t: -t[1])
+    return torch.tensor(tiles, dtype=torch.int32).to(device, non_blocking=True)
+
+
+def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale):
+    """q [T, nh, 64], k / v [T, nkv, 64] (last two dims contiguous, token stride free); returns (out [T, nh, 64] bf16,
+    lse [nh, T] f32)."""
+    lib = _lib.load()
+    T, nh, hd = q.shape
+    nkv = k.shape[1]
+    if q.dtype != torch.bfloat16 or hd != 64 or q.stride(2) != 1 or q.stride(1) != hd or k.stride(1) != hd or v.stride(1) != hd:
+        raise ValueError("flash_attn_varlen_fwd: bf16, head_dim 64, heads contiguous inside a token row")
+    out = torch.empty((T, nh, hd), dtype=q.dtype, device=q.device)
+    lse = torch.empty((nh, T), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        check(lib.rpo_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0),
+                                     cu_seqlens.data_ptr(), tiles.data_ptr(), tiles.shape[0], T, nh, nkv, hd, scale,
+                                     out.data_ptr(), nh * hd, lse.data_ptr(), _stream(q)), "rpo_flash_attn_fwd")
+    return out, lse
+
+
 __all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok"]
