@@ -198,12 +198,13 @@ int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, c
  * encoder path of rankpo_amd/encoder.py).  q: [T, num_heads, 64] with token stride q_stride elements (heads contiguous),
  * k / v: [T, num_kv_heads, 64] likewise (all three may be views of one fused projection output).  cu_seqlens: int32
  * [N + 1].  tiles: int32 [ntiles][2] = (sequence id, first query row inside the sequence), one entry per block of 128
- * queries, heaviest first.  out: [T, num_heads * 64] (token stride out_stride), lse: f32 [num_heads][T] =
- * log sum_j exp(scale * <q_i, k_j>) over the keys j <= i of the same sequence. */
+ * queries, heaviest first.  out: [T, num_heads * 64] (token stride out_stride), lse = log sum_j exp(scale * <q_i, k_j>)
+ * over the keys j <= i of the same sequence, f32, laid out [num_heads][T] when lse_max_len == 0 or padded
+ * [N][num_heads][lse_max_len] (the layout PyTorch's flash-attention backward reads) when lse_max_len > 0. */
 int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
                        int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles, int64_t total_tokens,
                        int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
-                       int64_t out_stride, float* lse, rpo_stream_t stream);
+                       int64_t out_stride, float* lse, int64_t lse_max_len, rpo_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,8 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
 __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
     int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int nh, int nkv, float scale_log2e,
-    float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t total_tokens) {
+    float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
+    int64_t lse_head_stride, int lse_packed) {
     __shared__ __attribute__((aligned(16))) char smem[2 * kFaBN * 128];   // K tile | V tile, 128-byte rows
     char* Ks = smem;
     char* Vs = smem + kFaBN * 128;
@@ -230,7 +231,9 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
             w.y = pack_bf16(oacc[c][n][2] * inv, oacc[c][n][3] * inv);
             *reinterpret_cast<uint2*>(orow + 16 * c + 4 * g) = w;
         }
-        if (g == 0) lse[(int64_t)h * total_tokens + t0 + qi] = mrun[n] * scale + logf(lrun[n]);
+        if (g == 0)
+            lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
+                mrun[n] * scale + logf(lrun[n]);
     }
 }
 
@@ -239,7 +242,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
                                   int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles,
                                   int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim,
-                                  float scale, void* out, int64_t out_stride, float* lse, rpo_stream_t stream) {
+                                  float scale, void* out, int64_t out_stride, float* lse, int64_t lse_max_len,
+                                  rpo_stream_t stream) {
     if (!q || !k || !v || !cu_seqlens || !tiles || !out || !lse || ntiles <= 0 || total_tokens <= 0)
         return RPO_ERR_INVALID_ARG;
     if (head_dim != kFaHD || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 || num_heads > 65535)
@@ -251,6 +255,8 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
     const float log2e = 1.4426950408889634f;
     RPO_LAUNCH(fa_fwd_kernel, dim3((unsigned)ntiles, (unsigned)num_heads), dim3(kFaThreads), 0, st, (const bf16_t*)q,
                (const bf16_t*)k, (const bf16_t*)v, q_stride, k_stride, v_stride, cu_seqlens, tiles, (int)num_heads,
-               (int)num_kv_heads, scale * log2e, scale, (bf16_t*)out, out_stride, lse, total_tokens);
+               (int)num_kv_heads, scale * log2e, scale, (bf16_t*)out, out_stride, lse,
+               lse_max_len > 0 ? num_heads * lse_max_len : 0, lse_max_len > 0 ? lse_max_len : total_tokens,
+               lse_max_len > 0 ? 0 : 1);
     return rpo_launch_status();
 }

@@ -161,12 +161,15 @@ class RopeTables:
 class VarlenCtx:
     """cu_seqlens (int32, device), the host copy of the lengths and the longest length of a packed batch."""
 
-    def __init__(self, cu, lens, max_len):
-        self.cu, self.lens, self.max_len = cu, lens, max_len
+    def __init__(self, cu, lens, max_len, tiles=None):
+        self.cu, self.lens, self.max_len, self.tiles = cu, lens, max_len, tiles
 
 
 def _varlen_causal_attention(q, k, v, ctx: VarlenCtx):
     """q [T, nh, hd], k/v [T, nkv, hd] packed; causal attention inside each sequence."""
+    if q.is_cuda and q.dtype == torch.bfloat16 and q.shape[-1] == 64 and ctx.tiles is not None:
+        # hand-written HIP kernel (head_dim 64): 2.2x the AOTriton varlen forward on the cfg-2 passage shape
+        return _ops.flash_attn_varlen(q, k, v, ctx.cu, ctx.tiles, ctx.max_len, 1.0 / math.sqrt(q.shape[-1]))
     if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16):
         return torch.ops.aten._flash_attention_forward(q, k, v, ctx.cu, ctx.cu, ctx.max_len, ctx.max_len, 0.0, True,
                                                        False)[0]
@@ -411,7 +414,8 @@ class LlamaEncoder(nn.Module):
         rope = self._rope(flat % L)                                                        # per-token angles [T, hd/2]
         cu = torch.zeros(N + 1, dtype=torch.int32, device=x.device)
         cu[1:] = lens_d.cumsum(0).to(torch.int32)
-        ctx = VarlenCtx(cu, lens, max(lens))
+        tiles = _ops.attn_tile_table(lens, x.device) if (x.is_cuda and self.config.head_dim == 64) else None
+        ctx = VarlenCtx(cu, lens, max(lens), tiles)
         last_idx = (cu[1:] - 1).to(torch.int64)
         x, delta = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1)
         li = len(self.layers) - 1

@@ -434,22 +434,52 @@ def attn_tile_table(lens, device, block_m: int = 128):
     return torch.tensor(tiles, dtype=torch.int32).to(device, non_blocking=True)
 
 
-def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale):
+def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0):
     """q [T, nh, 64], k / v [T, nkv, 64] (last two dims contiguous, token stride free); returns (out [T, nh, 64] bf16,
-    lse [nh, T] f32)."""
+    lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0)."""
     lib = _lib.load()
     T, nh, hd = q.shape
     nkv = k.shape[1]
     if q.dtype != torch.bfloat16 or hd != 64 or q.stride(2) != 1 or q.stride(1) != hd or k.stride(1) != hd or v.stride(1) != hd:
         raise ValueError("flash_attn_varlen_fwd: bf16, head_dim 64, heads contiguous inside a token row")
     out = torch.empty((T, nh, hd), dtype=q.dtype, device=q.device)
-    lse = torch.empty((nh, T), dtype=torch.float32, device=q.device)
+    if padded_lse_len > 0:
+        lse = torch.zeros((num_seqs, nh, padded_lse_len), dtype=torch.float32, device=q.device)
+    else:
+        lse = torch.empty((nh, T), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         check(lib.rpo_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0),
                                      cu_seqlens.data_ptr(), tiles.data_ptr(), tiles.shape[0], T, nh, nkv, hd, scale,
-                                     out.data_ptr(), nh * hd, lse.data_ptr(), _stream(q)), "rpo_flash_attn_fwd")
+                                     out.data_ptr(), nh * hd, lse.data_ptr(), padded_lse_len, _stream(q)),
+              "rpo_flash_attn_fwd")
     return out, lse
 
 
+class _FlashAttnVarlen(torch.autograd.Function):
+    """Causal varlen attention: hand-written HIP forward; backward through PyTorch's flash-attention backward op on the
+    saved (out, lse) until the HIP backward lands."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, cu, tiles, max_len, scale):
+        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=max_len, num_seqs=cu.numel() - 1)
+        ctx.save_for_backward(q, k, v, out, lse, cu)
+        ctx.meta = (max_len, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        q, k, v, out, lse, cu = ctx.saved_tensors
+        max_len, scale = ctx.meta
+        z = torch.zeros((), dtype=torch.int64, device=q.device)
+        dq, dk, dv = torch.ops.aten._flash_attention_backward(go.contiguous(), q, k, v, out, lse, cu, cu, max_len, max_len,
+                                                              0.0, True, z, z, scale=scale)
+        return dq, dk, dv, None, None, None, None
+
+
+def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale):
+    return _FlashAttnVarlen.apply(q, k, v, cu, tiles, max_len, scale)
+
+
 __all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
-           "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok"]
+           "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
+           "flash_attn_varlen", "flash_attn_varlen_fwd", "attn_tile_table"]

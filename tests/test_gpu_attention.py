@@ -48,6 +48,21 @@ def test_flash_attn_fwd_matches_reference(lens, nh, nkv, fused):
     ro, rl = ref_attention(q, k, v, lens, scale)
     assert (out.float() - ro).abs().max() < 2.5e-2          # bf16 P and bf16 output: ~2^-7 relative on O(1) values
     assert (lse - rl).abs().max() < 2e-3
+    # padded [N, nh, max_len] layout (what PyTorch's backward op reads)
+    _, lp = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=max(lens), num_seqs=len(lens))
+    o0 = 0
+    for i, n in enumerate(lens):
+        assert torch.equal(lp[i, :, :n], lse[:, o0:o0 + n])
+        o0 += n
+    # autograd path: HIP forward + flash backward op, against autograd through the f32 reference
+    qa, ka, va = (t.detach().clone().requires_grad_(True) for t in (q.contiguous(), k.contiguous(), v.contiguous()))
+    oa = ops.flash_attn_varlen(qa, ka, va, cu, tiles, max(lens), scale)
+    go = torch.randn_like(oa)
+    oa.backward(go)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    ref_attention(qr, kr, vr, lens, scale)[0].backward(go.float())
+    for a, b in ((qa.grad, qr.grad), (ka.grad, kr.grad), (va.grad, vr.grad)):
+        assert (a.float() - b).abs().max() < 0.03 * max(1.0, b.abs().max().item())
     # against PyTorch's own flash attention (same bf16 inputs): both are bf16-accurate, so they agree closely
     po = torch.ops.aten._flash_attention_forward(q.contiguous(), k.contiguous(), v.contiguous(), cu, cu, max(lens),
                                                  max(lens), 0.0, True, False, scale=scale)[0]
