@@ -206,6 +206,17 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
                        int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
                        int64_t out_stride, float* lse, int64_t lse_max_len, rpo_stream_t stream);
 
+/* Backward of rpo_flash_attn_fwd (three launches, no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
+ * forward with lse_max_len == 0; delta: f32 [num_heads][T] scratch (written here: rowsum(dout * out)).  q_tiles as in the
+ * forward; k_tiles: int32 [n_k_tiles][2] = (sequence id, first key of a 32-key tile), earliest keys first.
+ * dq: [T, num_heads, 64], dk / dv: [T, num_kv_heads, 64] (token strides given), every valid row is written. */
+int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, int64_t q_stride,
+                       int64_t k_stride, int64_t v_stride, int64_t out_stride, int64_t dout_stride,
+                       const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles, const int* k_tiles,
+                       int64_t n_k_tiles, int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads,
+                       int64_t head_dim, float scale, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                       int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, rpo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

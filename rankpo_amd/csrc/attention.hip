@@ -237,6 +237,400 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Backward.  Three launches, no atomics, deterministic:
+//   fa_delta_kernel      delta[h][t] = sum_d dO[t,h,d] O[t,h,d]
+//   fa_bwd_dq_kernel     block = 128 queries of one (sequence, head), loop over key tiles <= diagonal:
+//                        S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP - delta) scale, dQ^T += K^T dS^T
+//                        (query on the lane: lse / delta are per-lane scalars; dS^T accumulators are the B fragments)
+//   fa_bwd_dkdv_kernel   block = 32 keys of one (sequence, kv head), loop over the q heads of the group and the query
+//                        tiles >= the key tile: S = Q K^T, dP = dO V^T (key on the lane, K / V fragments stay in
+//                        registers), dV^T += dO^T P, dK^T += Q^T dS with Q^T / dO^T read transposed from the same LDS
+//                        images that serve the row reads (chunk ^= row & 7 is conflict-free for both kinds of read).
+// P is recomputed from the saved lse: P = exp(scale s - lse).
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void fa_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
+                                                       int64_t so, int64_t sdo, int nh, int64_t T,
+                                                       float* __restrict__ delta) {
+    // one wave per (token, 8 heads): lane = (head in group of 8, 16-byte chunk)
+    const int64_t t = blockIdx.x;
+    for (int hc = threadIdx.x; hc < nh * 8; hc += 256) {
+        const int h = hc >> 3, ch = hc & 7;
+        Vec16<bf16_t> a, b;
+        a.load(o + t * so + h * kFaHD + ch * 8);
+        b.load(dout + t * sdo + h * kFaHD + ch * 8);
+        float acc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc = fmaf(a.v[e], b.v[e], acc);
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        if (ch == 0) delta[(int64_t)h * T + t] = acc;
+    }
+}
+
+// 8 transposed reads of a 64-hd x 32-row block (rows r0 + {0..3} and r0 + 16 + {0..3} per lane group), returned as the
+// four A fragments (hd tiles c = 0..3); `base` = LDS byte address of the [rows][128 B] image, swizzle chunk ^= row & 7.
+__device__ __forceinline__ void lds_tr_frags(unsigned base, int rowbase, int g, int fr, short8_t (&av)[4]) {
+    const int qq = fr >> 2, pp = fr & 3;
+    unsigned ad[8];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int r0 = rowbase + 4 * g + qq, r1 = r0 + 16;
+        const int lc = 2 * c + (pp >> 1);
+        ad[2 * c] = base + r0 * 128 + ((lc ^ (r0 & 7)) << 4) + 8 * (pp & 1);
+        ad[2 * c + 1] = base + r1 * 128 + ((lc ^ (r1 & 7)) << 4) + 8 * (pp & 1);
+    }
+    u32x2 t0v, t1v, t2v, t3v, t4v, t5v, t6v, t7v;
+    asm volatile(
+        "ds_read_b64_tr_b16 %0, %8\n\t"
+        "ds_read_b64_tr_b16 %1, %9\n\t"
+        "ds_read_b64_tr_b16 %2, %10\n\t"
+        "ds_read_b64_tr_b16 %3, %11\n\t"
+        "ds_read_b64_tr_b16 %4, %12\n\t"
+        "ds_read_b64_tr_b16 %5, %13\n\t"
+        "ds_read_b64_tr_b16 %6, %14\n\t"
+        "ds_read_b64_tr_b16 %7, %15\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(t0v), "=&v"(t1v), "=&v"(t2v), "=&v"(t3v), "=&v"(t4v), "=&v"(t5v), "=&v"(t6v), "=&v"(t7v)
+        : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
+        : "memory");
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 w0 = {t0v[0], t0v[1], t1v[0], t1v[1]}, w1 = {t2v[0], t2v[1], t3v[0], t3v[1]};
+    const u32x4 w2 = {t4v[0], t4v[1], t5v[0], t5v[1]}, w3 = {t6v[0], t6v[1], t7v[0], t7v[1]};
+    av[0] = __builtin_bit_cast(short8_t, w0);
+    av[1] = __builtin_bit_cast(short8_t, w1);
+    av[2] = __builtin_bit_cast(short8_t, w2);
+    av[3] = __builtin_bit_cast(short8_t, w3);
+}
+
+__device__ __forceinline__ short8_t pack_frag(const float4_t& lo, const float4_t& hi) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 w = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+    return __builtin_bit_cast(short8_t, w);
+}
+
+__global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
+    const int* __restrict__ tiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ lse,
+    const float* __restrict__ delta, int64_t T, bf16_t* __restrict__ dq, int64_t sdq) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kFaBN * 128];   // K tile | V tile (both chunk ^= row & 7)
+    char* Ks = smem;
+    char* Vs = smem + kFaBN * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, fr = lane & 15;
+    const int seq = tiles[2 * blockIdx.x], q0 = tiles[2 * blockIdx.x + 1];
+    const int h = blockIdx.y, hk = h / (nh / nkv);
+    const int64_t t0 = cu[seq];
+    const int len = cu[seq + 1] - (int)t0;
+    const int qw = q0 + 32 * wave;
+    short8_t bq[2][2], bdo[2][2];
+    float lq[2], dl[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int qi = qw + 16 * n + fr;
+        const bool ok = qi < len;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bq[n][ks] = ok ? *reinterpret_cast<const short8_t*>(q + (t0 + qi) * sq + h * kFaHD + 32 * ks + 8 * g)
+                           : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            bdo[n][ks] = ok ? *reinterpret_cast<const short8_t*>(dout + (t0 + qi) * sdo + h * kFaHD + 32 * ks + 8 * g)
+                            : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        lq[n] = ok ? lse[(int64_t)h * T + t0 + qi] * 1.4426950408889634f : 0.f;
+        dl[n] = ok ? delta[(int64_t)h * T + t0 + qi] : 0.f;
+    }
+    float4_t acc[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const int last_q = min(q0 + kFaBM - 1, len - 1);
+    const int nkt = last_q / kFaBN + 1;
+    uint4 kreg[2], vreg[2];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            const int key = kt * kFaBN + row;
+            if (key < len) {
+                kreg[i] = *reinterpret_cast<const uint4*>(k + (t0 + key) * sk + hk * kFaHD + ch * 8);
+                vreg[i] = *reinterpret_cast<const uint4*>(v + (t0 + key) * sv + hk * kFaHD + ch * 8);
+            } else {
+                kreg[i] = make_uint4(0, 0, 0, 0);
+                vreg[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<uint4*>(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = kreg[i];
+            *reinterpret_cast<uint4*>(Vs + row * 128 + ((ch ^ (row & 7)) << 4)) = vreg[i];
+        }
+    };
+    stage_load(0);
+    stage_write();
+    __syncthreads();
+    const unsigned ks_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Ks;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) stage_load(kt + 1);
+        const bool active = (kt * kFaBN <= qw + 31) && (qw < len);
+        if (active) {
+            float4_t s[4][2], dp[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    s[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+                    dp[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int row = 16 * m + fr;
+                    const int off = row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4);
+                    const short8_t ak = *reinterpret_cast<const short8_t*>(Ks + off);
+                    const short8_t av = *reinterpret_cast<const short8_t*>(Vs + off);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        s[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bq[n][ks], s[m][n], 0, 0, 0);
+                        dp[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bdo[n][ks], dp[m][n], 0, 0, 0);
+                    }
+                }
+            }
+            const int kbase = kt * kFaBN + 4 * g;
+            const bool need_mask = (kt * kFaBN + kFaBN - 1 > qw) || (kt * kFaBN + kFaBN > len);
+            short8_t dsf[2][2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int qi = qw + 16 * n + fr;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -lq[n]));
+                        if (need_mask) {
+                            const int key = kbase + 16 * m + r;
+                            if (key > qi || key >= len || qi >= len) pv = 0.f;
+                        }
+                        s[m][n][r] = pv * (dp[m][n][r] - dl[n]) * scale;
+                    }
+                dsf[0][n] = pack_frag(s[0][n], s[1][n]);
+                dsf[1][n] = pack_frag(s[2][n], s[3][n]);
+            }
+#pragma unroll
+            for (int sI = 0; sI < 2; ++sI) {
+                short8_t av[4];
+                lds_tr_frags(ks_base, 32 * sI, g, fr, av);
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+                        acc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[c], dsf[sI][n], acc[c][n], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        if (kt + 1 < nkt) {
+            stage_write();
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int qi = qw + 16 * n + fr;
+        if (qi >= len) continue;
+        bf16_t* row = dq + (t0 + qi) * sdq + h * kFaHD;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint2 w;
+            w.x = pack_bf16(acc[c][n][0], acc[c][n][1]);
+            w.y = pack_bf16(acc[c][n][2], acc[c][n][3]);
+            *reinterpret_cast<uint2*>(row + 16 * c + 4 * g) = w;
+        }
+    }
+}
+
+// ktiles: int32 [nkt][2] = (sequence id, first key of a 32-key tile), earliest keys (most work) first.
+__global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dkdv_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
+    const int* __restrict__ ktiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ lse,
+    const float* __restrict__ delta, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
+    int64_t sdv) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kFaBM * 128];   // Q tile | dO tile, 128 rows each
+    char* Qs = smem;
+    char* Ds = smem + kFaBM * 128;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, fr = lane & 15;
+    const int seq = ktiles[2 * blockIdx.x], k0 = ktiles[2 * blockIdx.x + 1];
+    const int hk = blockIdx.y, group = nh / nkv;
+    const int64_t t0 = cu[seq];
+    const int len = cu[seq + 1] - (int)t0;
+    // K / V fragments of this block's 32 keys (B operands: lane = key fr of tile n, k = hd 32 ks + 8 g ..)
+    short8_t bk[2][2], bv[2][2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int key = k0 + 16 * n + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bk[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(k + (t0 + key) * sk + hk * kFaHD + 32 * ks + 8 * g)
+                                  : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            bv[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(v + (t0 + key) * sv + hk * kFaHD + 32 * ks + 8 * g)
+                                  : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    float4_t dka[4][2], dva[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            dka[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+            dva[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    const int qt0 = (k0 / kFaBM) * kFaBM;                  // first query tile that can see these keys
+    const int nqt = (len - qt0 + kFaBM - 1) / kFaBM;
+    const int niter = nqt * group;
+    uint4 qreg[4], dreg[4];
+    auto stage_load = [&](int it) {
+        const int hq = hk * group + it / nqt, qb = qt0 + (it % nqt) * kFaBM;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            const int qi = qb + row;
+            if (qi < len) {
+                qreg[i] = *reinterpret_cast<const uint4*>(q + (t0 + qi) * sq + hq * kFaHD + ch * 8);
+                dreg[i] = *reinterpret_cast<const uint4*>(dout + (t0 + qi) * sdo + hq * kFaHD + ch * 8);
+            } else {
+                qreg[i] = make_uint4(0, 0, 0, 0);
+                dreg[i] = make_uint4(0, 0, 0, 0);
+            }
+        }
+    };
+    auto stage_write = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
+            *reinterpret_cast<uint4*>(Qs + row * 128 + ((ch ^ (row & 7)) << 4)) = qreg[i];
+            *reinterpret_cast<uint4*>(Ds + row * 128 + ((ch ^ (row & 7)) << 4)) = dreg[i];
+        }
+    };
+    stage_load(0);
+    stage_write();
+    __syncthreads();
+    const unsigned qs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Qs;
+    const unsigned ds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Ds;
+    for (int it = 0; it < niter; ++it) {
+        if (it + 1 < niter) stage_load(it + 1);
+        const int hq = hk * group + it / nqt, qb = qt0 + (it % nqt) * kFaBM;
+        const int qw = qb + 32 * wave;                       // this wave's 32 queries
+        const bool active = (qw + 31 >= k0) && (qw < len);
+        if (active) {
+            float4_t s[2][2], dp[2][2];                       // [query tile m][key tile n]; rows = queries 4g + r
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    s[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+                    dp[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int row = 32 * wave + 16 * m + fr;
+                    const int off = row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4);
+                    const short8_t aq = *reinterpret_cast<const short8_t*>(Qs + off);
+                    const short8_t ad = *reinterpret_cast<const short8_t*>(Ds + off);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        s[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, bk[n][ks], s[m][n], 0, 0, 0);
+                        dp[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, bv[n][ks], dp[m][n], 0, 0, 0);
+                    }
+                }
+            }
+            // rows of the accumulators are queries qw + 16 m + 4 g + r: per-row lse / delta
+            const bool need_mask = (qw < k0 + 31) || (qw + 32 > len) || (k0 + 32 > len);
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int qr0 = qw + 16 * m + 4 * g;
+                float lr[4], dr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const bool ok = qr0 + r < len;
+                    lr[r] = ok ? lse[(int64_t)hq * T + t0 + qr0 + r] * 1.4426950408889634f : 0.f;
+                    dr[r] = ok ? delta[(int64_t)hq * T + t0 + qr0 + r] : 0.f;
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int key = k0 + 16 * n + fr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -lr[r]));
+                        if (need_mask && (key > qr0 + r || key >= len || qr0 + r >= len)) pv = 0.f;
+                        s[m][n][r] = pv;                                   // P
+                        dp[m][n][r] = pv * (dp[m][n][r] - dr[r]) * scale;   // dS
+                    }
+                }
+            }
+            short8_t pf[2], dsf[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                pf[n] = pack_frag(s[0][n], s[1][n]);      // k-slots = queries {4g + j, 16 + 4g + (j - 4)} of the wave's 32
+                dsf[n] = pack_frag(dp[0][n], dp[1][n]);
+            }
+            short8_t at[4];
+            lds_tr_frags(ds_base, 32 * wave, g, fr, at);   // dO^T: rows = hd, k = queries in the same order
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    dva[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[c], pf[n], dva[c][n], 0, 0, 0);
+            lds_tr_frags(qs_base, 32 * wave, g, fr, at);   // Q^T
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    dka[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[c], dsf[n], dka[c][n], 0, 0, 0);
+        }
+        __syncthreads();
+        if (it + 1 < niter) {
+            stage_write();
+            __syncthreads();
+        }
+    }
+    // cross-wave sum (each wave holds the partial over its own queries): 8 tiles x 4 waves through LDS, dK then dV
+    float4_t* red = reinterpret_cast<float4_t*>(smem);       // [wave][tile 0..7][lane]
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) red[(wave * 8 + c * 2 + n) * 64 + lane] = pass == 0 ? dka[c][n] : dva[c][n];
+        __syncthreads();
+        // wave w finishes tiles 2w, 2w+1 (c = w, n = 0 / 1)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int tile = wave * 2 + n;
+            float4_t tot = red[(0 * 8 + tile) * 64 + lane];
+#pragma unroll
+            for (int w = 1; w < 4; ++w) tot += red[(w * 8 + tile) * 64 + lane];
+            const int key = k0 + 16 * n + fr;
+            if (key < len) {
+                bf16_t* dst = (pass == 0 ? dk + (t0 + key) * sdk : dv + (t0 + key) * sdv) + hk * kFaHD + 16 * wave + 4 * g;
+                uint2 w2;
+                w2.x = pack_bf16(tot[0], tot[1]);
+                w2.y = pack_bf16(tot[2], tot[3]);
+                *reinterpret_cast<uint2*>(dst) = w2;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace
 
 extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
@@ -258,5 +652,40 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
                (int)num_kv_heads, scale * log2e, scale, (bf16_t*)out, out_stride, lse,
                lse_max_len > 0 ? num_heads * lse_max_len : 0, lse_max_len > 0 ? lse_max_len : total_tokens,
                lse_max_len > 0 ? 0 : 1);
+    return rpo_launch_status();
+}
+
+extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
+                                  int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t out_stride,
+                                  int64_t dout_stride, const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles,
+                                  const int* k_tiles, int64_t n_k_tiles, int64_t total_tokens, int64_t num_heads,
+                                  int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta,
+                                  void* dq, void* dk, void* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
+                                  rpo_stream_t stream) {
+    if (!q || !k || !v || !out || !dout || !cu_seqlens || !q_tiles || !k_tiles || !lse || !delta || !dq || !dk || !dv)
+        return RPO_ERR_INVALID_ARG;
+    if (n_q_tiles <= 0 || n_k_tiles <= 0 || total_tokens <= 0) return RPO_ERR_INVALID_ARG;
+    if (head_dim != kFaHD || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 || num_heads > 65535)
+        return RPO_ERR_UNSUPPORTED;
+    if (q_stride % 8 || k_stride % 8 || v_stride % 8 || out_stride % 8 || dout_stride % 8 || dq_stride % 4 ||
+        dk_stride % 4 || dv_stride % 4 || !rpo_aligned16(q) || !rpo_aligned16(k) || !rpo_aligned16(v) ||
+        !rpo_aligned16(out) || !rpo_aligned16(dout))
+        return RPO_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const float log2e = 1.4426950408889634f;
+    RPO_LAUNCH(fa_delta_kernel, dim3((unsigned)total_tokens), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout,
+               out_stride, dout_stride, (int)num_heads, total_tokens, delta);
+    int rc = rpo_launch_status();
+    if (rc != RPO_OK) return rc;
+    RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, (unsigned)num_heads), dim3(kFaThreads), 0, st,
+               (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
+               dout_stride, cu_seqlens, q_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse, delta,
+               total_tokens, (bf16_t*)dq, dq_stride);
+    rc = rpo_launch_status();
+    if (rc != RPO_OK) return rc;
+    RPO_LAUNCH(fa_bwd_dkdv_kernel, dim3((unsigned)n_k_tiles, (unsigned)num_kv_heads), dim3(kFaThreads), 0, st,
+               (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
+               dout_stride, cu_seqlens, k_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse, delta,
+               total_tokens, (bf16_t*)dk, (bf16_t*)dv, dk_stride, dv_stride);
     return rpo_launch_status();
 }

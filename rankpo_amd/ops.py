@@ -455,31 +455,63 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
     return out, lse
 
 
+def attn_key_tile_table(lens, device, block_n: int = 32):
+    """int32 [n, 2] = (sequence id, first key of a 32-key tile), earliest keys first (they see the most queries)."""
+    tiles = [(s, k0) for s, n in enumerate(lens) for k0 in range(0, n, block_n)]
+    tiles.sort(key=lambda t: t[1])
+    return torch.tensor(tiles, dtype=torch.int32).to(device, non_blocking=True)
+
+
+def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale):
+    lib = _lib.load()
+    T, nh, hd = q.shape
+    nkv = k.shape[1]
+    dout = dout.contiguous()
+    dq = torch.empty((T, nh, hd), dtype=q.dtype, device=q.device)
+    dk = torch.empty((T, nkv, hd), dtype=q.dtype, device=q.device)
+    dv = torch.empty((T, nkv, hd), dtype=q.dtype, device=q.device)
+    delta = torch.empty((nh, T), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        check(lib.rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
+                                     q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0),
+                                     cu_seqlens.data_ptr(), q_tiles.data_ptr(), q_tiles.shape[0], k_tiles.data_ptr(),
+                                     k_tiles.shape[0], T, nh, nkv, hd, scale, lse.data_ptr(), delta.data_ptr(),
+                                     dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), nh * hd, nkv * hd, nkv * hd,
+                                     _stream(q)), "rpo_flash_attn_bwd")
+    return dq, dk, dv
+
+
 class _FlashAttnVarlen(torch.autograd.Function):
-    """Causal varlen attention: hand-written HIP forward; backward through PyTorch's flash-attention backward op on the
-    saved (out, lse) until the HIP backward lands."""
+    """Causal varlen attention, head_dim 64: hand-written HIP forward and backward (k_tiles given), or HIP forward +
+    PyTorch's flash-attention backward op on the saved (out, padded lse) when k_tiles is None."""
 
     @staticmethod
-    def forward(ctx, q, k, v, cu, tiles, max_len, scale):
-        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=max_len, num_seqs=cu.numel() - 1)
-        ctx.save_for_backward(q, k, v, out, lse, cu)
-        ctx.meta = (max_len, scale)
+    def forward(ctx, q, k, v, cu, tiles, k_tiles, max_len, scale):
+        own_bwd = k_tiles is not None
+        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0 if own_bwd else max_len,
+                                         num_seqs=cu.numel() - 1)
+        ctx.save_for_backward(q, k, v, out, lse, cu, tiles, k_tiles if own_bwd else cu)
+        ctx.meta = (max_len, scale, own_bwd)
         return out
 
     @staticmethod
     def backward(ctx, go):
-        q, k, v, out, lse, cu = ctx.saved_tensors
-        max_len, scale = ctx.meta
-        z = torch.zeros((), dtype=torch.int64, device=q.device)
-        dq, dk, dv = torch.ops.aten._flash_attention_backward(go.contiguous(), q, k, v, out, lse, cu, cu, max_len, max_len,
-                                                              0.0, True, z, z, scale=scale)
-        return dq, dk, dv, None, None, None, None
+        q, k, v, out, lse, cu, tiles, k_tiles = ctx.saved_tensors
+        max_len, scale, own_bwd = ctx.meta
+        if own_bwd:
+            dq, dk, dv = flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale)
+        else:
+            z = torch.zeros((), dtype=torch.int64, device=q.device)
+            dq, dk, dv = torch.ops.aten._flash_attention_backward(go.contiguous(), q, k, v, out, lse, cu, cu, max_len,
+                                                                  max_len, 0.0, True, z, z, scale=scale)
+        return dq, dk, dv, None, None, None, None, None
 
 
-def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale):
-    return _FlashAttnVarlen.apply(q, k, v, cu, tiles, max_len, scale)
+def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale, k_tiles=None):
+    return _FlashAttnVarlen.apply(q, k, v, cu, tiles, k_tiles, max_len, scale)
 
 
 __all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
-           "flash_attn_varlen", "flash_attn_varlen_fwd", "attn_tile_table"]
+           "flash_attn_varlen", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
+           "attn_key_tile_table"]

@@ -63,6 +63,13 @@ def test_flash_attn_fwd_matches_reference(lens, nh, nkv, fused):
     ref_attention(qr, kr, vr, lens, scale)[0].backward(go.float())
     for a, b in ((qa.grad, qr.grad), (ka.grad, kr.grad), (va.grad, vr.grad)):
         assert (a.float() - b).abs().max() < 0.03 * max(1.0, b.abs().max().item())
+    # hand-written backward (delta + dQ + dK/dV kernels), on the strided views as well
+    qb, kb, vb = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+    ob = ops.flash_attn_varlen(qb, kb, vb, cu, tiles, max(lens), scale, k_tiles=ops.attn_key_tile_table(lens, DEV))
+    ob.backward(go)
+    for name, a, b in (("dq", qb.grad, qr.grad), ("dk", kb.grad, kr.grad), ("dv", vb.grad, vr.grad)):
+        err = (a.float() - b).abs().max().item()
+        assert err < 0.03 * max(1.0, b.abs().max().item()), (name, err, b.abs().max().item())
     # against PyTorch's own flash attention (same bf16 inputs): both are bf16-accurate, so they agree closely
     po = torch.ops.aten._flash_attention_forward(q.contiguous(), k.contiguous(), v.contiguous(), cu, cu, max(lens),
                                                  max(lens), 0.0, True, False, scale=scale)[0]
@@ -97,3 +104,15 @@ def test_flash_attn_fwd_speed_report():
     a = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale)[0]
     b = torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False)[0]
     assert (a.float() - b.float()).abs().max() < 2.5e-2
+    # backward: HIP (delta + dQ + dK/dV) vs PyTorch's op
+    out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale)
+    go = torch.randn_like(out)
+    kt = ops.attn_key_tile_table(lens, DEV)
+    ours_b = bench(lambda: ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, scale), 5)
+    r = torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False)
+    theirs_b = bench(lambda: torch.ops.aten._flash_attention_backward(go, q, k, v, r[0], r[1], cu, cu, max(lens), max(lens), 0.0, True, r[2], r[3]), 5)
+    print(f"flash bwd cfg-2 passages: HIP {ours_b:.2f} ms = {2.5 * fl / ours_b / 1e9:.0f} TFLOP/s ; AOTriton {theirs_b:.2f} ms = {2.5 * fl / theirs_b / 1e9:.0f} TFLOP/s")
+    d1 = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, scale)
+    d2 = torch.ops.aten._flash_attention_backward(go, q, k, v, r[0], r[1], cu, cu, max(lens), max(lens), 0.0, True, r[2], r[3])
+    for x, y in zip(d1, d2):
+        assert (x.float() - y.float()).abs().max() < 0.03 * max(1.0, y.float().abs().max().item())
