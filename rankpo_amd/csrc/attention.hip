@@ -454,23 +454,53 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
     }
 }
 
-// ktiles: int32 [nkt][2] = (sequence id, first key of a 32-key tile), earliest keys (most work) first.
+// LDS images of the dK/dV kernel use PADDED rows (160 bytes per 128-byte row): with that stride both the ds_read_b128
+// row reads and the ds_read_b64_tr_b16 transposed reads are bank-conflict-free WITHOUT an XOR swizzle, so every
+// transposed read is `base + immediate` and one asm statement can issue all 16 of an iteration from two address VGPRs.
+constexpr int kPadRow = 160;
+
+// Issues (does not wait for) the 16 transposed reads of one iteration: A fragments dO^T[c] (from image `dbase`) and
+// Q^T[c] (from `qbase`), c = hd tile 0..3, k-slots = rows rowbase + {4g + j, 16 + 4g + (j - 4)}.
+#define RPO_TR8(OUT0, OUT1, OUT2, OUT3, OUT4, OUT5, OUT6, OUT7, ADDR)                                               \
+    asm volatile(                                                                                                   \
+        "ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:2560\n\t"                                    \
+        "ds_read_b64_tr_b16 %2, %8 offset:32\n\tds_read_b64_tr_b16 %3, %8 offset:2592\n\t"                          \
+        "ds_read_b64_tr_b16 %4, %8 offset:64\n\tds_read_b64_tr_b16 %5, %8 offset:2624\n\t"                          \
+        "ds_read_b64_tr_b16 %6, %8 offset:96\n\tds_read_b64_tr_b16 %7, %8 offset:2656"                              \
+        : "=&v"(OUT0), "=&v"(OUT1), "=&v"(OUT2), "=&v"(OUT3), "=&v"(OUT4), "=&v"(OUT5), "=&v"(OUT6), "=&v"(OUT7)    \
+        : "v"(ADDR)                                                                                                 \
+        : "memory")
+
+__device__ __forceinline__ short8_t join_tr(const u32x2& lo, const u32x2& hi) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(short8_t, w);
+}
+
+// ktiles: int32 [n][3] = (sequence id, kv head, first key of a 32-key tile), sorted by (sequence, head, key): all
+// key tiles of one (sequence, kv head) re-read the same Q / dO rows, so they should run at the same time on ONE XCD
+// (shared L2).  Blocks b, b + 8, b + 16, ... share an XCD: block b takes entry (b % 8) * ceil(n / 8) + b / 8, i.e.
+// every XCD walks its own contiguous eighth of the table (placement is a speed matter only).
 __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
     const int* __restrict__ ktiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ lse,
     const float* __restrict__ delta, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
-    int64_t sdv) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kFaBM * 128];   // Q tile | dO tile, 128 rows each
+    int64_t sdv, int n_ktiles) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * kFaBM * kPadRow + 2 * kFaBM * 4];   // Q | dO | lse | delta
     char* Qs = smem;
-    char* Ds = smem + kFaBM * 128;
+    char* Ds = smem + kFaBM * kPadRow;
+    float* Ls = reinterpret_cast<float*>(smem + 2 * kFaBM * kPadRow);     // lse * log2(e) of the tile's 128 query rows
+    float* Dl = Ls + kFaBM;                                                // delta of the same rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, fr = lane & 15;
-    const int seq = ktiles[2 * blockIdx.x], k0 = ktiles[2 * blockIdx.x + 1];
-    const int hk = blockIdx.y, group = nh / nkv;
+    const int per = (n_ktiles + 7) >> 3;
+    const int entry = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (entry >= n_ktiles) return;
+    const int seq = ktiles[3 * entry], hk = ktiles[3 * entry + 1], k0 = ktiles[3 * entry + 2];
+    const int group = nh / nkv;
     const int64_t t0 = cu[seq];
     const int len = cu[seq + 1] - (int)t0;
-    // K / V fragments of this block's 32 keys (B operands: lane = key fr of tile n, k = hd 32 ks + 8 g ..)
     short8_t bk[2][2], bv[2][2];
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -495,6 +525,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dkdv_kernel(
     const int nqt = (len - qt0 + kFaBM - 1) / kFaBM;
     const int niter = nqt * group;
     uint4 qreg[4], dreg[4];
+    float sreg;                                            // one lse (threads 0..127) or delta (128..255) value
     auto stage_load = [&](int it) {
         const int hq = hk * group + it / nqt, qb = qt0 + (it % nqt) * kFaBM;
 #pragma unroll
@@ -509,26 +540,42 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dkdv_kernel(
                 dreg[i] = make_uint4(0, 0, 0, 0);
             }
         }
+        const int qi = qb + (tid & 127);
+        sreg = 0.f;
+        if (qi < len) sreg = tid < 128 ? lse[(int64_t)hq * T + t0 + qi] * 1.4426950408889634f : delta[(int64_t)hq * T + t0 + qi];
     };
     auto stage_write = [&]() {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4*>(Qs + row * 128 + ((ch ^ (row & 7)) << 4)) = qreg[i];
-            *reinterpret_cast<uint4*>(Ds + row * 128 + ((ch ^ (row & 7)) << 4)) = dreg[i];
+            *reinterpret_cast<uint4*>(Qs + row * kPadRow + ch * 16) = qreg[i];
+            *reinterpret_cast<uint4*>(Ds + row * kPadRow + ch * 16) = dreg[i];
         }
+        Ls[tid] = sreg;                                    // Ls[0..127] then Dl[0..127] are contiguous
     };
     stage_load(0);
     stage_write();
     __syncthreads();
-    const unsigned qs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Qs;
-    const unsigned ds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Ds;
+    const int qq = fr >> 2, pp = fr & 3;
+    const unsigned tr_off = (32 * wave + 4 * g + qq) * kPadRow + 8 * pp;
+    const unsigned qs_tr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Qs + tr_off;
+    const unsigned ds_tr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Ds + tr_off;
     for (int it = 0; it < niter; ++it) {
-        if (it + 1 < niter) stage_load(it + 1);
-        const int hq = hk * group + it / nqt, qb = qt0 + (it % nqt) * kFaBM;
+        const int qb = qt0 + (it % nqt) * kFaBM;
         const int qw = qb + 32 * wave;                       // this wave's 32 queries
+        // lse (x log2 e) and delta of this wave's accumulator rows 16 m + 4 g + r, staged in LDS with the tile
+        float4_t lr[2], dr[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            lr[m] = *reinterpret_cast<const float4_t*>(Ls + 32 * wave + 16 * m + 4 * g);
+            dr[m] = *reinterpret_cast<const float4_t*>(Dl + 32 * wave + 16 * m + 4 * g);
+        }
+        if (it + 1 < niter) stage_load(it + 1);
         const bool active = (qw + 31 >= k0) && (qw < len);
         if (active) {
+            // transposed fragments of this wave's 32 query rows: issued now, consumed after the softmax arithmetic
+            u32x2 d0, d1, d2, d3, d4, d5, d6, d7, e0, e1, e2, e3, e4, e5, e6, e7;
+            RPO_TR8(d0, d1, d2, d3, d4, d5, d6, d7, ds_tr);
             float4_t s[2][2], dp[2][2];                       // [query tile m][key tile n]; rows = queries 4g + r
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -541,8 +588,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dkdv_kernel(
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
-                    const int row = 32 * wave + 16 * m + fr;
-                    const int off = row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4);
+                    const int off = (32 * wave + 16 * m + fr) * kPadRow + (ks * 4 + g) * 16;
                     const short8_t aq = *reinterpret_cast<const short8_t*>(Qs + off);
                     const short8_t ad = *reinterpret_cast<const short8_t*>(Ds + off);
 #pragma unroll
@@ -552,27 +598,20 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dkdv_kernel(
                     }
                 }
             }
-            // rows of the accumulators are queries qw + 16 m + 4 g + r: per-row lse / delta
+            RPO_TR8(e0, e1, e2, e3, e4, e5, e6, e7, qs_tr);   // Q^T: lands under the exp / mask arithmetic below
             const bool need_mask = (qw < k0 + 31) || (qw + 32 > len) || (k0 + 32 > len);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 const int qr0 = qw + 16 * m + 4 * g;
-                float lr[4], dr[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const bool ok = qr0 + r < len;
-                    lr[r] = ok ? lse[(int64_t)hq * T + t0 + qr0 + r] * 1.4426950408889634f : 0.f;
-                    dr[r] = ok ? delta[(int64_t)hq * T + t0 + qr0 + r] : 0.f;
-                }
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const int key = k0 + 16 * n + fr;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -lr[r]));
+                        float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -lr[m][r]));
                         if (need_mask && (key > qr0 + r || key >= len || qr0 + r >= len)) pv = 0.f;
-                        s[m][n][r] = pv;                                   // P
-                        dp[m][n][r] = pv * (dp[m][n][r] - dr[r]) * scale;   // dS
+                        s[m][n][r] = pv;                                       // P
+                        dp[m][n][r] = pv * (dp[m][n][r] - dr[m][r]) * scale;    // dS
                     }
                 }
             }
@@ -582,19 +621,22 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dkdv_kernel(
                 pf[n] = pack_frag(s[0][n], s[1][n]);      // k-slots = queries {4g + j, 16 + 4g + (j - 4)} of the wave's 32
                 dsf[n] = pack_frag(dp[0][n], dp[1][n]);
             }
-            short8_t at[4];
-            lds_tr_frags(ds_base, 32 * wave, g, fr, at);   // dO^T: rows = hd, k = queries in the same order
+            // the transposed reads must have landed before their first consumer; naming every destination keeps
+            // hipcc from scheduling a consumer above this wait
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(e0),
+                           "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
+                         :
+                         : "memory");
+            const short8_t atd[4] = {join_tr(d0, d1), join_tr(d2, d3), join_tr(d4, d5), join_tr(d6, d7)};
+            const short8_t atq[4] = {join_tr(e0, e1), join_tr(e2, e3), join_tr(e4, e5), join_tr(e6, e7)};
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    dva[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[c], pf[n], dva[c][n], 0, 0, 0);
-            lds_tr_frags(qs_base, 32 * wave, g, fr, at);   // Q^T
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    dka[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(at[c], dsf[n], dka[c][n], 0, 0, 0);
+                for (int n = 0; n < 2; ++n) {
+                    dva[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atd[c], pf[n], dva[c][n], 0, 0, 0);
+                    dka[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atq[c], dsf[n], dka[c][n], 0, 0, 0);
+                }
         }
         __syncthreads();
         if (it + 1 < niter) {
@@ -611,7 +653,6 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dkdv_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) red[(wave * 8 + c * 2 + n) * 64 + lane] = pass == 0 ? dka[c][n] : dva[c][n];
         __syncthreads();
-        // wave w finishes tiles 2w, 2w+1 (c = w, n = 0 / 1)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int tile = wave * 2 + n;
@@ -683,9 +724,10 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
                total_tokens, (bf16_t*)dq, dq_stride);
     rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
-    RPO_LAUNCH(fa_bwd_dkdv_kernel, dim3((unsigned)n_k_tiles, (unsigned)num_kv_heads), dim3(kFaThreads), 0, st,
-               (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
-               dout_stride, cu_seqlens, k_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse, delta,
-               total_tokens, (bf16_t*)dk, (bf16_t*)dv, dk_stride, dv_stride);
+    const unsigned dkdv_grid = (unsigned)(((n_k_tiles + 7) / 8) * 8);
+    RPO_LAUNCH(fa_bwd_dkdv_kernel, dim3(dkdv_grid), dim3(kFaThreads), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+               (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
+               (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse, delta, total_tokens, (bf16_t*)dk,
+               (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles);
     return rpo_launch_status();
 }

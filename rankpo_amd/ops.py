@@ -455,11 +455,16 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
     return out, lse
 
 
-def attn_key_tile_table(lens, device, block_n: int = 32):
-    """int32 [n, 2] = (sequence id, first key of a 32-key tile), earliest keys first (they see the most queries)."""
-    tiles = [(s, k0) for s, n in enumerate(lens) for k0 in range(0, n, block_n)]
-    tiles.sort(key=lambda t: t[1])
-    return torch.tensor(tiles, dtype=torch.int32).to(device, non_blocking=True)
+def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 32):
+    """int32 [n, 3] = (sequence id, kv head, first key of a 32-key tile), sorted by (sequence, head, key): key tiles of one
+    (sequence, kv head) read the same Q / dO rows and are placed on one XCD by the kernel's block -> entry map."""
+    import numpy as np
+    parts = []
+    for s, n in enumerate(lens):
+        k0 = np.arange(0, n, block_n, dtype=np.int32)
+        for h in range(num_kv_heads):
+            parts.append(np.stack([np.full_like(k0, s), np.full_like(k0, h), k0], 1))
+    return torch.from_numpy(np.concatenate(parts, 0)).to(device, non_blocking=True)
 
 
 def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale):

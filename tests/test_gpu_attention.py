@@ -65,7 +65,7 @@ def test_flash_attn_fwd_matches_reference(lens, nh, nkv, fused):
         assert (a.float() - b).abs().max() < 0.03 * max(1.0, b.abs().max().item())
     # hand-written backward (delta + dQ + dK/dV kernels), on the strided views as well
     qb, kb, vb = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
-    ob = ops.flash_attn_varlen(qb, kb, vb, cu, tiles, max(lens), scale, k_tiles=ops.attn_key_tile_table(lens, DEV))
+    ob = ops.flash_attn_varlen(qb, kb, vb, cu, tiles, max(lens), scale, k_tiles=ops.attn_key_tile_table(lens, DEV, nkv))
     ob.backward(go)
     for name, a, b in (("dq", qb.grad, qr.grad), ("dk", kb.grad, kr.grad), ("dv", vb.grad, vr.grad)):
         err = (a.float() - b).abs().max().item()
@@ -107,7 +107,7 @@ def test_flash_attn_fwd_speed_report():
     # backward: HIP (delta + dQ + dK/dV) vs PyTorch's op
     out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale)
     go = torch.randn_like(out)
-    kt = ops.attn_key_tile_table(lens, DEV)
+    kt = ops.attn_key_tile_table(lens, DEV, nkv)
     ours_b = bench(lambda: ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, scale), 5)
     r = torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False)
     theirs_b = bench(lambda: torch.ops.aten._flash_attention_backward(go, q, k, v, r[0], r[1], cu, cu, max(lens), max(lens), 0.0, True, r[2], r[3]), 5)
