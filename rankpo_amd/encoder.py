@@ -161,15 +161,16 @@ class RopeTables:
 class VarlenCtx:
     """cu_seqlens (int32, device), the host copy of the lengths and the longest length of a packed batch."""
 
-    def __init__(self, cu, lens, max_len, tiles=None):
-        self.cu, self.lens, self.max_len, self.tiles = cu, lens, max_len, tiles
+    def __init__(self, cu, lens, max_len, tiles=None, k_tiles=None):
+        self.cu, self.lens, self.max_len, self.tiles, self.k_tiles = cu, lens, max_len, tiles, k_tiles
 
 
 def _varlen_causal_attention(q, k, v, ctx: VarlenCtx):
     """q [T, nh, hd], k/v [T, nkv, hd] packed; causal attention inside each sequence."""
     if q.is_cuda and q.dtype == torch.bfloat16 and q.shape[-1] == 64 and ctx.tiles is not None:
         # hand-written HIP kernel (head_dim 64): 2.2x the AOTriton varlen forward on the cfg-2 passage shape
-        return _ops.flash_attn_varlen(q, k, v, ctx.cu, ctx.tiles, ctx.max_len, 1.0 / math.sqrt(q.shape[-1]))
+        return _ops.flash_attn_varlen(q, k, v, ctx.cu, ctx.tiles, ctx.max_len, 1.0 / math.sqrt(q.shape[-1]),
+                                      k_tiles=ctx.k_tiles)
     if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16):
         return torch.ops.aten._flash_attention_forward(q, k, v, ctx.cu, ctx.cu, ctx.max_len, ctx.max_len, 0.0, True,
                                                        False)[0]
@@ -414,8 +415,12 @@ class LlamaEncoder(nn.Module):
         rope = self._rope(flat % L)                                                        # per-token angles [T, hd/2]
         cu = torch.zeros(N + 1, dtype=torch.int32, device=x.device)
         cu[1:] = lens_d.cumsum(0).to(torch.int32)
-        tiles = _ops.attn_tile_table(lens, x.device) if (x.is_cuda and self.config.head_dim == 64) else None
-        ctx = VarlenCtx(cu, lens, max(lens), tiles)
+        tiles = k_tiles = None
+        if x.is_cuda and self.config.head_dim == 64 and x.dtype == torch.bfloat16:     # hand-written flash attention
+            tiles = _ops.attn_tile_table(lens, x.device)
+            if torch.is_grad_enabled():
+                k_tiles = _ops.attn_key_tile_table(lens, x.device, self.config.num_key_value_heads)
+        ctx = VarlenCtx(cu, lens, max(lens), tiles, k_tiles)
         last_idx = (cu[1:] - 1).to(torch.int64)
         x, delta = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1)
         li = len(self.layers) - 1
