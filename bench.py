@@ -53,6 +53,16 @@ def _es(dt):
     return 2 if dt == 1 else 4
 
 
+_ATTN_PAIRS = {}    # packed token count -> sum over sequences of len (len + 1) / 2, registered by register_attn_batch()
+
+
+def register_attn_batch(attention_mask):
+    """Flash attention's algorithmic flops depend on the sequence lengths, which its C arguments only hold on the device:
+    the bench registers every synthetic batch here, keyed by its packed token count."""
+    lens = attention_mask.sum(1).to(torch.int64).cpu()
+    _ATTN_PAIRS[int(lens.sum())] = int((lens * (lens + 1) // 2).sum())
+
+
 def _algo(name, a):
     """(algorithmic bytes, flops) of one call, from its C arguments (SURVEY.md §8d figures)."""
     if name == "rpo_infonce_fwd":
@@ -94,6 +104,14 @@ def _algo(name, a):
     if name == "rpo_add_rmsnorm_bwd":
         rows, d, dt = a[7], a[8], a[9]
         return rows * d * _es(dt) * (4 if a[4] is not None else 3) + rows * 4, 8 * rows * d
+    if name == "rpo_flash_attn_fwd":
+        T, nh, nkv, hd = a[9], a[10], a[11], a[12]
+        pairs = _ATTN_PAIRS.get(T, 0)                     # causal (query, key) pairs of this packed batch
+        return 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh, 4 * hd * pairs * nh
+    if name == "rpo_flash_attn_bwd":
+        T, nh, nkv, hd = a[15], a[16], a[17], a[18]
+        pairs = _ATTN_PAIRS.get(T, 0)
+        return 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, 10 * hd * pairs * nh
     if name == "rpo_rankpo_fwd":
         B, d, dt = a[4], a[5], a[6]
         return 3 * B * d * _es(dt), 4 * B * d
@@ -142,9 +160,13 @@ class TimedLib:
         for name, d in agg.items():
             avg_us = 1e3 * d["ms"] / d["calls"]
             gbs = d["bytes"] / d["calls"] / (avg_us * 1e-6) / 1e9
+            tfs = d["flops"] / d["calls"] / (avg_us * 1e-6) / 1e12
+            # the roofline that bounds the entry point: MFMA when its flops / byte exceed the machine balance
+            bound = "mfma" if d["flops"] * HBM_PEAK_GBS * 1e9 > d["bytes"] * MFMA_BF16_PEAK_TFLOPS * 1e12 else "hbm"
             out.append(dict(entry=name, calls=d["calls"], avg_us=round(avg_us, 2), total_ms=round(d["ms"], 3),
-                            algo_bytes=d["bytes"] // d["calls"], algo_flops=d["flops"] // d["calls"],
-                            achieved_GBs=round(gbs, 2), frac_hbm=round(gbs / HBM_PEAK_GBS, 5)))
+                            algo_bytes=d["bytes"] // d["calls"], algo_flops=d["flops"] // d["calls"], bound=bound,
+                            achieved_GBs=round(gbs, 2), frac_hbm=round(gbs / HBM_PEAK_GBS, 5),
+                            achieved_TFLOPs=round(tfs, 2), frac_mfma=round(tfs / MFMA_BF16_PEAK_TFLOPS, 5)))
         out.sort(key=lambda r: -r["total_ms"])
         return out
 
@@ -176,6 +198,7 @@ def synth_batch(cfg, B, K, Lq, Lp, seed, device):
         lens[0] = L
         m = (torch.arange(L)[None, :] < lens[:, None]).long()
         ids = ids * m + pad * (1 - m)
+        register_attn_batch(m)
         return {"input_ids": ids.to(device), "attention_mask": m.to(device)}
     return {"query": side(B, Lq), "passage": side(B * (1 + K), Lp)}
 
@@ -432,9 +455,15 @@ def main():
                             % pmc[key]["traffic_over_algorithmic"])
             except Exception:
                 pass
-            out["roofline"] = {"kernel": top["entry"], "bound": "hbm", "achieved": top["achieved_GBs"],
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": traffic,
-                               "traffic_source": tsrc, "avg_us": top["avg_us"], "algo_bytes": top["algo_bytes"]}
+            if top["bound"] == "mfma":
+                out["roofline"] = {"kernel": top["entry"], "bound": "mfma", "achieved": top["achieved_TFLOPs"],
+                                   "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_mfma"], "traffic": None,
+                                   "avg_us": top["avg_us"], "algo_flops": top["algo_flops"],
+                                   "algo_bytes": top["algo_bytes"]}
+            else:
+                out["roofline"] = {"kernel": top["entry"], "bound": "hbm", "achieved": top["achieved_GBs"],
+                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": traffic,
+                                   "traffic_source": tsrc, "avg_us": top["avg_us"], "algo_bytes": top["algo_bytes"]}
             out["kernels"] = kernels
         if world == 1 and not args.no_sweep:
             out["roofline_sweep"] = sweep(timed, device)

@@ -455,8 +455,8 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
     return out, lse
 
 
-def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 32):
-    """int32 [n, 3] = (sequence id, kv head, first key of a 32-key tile), sorted by (sequence, head, key): key tiles of one
+def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 64):
+    """int32 [n, 3] = (sequence id, kv head, first key of a 64-key tile), sorted by (sequence, head, key): key tiles of one
     (sequence, kv head) read the same Q / dO rows and are placed on one XCD by the kernel's block -> entry map."""
     import numpy as np
     parts = []
