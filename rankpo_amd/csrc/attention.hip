@@ -20,11 +20,6 @@ constexpr int kFaThreads = 256, kFaBM = 128, kFaBN = 64, kFaHD = 64;
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
-__device__ __forceinline__ u32x2 lds_tr_read(unsigned addr) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
 
 // two f32 -> one dword of two bf16 (round to nearest even) in ONE instruction; written as `f32_to_bf16(a) | f32_to_bf16(b) << 16`
 // hipcc converts each value on its own and merges them with a third instruction.
@@ -34,16 +29,41 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
     return r;
 }
 
+// two accumulator tiles (rows 4g + r of each) -> one 8 x bf16 operand fragment: k-slots {4g + j, 16 + 4g + (j - 4)}
+__device__ __forceinline__ short8_t pack_frag(const float4_t& lo, const float4_t& hi) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 w = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
+    return __builtin_bit_cast(short8_t, w);
+}
+
+// K / V tiles (64 keys x 128 B each) go global -> LDS by 16-byte global_load_lds into a ring of three (K | V) images
+// (chunk ^= row & 7 on the source side: conflict-free for the ds_read_b128 row reads of K and for the transposed
+// ds_read_b64_tr_b16 reads of V): tile kt + 2 is issued while tile kt is consumed, ONE raw barrier per tile, counted
+// vmcnt.  Keys past the end of the sequence are clamped to its last row (their scores are masked).
+constexpr int kKvTile = 2 * kFaBN * 128;                          // 16 KiB
+
+#define RPO_TR4(OUT0, OUT1, OUT2, OUT3, ADDR, OFF0, OFF1, OFF2, OFF3)                                               \
+    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:" #OFF0 "\n\tds_read_b64_tr_b16 %1, %4 offset:" #OFF1 "\n\t"      \
+                 "ds_read_b64_tr_b16 %2, %4 offset:" #OFF2 "\n\tds_read_b64_tr_b16 %3, %4 offset:" #OFF3             \
+                 : "=&v"(OUT0), "=&v"(OUT1), "=&v"(OUT2), "=&v"(OUT3)                                                \
+                 : "v"(ADDR)                                                                                         \
+                 : "memory")
+
+__device__ __forceinline__ short8_t join_tr(const u32x2& lo, const u32x2& hi) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    const u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
+    return __builtin_bit_cast(short8_t, w);
+}
+
 // tiles: int32 [ntiles][2] = (sequence id, first query row inside the sequence), heaviest tiles first.
 __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
     int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int nh, int nkv, float scale_log2e,
     float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
     int64_t lse_head_stride, int lse_packed) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * kFaBN * 128];   // K tile | V tile, 128-byte rows
-    char* Ks = smem;
-    char* Vs = smem + kFaBN * 128;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) char smem[3 * kKvTile];       // ring of (K tile | V tile), 128-byte rows
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, fr = lane & 15;
     const int seq = tiles[2 * blockIdx.x], q0 = tiles[2 * blockIdx.x + 1];
     const int h = blockIdx.y, hk = h / (nh / nkv);
@@ -62,6 +82,35 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
             else bq[n][ks] = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
     }
+    const int last_q = min(q0 + kFaBM - 1, len - 1);
+    const int nkt = last_q / kFaBN + 1;                  // key tiles 0 .. nkt-1 (causal)
+    // staging: DMA instruction u = 2 * wave + i (i = 0, 1) fills tile rows 8u .. 8u + 7 of K and of V; lane l carries
+    // row 8u + (l >> 3), physical chunk l & 7 = logical chunk (l & 7) ^ (row & 7)
+    const int srow = lane >> 3, lchunk = (lane & 7) ^ srow;
+    const char* ksrc = reinterpret_cast<const char*>(k + t0 * sk + hk * kFaHD);
+    const char* vsrc = reinterpret_cast<const char*>(v + t0 * sv + hk * kFaHD);
+    const unsigned skb = (unsigned)sk * 2u, svb = (unsigned)sv * 2u;
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * kKvTile;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = 2 * wave + i;
+            const unsigned row = (unsigned)min(kt * kFaBN + 8 * u + srow, len - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + (row * skb + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + (row * svb + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + kFaBN * 128 + u * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+    // the Q fragments are ordinary loads issued BEFORE the DMAs: touching them here puts hipcc's wait for them in front
+    // of the loop (inside it, it would be a vmcnt(0) that makes every tile's DMA synchronous)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(bq[n][ks]));
+
     float4_t oacc[4][2];                                 // O^T: [hd tile c][query tile n], rows = hd 16c + 4g + r
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -69,43 +118,39 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
         for (int n = 0; n < 2; ++n) oacc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
     float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
 
-    const int last_q = min(q0 + kFaBM - 1, len - 1);
-    const int nkt = last_q / kFaBN + 1;                  // key tiles 0 .. nkt-1 (causal)
-    // staging: thread t moves chunks t and t + 256 of K and of V (64 rows x 8 chunks of 16 bytes each)
-    uint4 kreg[2], vreg[2];
-    auto stage_load = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            const int key = kt * kFaBN + row;
-            if (key < len) {
-                kreg[i] = *reinterpret_cast<const uint4*>(k + (t0 + key) * sk + hk * kFaHD + ch * 8);
-                vreg[i] = *reinterpret_cast<const uint4*>(v + (t0 + key) * sv + hk * kFaHD + ch * 8);
-            } else {
-                kreg[i] = make_uint4(0, 0, 0, 0);
-                vreg[i] = make_uint4(0, 0, 0, 0);
-            }
-        }
-    };
-    auto stage_write = [&]() {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, row = id >> 3, ch = id & 7;
-            *reinterpret_cast<uint4*>(Ks + row * 128 + ((ch ^ (row & 7)) << 4)) = kreg[i];
-            *reinterpret_cast<uint4*>(Vs + row * 128 + ((ch ^ (((row >> 1) & 3) << 1)) << 4)) = vreg[i];
-        }
-    };
-    stage_load(0);
-    stage_write();
-    __syncthreads();
-    const unsigned vs_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)Vs;
+    // per-lane offsets inside an image.  K row reads: row 16 m + fr, chunk (4 ks + g) ^ (fr & 7).  V transposed reads:
+    // lane (g, qq, pp) addresses row 32 sI + 16 h + 4 g + qq, hd columns 16 c + 4 pp .. + 3 = chunk (2 c) ^ x with
+    // x = (pp >> 1) ^ (4 (g & 1) + qq); h and sI are immediate offsets (2048, 4096).
     const int qq = fr >> 2, pp = fr & 3;                 // tr-read address roles inside a 16-lane group
+    const int xs = (pp >> 1) ^ (4 * (g & 1) + qq);
+    unsigned tr_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tr_off[c] = kFaBN * 128 + (4 * g + qq) * 128 + (((2 * c) ^ xs) << 4) + 8 * (pp & 1);
+    unsigned row_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) row_off[ks] = fr * 128 + (((4 * ks + g) ^ (fr & 7)) << 4);
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
+    int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) stage_load(kt + 1);
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile kt landed; tile kt + 1 may fly
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) stage(kt + 2, cur == 0 ? 2 : cur - 1);               // the buffer read in iteration kt - 1
         // this wave's queries may all lie before this key tile (upper waves of the last tiles): nothing to do
         const bool active = (kt * kFaBN <= qw + 31) && (qw < len);
         if (active) {
+            const char* Ks = smem + cur * kKvTile;
+            const unsigned tb = smem_base + cur * kKvTile;
+            // V^T fragments (A operands of O^T += V^T P^T): issued now, consumed after the softmax arithmetic
+            u32x2 x0, x1, x2, x3, x4, x5, x6, x7, y0, y1, y2, y3, y4, y5, y6, y7;
+            {
+                const unsigned a0 = tb + tr_off[0], a1 = tb + tr_off[1], a2 = tb + tr_off[2], a3 = tb + tr_off[3];
+                RPO_TR4(x0, x1, y0, y1, a0, 0, 2048, 4096, 6144);
+                RPO_TR4(x2, x3, y2, y3, a1, 0, 2048, 4096, 6144);
+                RPO_TR4(x4, x5, y4, y5, a2, 0, 2048, 4096, 6144);
+                RPO_TR4(x6, x7, y6, y7, a3, 0, 2048, 4096, 6144);
+            }
             // ---- S^T = K Q^T
             float4_t s[4][2];
 #pragma unroll
@@ -116,8 +161,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    const int row = 16 * m + fr;
-                    const short8_t a = *reinterpret_cast<const short8_t*>(Ks + row * 128 + (((ks * 4 + g) ^ (row & 7)) << 4));
+                    const short8_t a = *reinterpret_cast<const short8_t*>(Ks + row_off[ks] + m * 2048);
 #pragma unroll
                     for (int n = 0; n < 2; ++n) s[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[n][ks], s[m][n], 0, 0, 0);
                 }
@@ -139,89 +183,70 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                 }
             }
             // ---- online softmax (per query = per lane column), P^T fragments
+            float mnew[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float mx[4];
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    mx[m] = fmaxf(fmaxf(s[m][n][0], s[m][n][1]), fmaxf(s[m][n][2], s[m][n][3]));
+                float mm = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
+                mm = fmaxf(mm, __shfl_xor(mm, 16, 64));
+                mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
+                mnew[n] = fmaxf(mrun[n], mm);
+            }
+            // the running maximum rarely moves after the first tiles: skip the rescale of O (32 multiplies) when no lane's did
+            if (__builtin_amdgcn_ballot_w64(mnew[0] != mrun[0] || mnew[1] != mrun[1]) != 0) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const float alpha = __builtin_amdgcn_exp2f((mrun[n] - mnew[n]) * scale_log2e);
+                    lrun[n] *= alpha;
+                    mrun[n] = mnew[n];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) oacc[c][n] *= alpha;
+                }
+            }
             short8_t pfrag[2][2];                        // [k-step s (32 keys)][query tile n]
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float mx = s[0][n][0];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[m][n][r]);
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-                const float mnew = fmaxf(mrun[n], mx);
-                const float alpha = __builtin_amdgcn_exp2f((mrun[n] - mnew) * scale_log2e);
-                const float mls = mnew * scale_log2e;
-                float sum = 0.f;
+                const float mls = mnew[n] * scale_log2e;
+                float sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -mls));
                         s[m][n][r] = pv;
-                        sum += pv;
+                        sum[r] += pv;
                     }
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
-                lrun[n] = lrun[n] * alpha + sum;
-                mrun[n] = mnew;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) oacc[c][n] *= alpha;
-#pragma unroll
-                for (int sI = 0; sI < 2; ++sI) {
-                    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-                    u32x4 w;
-                    w[0] = pack_bf16(s[2 * sI][n][0], s[2 * sI][n][1]);
-                    w[1] = pack_bf16(s[2 * sI][n][2], s[2 * sI][n][3]);
-                    w[2] = pack_bf16(s[2 * sI + 1][n][0], s[2 * sI + 1][n][1]);
-                    w[3] = pack_bf16(s[2 * sI + 1][n][2], s[2 * sI + 1][n][3]);
-                    pfrag[sI][n] = __builtin_bit_cast(short8_t, w);
-                }
+                float st = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+                st += __shfl_xor(st, 16, 64);
+                st += __shfl_xor(st, 32, 64);
+                lrun[n] += st;
+                pfrag[0][n] = pack_frag(s[0][n], s[1][n]);
+                pfrag[1][n] = pack_frag(s[2][n], s[3][n]);
             }
-            // ---- O^T += V^T P^T   (A = V^T via transposed LDS reads, same key order as the P fragments).
-            // The 8 transposed reads of a 32-key step and their wait are ONE asm statement: hipcc does not model
-            // inline-asm LDS reads, so the MFMAs that consume them must not be schedulable above the wait.
+            // ---- O^T += V^T P^T   (A = V^T via the transposed LDS reads, same key order as the P fragments).
+            // hipcc does not model inline-asm LDS reads: naming every destination in the wait keeps the MFMAs below it.
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(y0),
+                           "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7)
+                         :
+                         : "memory");
+            const short8_t vt0[4] = {join_tr(x0, x1), join_tr(x2, x3), join_tr(x4, x5), join_tr(x6, x7)};
+            const short8_t vt1[4] = {join_tr(y0, y1), join_tr(y2, y3), join_tr(y4, y5), join_tr(y6, y7)};
 #pragma unroll
-            for (int sI = 0; sI < 2; ++sI) {
-                unsigned ad[8];
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int r0 = 32 * sI + 4 * g + qq, r1 = r0 + 16;
-                    const int lc = 2 * c + (pp >> 1);
-                    ad[2 * c] = vs_base + r0 * 128 + ((lc ^ (((r0 >> 1) & 3) << 1)) << 4) + 8 * (pp & 1);
-                    ad[2 * c + 1] = vs_base + r1 * 128 + ((lc ^ (((r1 >> 1) & 3) << 1)) << 4) + 8 * (pp & 1);
-                }
-                u32x2 t0v, t1v, t2v, t3v, t4v, t5v, t6v, t7v;
-                asm volatile(
-                    "ds_read_b64_tr_b16 %0, %8\n\t"
-                    "ds_read_b64_tr_b16 %1, %9\n\t"
-                    "ds_read_b64_tr_b16 %2, %10\n\t"
-                    "ds_read_b64_tr_b16 %3, %11\n\t"
-                    "ds_read_b64_tr_b16 %4, %12\n\t"
-                    "ds_read_b64_tr_b16 %5, %13\n\t"
-                    "ds_read_b64_tr_b16 %6, %14\n\t"
-                    "ds_read_b64_tr_b16 %7, %15\n\t"
-                    "s_waitcnt lgkmcnt(0)"
-                    : "=&v"(t0v), "=&v"(t1v), "=&v"(t2v), "=&v"(t3v), "=&v"(t4v), "=&v"(t5v), "=&v"(t6v), "=&v"(t7v)
-                    : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
-                    : "memory");
-                typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-                const u32x4 w0 = {t0v[0], t0v[1], t1v[0], t1v[1]}, w1 = {t2v[0], t2v[1], t3v[0], t3v[1]};
-                const u32x4 w2 = {t4v[0], t4v[1], t5v[0], t5v[1]}, w3 = {t6v[0], t6v[1], t7v[0], t7v[1]};
-                const short8_t av[4] = {__builtin_bit_cast(short8_t, w0), __builtin_bit_cast(short8_t, w1),
-                                        __builtin_bit_cast(short8_t, w2), __builtin_bit_cast(short8_t, w3)};
+                for (int n = 0; n < 2; ++n)
+                    oacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt0[c], pfrag[0][n], oacc[c][n], 0, 0, 0);
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int n = 0; n < 2; ++n)
-                        oacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[c], pfrag[sI][n], oacc[c][n], 0, 0, 0);
-            }
+                for (int n = 0; n < 2; ++n)
+                    oacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt1[c], pfrag[1][n], oacc[c][n], 0, 0, 0);
         }
-        __syncthreads();
-        if (kt + 1 < nkt) {
-            stage_write();
-            __syncthreads();
-        }
+        cur = cur == 2 ? 0 : cur + 1;
     }
     // ---- epilogue: O[q][16c + 4g + r] = O^T / l ;  lse = scale m + ln l
 #pragma unroll
@@ -275,64 +300,10 @@ __global__ __launch_bounds__(256) void fa_delta_kernel(const bf16_t* __restrict_
     }
 }
 
-// 8 transposed reads of a 64-hd x 32-row block (rows r0 + {0..3} and r0 + 16 + {0..3} per lane group), returned as the
-// four A fragments (hd tiles c = 0..3); `base` = LDS byte address of the [rows][128 B] image, swizzle chunk ^= row & 7.
-__device__ __forceinline__ void lds_tr_frags(unsigned base, int rowbase, int g, int fr, short8_t (&av)[4]) {
-    const int qq = fr >> 2, pp = fr & 3;
-    unsigned ad[8];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int r0 = rowbase + 4 * g + qq, r1 = r0 + 16;
-        const int lc = 2 * c + (pp >> 1);
-        ad[2 * c] = base + r0 * 128 + ((lc ^ (r0 & 7)) << 4) + 8 * (pp & 1);
-        ad[2 * c + 1] = base + r1 * 128 + ((lc ^ (r1 & 7)) << 4) + 8 * (pp & 1);
-    }
-    u32x2 t0v, t1v, t2v, t3v, t4v, t5v, t6v, t7v;
-    asm volatile(
-        "ds_read_b64_tr_b16 %0, %8\n\t"
-        "ds_read_b64_tr_b16 %1, %9\n\t"
-        "ds_read_b64_tr_b16 %2, %10\n\t"
-        "ds_read_b64_tr_b16 %3, %11\n\t"
-        "ds_read_b64_tr_b16 %4, %12\n\t"
-        "ds_read_b64_tr_b16 %5, %13\n\t"
-        "ds_read_b64_tr_b16 %6, %14\n\t"
-        "ds_read_b64_tr_b16 %7, %15\n\t"
-        "s_waitcnt lgkmcnt(0)"
-        : "=&v"(t0v), "=&v"(t1v), "=&v"(t2v), "=&v"(t3v), "=&v"(t4v), "=&v"(t5v), "=&v"(t6v), "=&v"(t7v)
-        : "v"(ad[0]), "v"(ad[1]), "v"(ad[2]), "v"(ad[3]), "v"(ad[4]), "v"(ad[5]), "v"(ad[6]), "v"(ad[7])
-        : "memory");
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const u32x4 w0 = {t0v[0], t0v[1], t1v[0], t1v[1]}, w1 = {t2v[0], t2v[1], t3v[0], t3v[1]};
-    const u32x4 w2 = {t4v[0], t4v[1], t5v[0], t5v[1]}, w3 = {t6v[0], t6v[1], t7v[0], t7v[1]};
-    av[0] = __builtin_bit_cast(short8_t, w0);
-    av[1] = __builtin_bit_cast(short8_t, w1);
-    av[2] = __builtin_bit_cast(short8_t, w2);
-    av[3] = __builtin_bit_cast(short8_t, w3);
-}
 
-__device__ __forceinline__ short8_t pack_frag(const float4_t& lo, const float4_t& hi) {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const u32x4 w = {pack_bf16(lo[0], lo[1]), pack_bf16(lo[2], lo[3]), pack_bf16(hi[0], hi[1]), pack_bf16(hi[2], hi[3])};
-    return __builtin_bit_cast(short8_t, w);
-}
 
-// K / V tiles (64 keys x 128 B each) go global -> LDS by 16-byte global_load_lds into a ring of three (K | V) images:
-// tile kt + 2 is issued while tile kt is consumed, ONE raw barrier per tile, counted vmcnt (as in the dK/dV kernel).
-// Keys past the end of the sequence are clamped to its last row (their P is masked to exactly 0).
-constexpr int kDqTile = 2 * kFaBN * 128;                          // 16 KiB
-
-#define RPO_TR4(OUT0, OUT1, OUT2, OUT3, ADDR, OFF0, OFF1, OFF2, OFF3)                                               \
-    asm volatile("ds_read_b64_tr_b16 %0, %4 offset:" #OFF0 "\n\tds_read_b64_tr_b16 %1, %4 offset:" #OFF1 "\n\t"      \
-                 "ds_read_b64_tr_b16 %2, %4 offset:" #OFF2 "\n\tds_read_b64_tr_b16 %3, %4 offset:" #OFF3             \
-                 : "=&v"(OUT0), "=&v"(OUT1), "=&v"(OUT2), "=&v"(OUT3)                                                \
-                 : "v"(ADDR)                                                                                         \
-                 : "memory")
-
-__device__ __forceinline__ short8_t join_tr(const u32x2& lo, const u32x2& hi) {
-    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-    const u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
-    return __builtin_bit_cast(short8_t, w);
-}
+// K / V tiles: the same LDS-DMA ring as the forward kernel.
+constexpr int kDqTile = kKvTile;
 
 __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
