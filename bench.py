@@ -93,8 +93,8 @@ def _algo(name, a):
         n = a[3] * a[4]
         return 3 * n * _es(a[7]), 5 * n
     if name == "rpo_swiglu_bwd":
-        n = a[5] * a[6]
-        return 5 * n * _es(a[10]), 12 * n
+        n = a[6] * a[7]
+        return (6 if a[5] is not None else 5) * n * _es(a[12]), 13 * n
     if name == "rpo_rope":
         rows, H, hd, dt = a[5], a[6], a[7], a[9]
         return 2 * rows * H * hd * _es(dt) + rows * hd * 4, 3 * rows * H * hd

@@ -167,7 +167,9 @@ int rpo_sumsq_partial(const void* x, int64_t n, int dtype, float* partial_out, i
  *     with row stride ld_gu elements (g and u may be the two halves of ONE fused gate|up projection output: u = g + cols,
  *     ld_gu = 2 cols); out: [rows, cols] with row stride ld_out.
  *   rpo_swiglu_bwd: dg = dout * u * silu'(g), du = dout * silu(g); dg / du with row stride ld_dgu (again possibly the
- *     two halves of one [rows, 2 cols] buffer).
+ *     two halves of one [rows, 2 cols] buffer).  prod_out (may be NULL): also writes silu(g) * u, row stride ld_prod --
+ *     the recomputed forward product that the weight gradient of the following projection needs; prod_out == dout is
+ *     allowed (every element of dout is read before it is overwritten), which makes the recompute free of extra traffic.
  *   rpo_rope: x_out = rot(x_in), both [rows, heads, head_dim] (row stride `row_stride` elements; x_in == x_out allowed), HF
  *     rotate_half convention: (x1, x2) -> (x1 cos - x2 sin, x2 cos + x1 sin) with x1 / x2 the low / high half of each
  *     head; cos_tab / sin_tab: f32 [period, head_dim / 2]; row r uses table row r % period.  backward != 0 applies
@@ -175,8 +177,9 @@ int rpo_sumsq_partial(const void* x, int64_t n, int dtype, float* partial_out, i
  * --------------------------------------------------------------------------------------------- */
 int rpo_swiglu_fwd(const void* g, const void* u, void* out, int64_t rows, int64_t cols, int64_t ld_gu, int64_t ld_out,
                    int dtype, rpo_stream_t stream);
-int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, void* dg, void* du, int64_t rows, int64_t cols,
-                   int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int dtype, rpo_stream_t stream);
+int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, void* dg, void* du, void* prod_out, int64_t rows,
+                   int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int64_t ld_prod, int dtype,
+                   rpo_stream_t stream);
 int rpo_rope(const void* x_in, void* x_out, int64_t row_stride, const float* cos_tab, const float* sin_tab,
              int64_t rows, int64_t heads, int64_t head_dim, int64_t period, int dtype, int backward,
              rpo_stream_t stream);

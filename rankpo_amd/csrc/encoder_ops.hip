@@ -36,14 +36,15 @@ __global__ __launch_bounds__(kEwThreads) void swiglu_fwd_kernel(const T* __restr
 
 template <typename T>
 __global__ __launch_bounds__(kEwThreads) void swiglu_bwd_kernel(const T* g, const T* u, const T* dout, T* dg, T* du,
-                                                                int64_t rows, int vec_per_row, int64_t ld_gu,
-                                                                int64_t ld_dout, int64_t ld_dgu) {   // outputs may alias inputs
+                                                                T* prod, int64_t rows, int vec_per_row, int64_t ld_gu,
+                                                                int64_t ld_dout, int64_t ld_dgu,
+                                                                int64_t ld_prod) {   // outputs may alias inputs
     constexpr int V = Elem<T>::kVec;
     const int64_t i = (int64_t)blockIdx.x * kEwThreads + threadIdx.x;
     const int64_t r = i / vec_per_row;
     if (r >= rows) return;
     const int c = (int)(i - r * vec_per_row) * V;
-    Vec16<T> a, b, d, og, ou;
+    Vec16<T> a, b, d, og, ou, op;
     a.load_nt(g + r * ld_gu + c);
     b.load_nt(u + r * ld_gu + c);
     d.load_nt(dout + r * ld_dout + c);
@@ -53,9 +54,11 @@ __global__ __launch_bounds__(kEwThreads) void swiglu_bwd_kernel(const T* g, cons
         const float silu = a.v[k] * s;
         og.v[k] = d.v[k] * b.v[k] * (s + silu * (1.0f - s));   // silu' = s (1 + g (1 - s))
         ou.v[k] = d.v[k] * silu;
+        op.v[k] = silu * b.v[k];                               // the forward product, same arithmetic as swiglu_fwd_kernel
     }
     og.store_nt(dg + r * ld_dgu + c);
     ou.store_nt(du + r * ld_dgu + c);
+    if (prod) op.store_nt(prod + r * ld_prod + c);
 }
 
 // x: [rows, H, hd] (row stride = row_stride elements, heads contiguous), cos/sin: f32 [period, hd/2];
@@ -118,25 +121,26 @@ extern "C" int rpo_swiglu_fwd(const void* g, const void* u, void* out, int64_t r
     return rpo_launch_status();
 }
 
-extern "C" int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, void* dg, void* du, int64_t rows,
-                              int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int dtype,
-                              rpo_stream_t stream) {
+extern "C" int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, void* dg, void* du, void* prod_out,
+                              int64_t rows, int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int64_t ld_prod,
+                              int dtype, rpo_stream_t stream) {
     if (!g || !u || !dout || !dg || !du || rows <= 0 || cols <= 0) return RPO_ERR_INVALID_ARG;
     const int V = dtype == RPO_DT_BF16 ? 8 : 4;
     if (cols % V != 0 || ld_gu % V != 0 || ld_dout % V != 0 || ld_dgu % V != 0 || !rpo_aligned16(g) ||
-        !rpo_aligned16(u) || !rpo_aligned16(dout) || !rpo_aligned16(dg) || !rpo_aligned16(du))
+        !rpo_aligned16(u) || !rpo_aligned16(dout) || !rpo_aligned16(dg) || !rpo_aligned16(du) ||
+        (prod_out && (ld_prod % V != 0 || !rpo_aligned16(prod_out))))
         return RPO_ERR_UNSUPPORTED;
     const int64_t nvec = rows * (cols / V);
     if (nvec / kEwThreads >= INT32_MAX) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == RPO_DT_BF16)
         RPO_LAUNCH(swiglu_bwd_kernel<bf16_t>, dim3(ew_grid(nvec)), dim3(kEwThreads), 0, st, (const bf16_t*)g,
-                   (const bf16_t*)u, (const bf16_t*)dout, (bf16_t*)dg, (bf16_t*)du, rows, (int)(cols / V), ld_gu, ld_dout,
-                   ld_dgu);
+                   (const bf16_t*)u, (const bf16_t*)dout, (bf16_t*)dg, (bf16_t*)du, (bf16_t*)prod_out, rows, (int)(cols / V),
+                   ld_gu, ld_dout, ld_dgu, ld_prod);
     else if (dtype == RPO_DT_F32)
         RPO_LAUNCH(swiglu_bwd_kernel<float>, dim3(ew_grid(nvec)), dim3(kEwThreads), 0, st, (const float*)g,
-                   (const float*)u, (const float*)dout, (float*)dg, (float*)du, rows, (int)(cols / V), ld_gu, ld_dout,
-                   ld_dgu);
+                   (const float*)u, (const float*)dout, (float*)dg, (float*)du, (float*)prod_out, rows, (int)(cols / V), ld_gu,
+                   ld_dout, ld_dgu, ld_prod);
     else
         return RPO_ERR_INVALID_ARG;
     return rpo_launch_status();

@@ -79,6 +79,17 @@ class FlatGradAllReducer:
         assert all(p.dtype == dtype and p.device == device for p in self.params), "one dtype/device per reducer"
         # backward produces gradients roughly in reverse registration order: lay the flat buffer out that way
         order = list(reversed(self.params))
+        # weights tagged as a fuse group (encoder.tag_fuse_group: q|k|v, gate|up) stay adjacent and in group order, so
+        # that their row-concatenation is a plain view of the flat buffer
+        i = 0
+        while i < len(order):
+            tag = getattr(order[i], "_rpo_fuse_group", None)
+            j = i + 1
+            if tag is not None:
+                while j < len(order) and getattr(order[j], "_rpo_fuse_group", (None,))[0] is tag[0]:
+                    j += 1
+                order[i:j] = sorted(order[i:j], key=lambda p: p._rpo_fuse_group[1])
+            i = j
         offs, n = [], 0
         for p in order:
             offs.append(n)

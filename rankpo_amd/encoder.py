@@ -200,6 +200,48 @@ def _varlen_last_query_attention(q, k, v, ctx: VarlenCtx):
     return torch.cat(outs, 0)
 
 
+
+def tag_fuse_group(*weights):
+    """Marks weights whose row-concatenation is used as ONE GEMM operand.  A flat-buffer optimizer
+    (distributed.FlatGradAllReducer / train_step.FlatAdamW) lays a tagged group out contiguously and in this order, which
+    turns `fused_weight` into a zero-copy view."""
+    key = object()
+    for i, w in enumerate(weights):
+        w._rpo_fuse_group = (key, i)
+
+
+class _FusedWeight(torch.autograd.Function):
+    """Row-concatenation of 2-D weights [n_i, k] -> [sum n_i, k].  When the weights already sit back to back in ONE
+    storage (they do once FlatAdamW has moved the parameters into its flat buffer) the result is a view of that storage:
+    no copy (torch.cat's copy kernel moved 80 MB per block at ~0.4 TB/s: 12 ms per cfg-2 step).  Backward hands every
+    weight its row slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        ctx.rows = [w.shape[0] for w in ws]
+        w0 = ws[0]
+        adjacent = all(w.is_contiguous() and w.dim() == 2 and w.shape[1] == w0.shape[1] and w.dtype == w0.dtype
+                       for w in ws)
+        if adjacent:
+            es = w0.element_size()
+            for a, b in zip(ws[:-1], ws[1:]):
+                if (a.untyped_storage().data_ptr() != b.untyped_storage().data_ptr()
+                        or a.data_ptr() + a.numel() * es != b.data_ptr()):
+                    adjacent = False
+                    break
+        if adjacent:
+            return w0.detach().as_strided((sum(ctx.rows), w0.shape[1]), (w0.shape[1], 1), w0.storage_offset())
+        return torch.cat([w.detach() for w in ws], 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.rows, 0))
+
+
+def fused_weight(ws):
+    return _FusedWeight.apply(*ws)
+
+
 class LlamaAttention(nn.Module):
     def __init__(self, cfg):
         super().__init__()
@@ -209,12 +251,13 @@ class LlamaAttention(nn.Module):
         self.k_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, bias=b)
         self.v_proj = nn.Linear(cfg.hidden_size, self.nkv * self.hd, bias=b)
         self.o_proj = nn.Linear(self.nh * self.hd, cfg.hidden_size, bias=b)
+        tag_fuse_group(self.q_proj.weight, self.k_proj.weight, self.v_proj.weight)
 
     def _fused(self, x, mods):
         """ONE projection GEMM for several Linear modules that read the same input (q|k|v, k|v): better GEMM shapes
         than the narrow k / v projections alone and ONE input-gradient GEMM instead of a GEMM + add per branch.  The
-        weights stay separate parameters (HF names); concatenating them costs ~13 MB of traffic per block."""
-        w = torch.cat([m.weight for m in mods], 0)
+        weights stay separate parameters (HF names); see `fused_weight`."""
+        w = fused_weight([m.weight for m in mods])
         b = torch.cat([m.bias for m in mods], 0) if mods[0].bias is not None else None
         return F.linear(x, w, b)
 
@@ -226,6 +269,13 @@ class LlamaAttention(nn.Module):
         if fused:       # one in-place HIP pass over the q and k heads instead of neg / cat / 2 mul / add per tensor
             qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd)
         q, k, v = qkv.split([nq, nk, nk], dim=-1)
+        if (isinstance(attn_mask, VarlenCtx) and fused and attn_mask.k_tiles is not None and self.hd == 64
+                and x.dtype == torch.bfloat16):
+            # training on packed tokens: attention reads q / k / v as column blocks of the projection output and its
+            # backward writes one d(q|k|v) buffer (no split / cat copies)
+            o = _ops.flash_attn_varlen_qkv(qkv.view(L, -1), self.nh, self.nkv, attn_mask.cu, attn_mask.tiles,
+                                           attn_mask.k_tiles, 1.0 / math.sqrt(self.hd))
+            return self.o_proj(o.reshape(1, L, self.nh * self.hd))
         if isinstance(attn_mask, VarlenCtx):
             # packed tokens [1, T, d]: variable-length causal flash attention, no pad tokens anywhere
             q, k, v = q.view(L, self.nh, self.hd), k.view(L, self.nkv, self.hd), v.view(L, self.nkv, self.hd)
@@ -255,12 +305,13 @@ class LlamaMLP(nn.Module):
         b = bool(getattr(cfg, "mlp_bias", False))
         self.gate_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=b)
         self.up_proj = nn.Linear(cfg.hidden_size, cfg.intermediate_size, bias=b)
+        tag_fuse_group(self.gate_proj.weight, self.up_proj.weight)
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=b)
 
     def forward(self, x):
         if self.down_proj.bias is None and self.gate_proj.bias is None and _ops.fused_encoder_ops_ok(x):
             # ONE gate|up projection GEMM; fused HIP silu*mul on its two halves, product not kept alive
-            gu = F.linear(x, torch.cat([self.gate_proj.weight, self.up_proj.weight], 0))
+            gu = F.linear(x, fused_weight([self.gate_proj.weight, self.up_proj.weight]))
             return _ops.swiglu_down(gu, self.down_proj.weight)
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 

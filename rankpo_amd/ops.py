@@ -294,17 +294,19 @@ class _SwiGLUDown(torch.autograd.Function):
         ff = gu.shape[-1] // 2
         rows = gu.numel() // (2 * ff)
         es = gu.element_size()
-        prod = _swiglu_fwd(lib, gu, torch.empty(gu.shape[:-1] + (ff,), dtype=gu.dtype, device=gu.device), rows, ff)
-        dW = None
-        if ctx.needs_input_grad[1]:
-            dW = dy.reshape(-1, dy.shape[-1]).t() @ prod.reshape(-1, ff)
-        del prod
+        # dprod first; ONE pass then reads g, u, dprod and writes dg, du AND the recomputed product over dprod (6 units of
+        # [T, ff] traffic instead of 3 + 5 for a separate recompute), which the weight gradient consumes afterwards
         dprod = dy @ weight                                   # [..., ff]
         dgu = torch.empty_like(gu)                            # [dg | du]: the gradient of the fused projection output
+        want_dw = ctx.needs_input_grad[1]
         with torch.cuda.device(gu.device):
             check(lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),
-                                     dgu.data_ptr() + ff * es, rows, ff, 2 * ff, ff, 2 * ff, _dt(gu), _stream(gu)),
-                  "rpo_swiglu_bwd")
+                                     dgu.data_ptr() + ff * es, dprod.data_ptr() if want_dw else None, rows, ff, 2 * ff,
+                                     ff, 2 * ff, ff, _dt(gu), _stream(gu)), "rpo_swiglu_bwd")
+        dW = None
+        if want_dw:
+            prod = dprod                                      # overwritten in place by the kernel
+            dW = dy.reshape(-1, dy.shape[-1]).t() @ prod.reshape(-1, ff)
         return dgu, dW
 
 
@@ -467,21 +469,29 @@ def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 64):
     return torch.from_numpy(np.concatenate(parts, 0)).to(device, non_blocking=True)
 
 
-def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale):
+def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale, grads=None):
+    """grads: optional preallocated (dq, dk, dv) [T, heads, 64] views with arbitrary token strides (e.g. the three column
+    blocks of ONE fused d(q|k|v) buffer)."""
     lib = _lib.load()
     T, nh, hd = q.shape
     nkv = k.shape[1]
     dout = dout.contiguous()
-    dq = torch.empty((T, nh, hd), dtype=q.dtype, device=q.device)
-    dk = torch.empty((T, nkv, hd), dtype=q.dtype, device=q.device)
-    dv = torch.empty((T, nkv, hd), dtype=q.dtype, device=q.device)
+    if grads is None:
+        dq = torch.empty((T, nh, hd), dtype=q.dtype, device=q.device)
+        dk = torch.empty((T, nkv, hd), dtype=q.dtype, device=q.device)
+        dv = torch.empty((T, nkv, hd), dtype=q.dtype, device=q.device)
+    else:
+        dq, dk, dv = grads
+        for t, h in ((dq, nh), (dk, nkv), (dv, nkv)):
+            if t.shape != (T, h, hd) or t.stride(2) != 1 or t.stride(1) != hd or t.dtype != q.dtype:
+                raise ValueError("flash_attn_varlen_bwd: gradient views must be [T, heads, 64] with contiguous heads")
     delta = torch.empty((nh, T), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         check(lib.rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0),
                                      cu_seqlens.data_ptr(), q_tiles.data_ptr(), q_tiles.shape[0], k_tiles.data_ptr(),
                                      k_tiles.shape[0], T, nh, nkv, hd, scale, lse.data_ptr(), delta.data_ptr(),
-                                     dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), nh * hd, nkv * hd, nkv * hd,
+                                     dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0), dk.stride(0), dv.stride(0),
                                      _stream(q)), "rpo_flash_attn_bwd")
     return dq, dk, dv
 
@@ -516,7 +526,46 @@ def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale, k_tiles=None):
     return _FlashAttnVarlen.apply(q, k, v, cu, tiles, k_tiles, max_len, scale)
 
 
+class _FlashAttnVarlenQKV(torch.autograd.Function):
+    """Same attention on the output of ONE fused q|k|v projection, [T, (nh + 2 nkv) * 64] (rotary already applied): the
+    kernels read q / k / v as strided column blocks and the backward writes dq / dk / dv straight into the column blocks
+    of one d(q|k|v) buffer, which is the operand of the projection's gradient GEMMs (no split / cat copies: the cat
+    moved 1.6 GB per block on the cfg-2 passage tower)."""
+
+    @staticmethod
+    def _views(x, nh, nkv):
+        T = x.shape[0]
+        nq, nk = nh * 64, nkv * 64
+        return (x[:, :nq].unflatten(1, (nh, 64)), x[:, nq:nq + nk].unflatten(1, (nkv, 64)),
+                x[:, nq + nk:].unflatten(1, (nkv, 64)))
+
+    @staticmethod
+    def forward(ctx, qkv, nh, nkv, cu, tiles, k_tiles, scale):
+        q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv)
+        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0, num_seqs=cu.numel() - 1)
+        ctx.save_for_backward(qkv, out, lse, cu, tiles, k_tiles)
+        ctx.meta = (nh, nkv, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        qkv, out, lse, cu, tiles, k_tiles = ctx.saved_tensors
+        nh, nkv, scale = ctx.meta
+        q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv)
+        dqkv = torch.empty_like(qkv)
+        flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale,
+                              grads=_FlashAttnVarlenQKV._views(dqkv, nh, nkv))
+        return dqkv, None, None, None, None, None, None
+
+
+def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale):
+    """qkv: [T, (num_heads + 2 num_kv_heads) * 64] bf16, contiguous rows -> out [T, num_heads, 64]."""
+    if qkv.dim() != 2 or qkv.shape[1] != (num_heads + 2 * num_kv_heads) * 64 or not qkv.is_contiguous():
+        raise ValueError("flash_attn_varlen_qkv: qkv must be a contiguous [T, (nh + 2 nkv) * 64] tensor")
+    return _FlashAttnVarlenQKV.apply(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale)
+
+
 __all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
-           "flash_attn_varlen", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
+           "flash_attn_varlen", "flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
            "attn_key_tile_table"]

@@ -116,3 +116,28 @@ def test_flash_attn_fwd_speed_report():
     d2 = torch.ops.aten._flash_attention_backward(go, q, k, v, r[0], r[1], cu, cu, max(lens), max(lens), 0.0, True, r[2], r[3])
     for x, y in zip(d1, d2):
         assert (x.float() - y.float()).abs().max() < 0.03 * max(1.0, y.float().abs().max().item())
+
+
+def test_flash_attn_qkv_fused_buffer_matches_split_views():
+    """flash_attn_varlen_qkv (reads q|k|v as column blocks of one projection output, writes ONE d(q|k|v) buffer) must give
+    bit-identical results to flash_attn_varlen on separate tensors: same kernels, different strides."""
+    from rankpo_amd import ops
+    torch.manual_seed(3)
+    nh, nkv, hd = 8, 2, 64
+    lens = [1, 63, 64, 65, 200, 129, 333]
+    T = sum(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    tiles = ops.attn_tile_table(lens, DEV)
+    kt = ops.attn_key_tile_table(lens, DEV, nkv)
+    qkv = torch.randn(T, (nh + 2 * nkv) * hd, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    out = ops.flash_attn_varlen_qkv(qkv, nh, nkv, cu, tiles, kt, 0.125)
+    go = torch.randn_like(out)
+    out.backward(go)
+    q, k, v = (t.detach().clone().contiguous().requires_grad_(True) for t in
+               (qkv[:, :nh * hd].view(T, nh, hd), qkv[:, nh * hd:(nh + nkv) * hd].view(T, nkv, hd),
+                qkv[:, (nh + nkv) * hd:].view(T, nkv, hd)))
+    ref = ops.flash_attn_varlen(q, k, v, cu, tiles, max(lens), 0.125, k_tiles=kt)
+    ref.backward(go)
+    assert torch.equal(out, ref)
+    dref = torch.cat([q.grad.reshape(T, -1), k.grad.reshape(T, -1), v.grad.reshape(T, -1)], 1)
+    assert torch.equal(qkv.grad, dref)

@@ -40,6 +40,10 @@ def test_swiglu_down_matches_torch(dtype):
     tol = 2e-5 if dtype == torch.float32 else 2.0 ** -6
     for a, b in ((y, y2), (g.grad, g2.grad), (u.grad, u2.grad), (W.grad, W2.grad)):
         assert (a.double() - b).abs().max() <= tol * max(1.0, b.abs().max().item())
+    # frozen down projection: the backward skips the product recompute (prod_out = NULL), same input gradient
+    gu3 = gu.detach().clone().requires_grad_(True)
+    ops.swiglu_down(gu3, W.detach()).backward(gy)
+    assert torch.equal(gu3.grad, gu.grad)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])

@@ -195,3 +195,41 @@ def test_compute_metrics_matches_reference(golden):
     assert list(m) == list(meta["metrics"])            # same keys, same order
     for k, v in meta["metrics"].items():
         assert (np.isnan(v) and np.isnan(m[k])) or abs(m[k] - v) < 1e-12, k      # AUC with one class is nan in both
+
+
+def test_fused_weight_is_a_view_of_the_flat_buffer():
+    """encoder.fused_weight: q|k|v and gate|up tagged groups are laid out back to back by FlatGradAllReducer, their
+    row-concatenation is then a zero-copy view, and the backward hands each weight its own rows."""
+    from rankpo_amd import encoder as E
+    from rankpo_amd.distributed import FlatGradAllReducer
+    torch.manual_seed(0)
+    cfg = E.llama_config(vocab_size=128, hidden_size=32, intermediate_size=64, num_hidden_layers=2,
+                         num_attention_heads=4, num_key_value_heads=2, pad_token_id=0)
+    model = E.LlamaEncoder(cfg)
+    red = FlatGradAllReducer(list(model.parameters()), world_size=1)
+    off = {id(p): o for p, o in zip(red.order, red.offsets)}
+    att, mlp = model.layers[0].self_attn, model.layers[0].mlp
+    q, k, v = att.q_proj.weight, att.k_proj.weight, att.v_proj.weight
+    assert off[id(k)] == off[id(q)] + q.numel() and off[id(v)] == off[id(k)] + k.numel()
+    assert off[id(mlp.up_proj.weight)] == off[id(mlp.gate_proj.weight)] + mlp.gate_proj.weight.numel()
+    # every parameter still has exactly one slot
+    assert len(set(off.values())) == len(red.order) == len(list(model.parameters()))
+    # move the parameters into a flat buffer with the same layout (what FlatAdamW does on the device)
+    flat = torch.zeros(red.numel)
+    for p, o in zip(red.order, red.offsets):
+        view = flat[o:o + p.numel()].view_as(p)
+        view.copy_(p.data)
+        p.data = view
+    w = E.fused_weight([q, k, v])
+    assert w.data_ptr() == q.data_ptr() and w.shape == (q.shape[0] + k.shape[0] + v.shape[0], q.shape[1])
+    assert torch.equal(w, torch.cat([q, k, v], 0))
+    g = torch.randn_like(w)
+    w.backward(g)
+    for t, sl in zip((q, k, v), g.split([q.shape[0], k.shape[0], v.shape[0]], 0)):
+        assert torch.equal(t.grad, sl)
+    # not adjacent (fresh tensors): falls back to a copy with the same values and gradients
+    a, b = torch.randn(3, 8, requires_grad=True), torch.randn(5, 8, requires_grad=True)
+    w2 = E.fused_weight([a, b])
+    assert torch.equal(w2, torch.cat([a, b], 0))
+    w2.sum().backward()
+    assert torch.equal(a.grad, torch.ones_like(a)) and torch.equal(b.grad, torch.ones_like(b))

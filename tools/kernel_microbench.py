@@ -94,7 +94,7 @@ lib = _lib.load()
 st = lambda: torch.cuda.current_stream().cuda_stream
 timeit("swiglu_fwd 150000x8192", lambda: lib.rpo_swiglu_fwd(gg.data_ptr(), uu.data_ptr(), oo.data_ptr(), T, ff, ff, ff, 1, st()))
 dg = torch.empty_like(gg)
-timeit("swiglu_bwd 150000x8192", lambda: lib.rpo_swiglu_bwd(gg.data_ptr(), uu.data_ptr(), oo.data_ptr(), dg.data_ptr(), oo.data_ptr(), T, ff, ff, ff, ff, 1, st()))
+timeit("swiglu_bwd 150000x8192", lambda: lib.rpo_swiglu_bwd(gg.data_ptr(), uu.data_ptr(), oo.data_ptr(), dg.data_ptr(), oo.data_ptr(), None, T, ff, ff, ff, ff, ff, 1, st()))
 del gg, uu, oo, dg
 xq = torch.randn(T, 32 * 64, device=dev, dtype=bf)
 fr = torch.outer(torch.arange(T, device=dev).float() % 4096, 1.0 / (5e5 ** (torch.arange(0, 64, 2, device=dev).float() / 64)))
