@@ -504,6 +504,20 @@ constexpr int kDmaLds = 3 * kDmaTile;                             // 101376 B (o
                  : "v"(ADDR)                                                                                         \
                  : "memory")
 
+#ifdef RPO_FA_STAMP   // diagnostic build only (tools/exp): in-kernel cycle stamps of the dK/dV loop, summed per wave role
+__device__ unsigned long long g_fa_stamp[8 * 8];
+#define RPO_STAMP(VAR)                                                                     \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(VAR)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#define RPO_STAMP_ADD(I, A, B) st_acc[I] += (B) - (A)
+#else
+#define RPO_STAMP(VAR)
+#define RPO_STAMP_ADD(I, A, B)
+#endif
+
 __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
@@ -596,12 +610,22 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
     for (int ks = 0; ks < 2; ++ks) row_off[ks] = (32 * wave + fr) * 128 + (((4 * ks + g) ^ (fr & 7)) << 4);
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
+#ifdef RPO_FA_STAMP
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta, tb_, tc, td, te, tf, tg;
+#endif
     int cur = 0;
     for (int it = 0; it < niter; ++it) {
+        RPO_STAMP(ta);
         if (it + 1 < niter) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");   // tile it landed; tile it + 1 may fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RPO_STAMP(tb_);
         __builtin_amdgcn_s_barrier();
+        RPO_STAMP(tc);
         if (it + 2 < niter) stage(it + 2, cur == 0 ? 2 : cur - 1);               // the buffer read in iteration it - 1
+        RPO_STAMP(td);
+        RPO_STAMP_ADD(0, ta, tb_);
+        RPO_STAMP_ADD(1, tb_, tc);
+        RPO_STAMP_ADD(2, tc, td);
         const char* Qs = smem + cur * kDmaTile;
         const char* Ds = Qs + kFaBM * 128;
         const float* Ls = reinterpret_cast<const float*>(Qs + 2 * kFaBM * 128);
@@ -646,6 +670,8 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
                     }
                 }
             }
+            RPO_STAMP(te);
+            RPO_STAMP_ADD(3, td, te);
             {   // Q^T: lands under the exp / mask arithmetic below
                 const unsigned a0 = tb + tr_off[0], a1 = tb + tr_off[1], a2 = tb + tr_off[2], a3 = tb + tr_off[3];
                 RPO_TR2(e0, e1, a0, 0, 2048);
@@ -680,6 +706,8 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
                            "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
                          :
                          : "memory");
+            RPO_STAMP(tf);
+            RPO_STAMP_ADD(4, te, tf);
             const short8_t atd[4] = {join_tr(d0, d1), join_tr(d2, d3), join_tr(d4, d5), join_tr(d6, d7)};
             const short8_t atq[4] = {join_tr(e0, e1), join_tr(e2, e3), join_tr(e4, e5), join_tr(e6, e7)};
 #pragma unroll
@@ -689,9 +717,21 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
                     dva[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atd[c], pf[n], dva[c][n], 0, 0, 0);
                     dka[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(atq[c], dsf[n], dka[c][n], 0, 0, 0);
                 }
+            RPO_STAMP(tg);
+            RPO_STAMP_ADD(5, tf, tg);
+#ifdef RPO_FA_STAMP
+            st_acc[6] += 1;
+#endif
         }
+#ifdef RPO_FA_STAMP
+        st_acc[7] += 1;
+#endif
         cur = cur == 2 ? 0 : cur + 1;
     }
+#ifdef RPO_FA_STAMP
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_fa_stamp[wave8 * 8 + i], st_acc[i]);
+#endif
     __syncthreads();                                        // every wave is done with the tile images
     float4_t* red = reinterpret_cast<float4_t*>(smem);       // [wave8][c in pair][n][lane]
 #pragma unroll
@@ -723,6 +763,17 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
 }
 
 }  // namespace
+
+#ifdef RPO_FA_STAMP
+extern "C" int rpo_debug_fa_stamps(unsigned long long* out64, int reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_fa_stamp), sizeof(unsigned long long) * 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[64] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_fa_stamp), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
                                   int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles,
