@@ -112,6 +112,9 @@ def _algo(name, a):
         T, nh, nkv, hd = a[15], a[16], a[17], a[18]
         pairs = _ATTN_PAIRS.get(T, 0)
         return 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, 10 * hd * pairs * nh
+    if name == "rpo_topk_merge":
+        rows, cols, k, dt = a[2], a[3], a[5], a[6]
+        return rows * cols * _es(dt) + 2 * rows * k * 12, rows * cols
     if name == "rpo_rankpo_fwd":
         B, d, dt = a[4], a[5], a[6]
         return 3 * B * d * _es(dt), 4 * B * d

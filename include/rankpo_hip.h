@@ -220,6 +220,15 @@ int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* 
                        int64_t head_dim, float scale, const float* lse, float* delta, void* dq, void* dk, void* dv,
                        int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, rpo_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * (8) exact top-k over score rows, merged chunk by chunk ("next" row f3: the k-selection of faiss.IndexFlatIP.search,
+ * reference src/utils.py:58-80).  scores: [rows, cols] (row stride ld elements) of the chunk whose first column is corpus
+ * row col0; best_val f32 [rows, k] / best_idx int64 [rows, k]: the winners so far, best first (value descending, ties by
+ * the smaller corpus index); first != 0: best_* hold nothing yet.  Unfilled slots are (-inf, INT64_MAX).  k <= 1024.
+ * --------------------------------------------------------------------------------------------- */
+int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype,
+                   float* best_val, int64_t* best_idx, int first, rpo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

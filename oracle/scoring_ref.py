@@ -318,3 +318,12 @@ RANKPO_METRIC_KEYS = (
     "rankpo_loss", "sft_loss", "rewards/chosen", "rewards/rejected", "rewards/accuracies",
     "rewards/margins", "scores/chosen", "scores/rejected", "scores/margins",
 )
+
+
+def topk_ref(scores, k):
+    """Exact top-k per row: value descending, ties by the smaller column index (a stable argsort of -score).  This is the
+    selection faiss.IndexFlatIP.search performs for the reference (src/utils.py:58-80; FAISS leaves the order of exact ties
+    unspecified, the build fixes it).  Returns (values float32 [rows, k], indices int64 [rows, k])."""
+    s = np.asarray(scores, dtype=np.float32)
+    order = np.argsort(-s.astype(np.float64), axis=1, kind="stable")[:, :k]
+    return np.take_along_axis(s, order, 1), order.astype(np.int64)

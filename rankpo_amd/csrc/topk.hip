@@ -1,0 +1,128 @@
+// Exact top-k selection over score rows, merged chunk by chunk ("next" row f3 of SURVEY.md §8: replaces the k-selection of
+// faiss.IndexFlatIP.search, reference src/utils.py:58-80, which runs on the CPU there).  HBM-bound integer / compare work:
+// every score is read exactly once (4 or 2 bytes per (query, corpus row) pair), nothing but the k winners is written.
+//
+// Order: value descending, ties by the smaller corpus index (= a stable argsort of -score, the oracle's definition).
+// One block per query row.  The row's current winners live in LDS; the block streams the row in segments of 1024
+// columns, collecting every element that beats the current k-th winner into an LDS candidate list (atomic counter), and
+// re-selects (bitonic sort of winners + candidates, 4096 slots) whenever the list could overflow during the next segment.
+// After the first few segments the k-th winner is high and almost nothing passes the filter, so the kernel is one
+// coalesced pass over the scores.
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTopkThreads = 256;
+constexpr int kTopkMaxK = 1024;      // winners kept per row
+constexpr int kTopkCap = 2048;       // candidate list
+constexpr int kTopkSeg = 1024;       // columns per segment (<= kTopkCap / 2)
+constexpr int kTopkSlots = 4096;     // bitonic sort size >= kTopkMaxK + kTopkCap
+
+__device__ __forceinline__ bool before(float va, long long ia, float vb, long long ib) {
+    return va > vb || (va == vb && ia < ib);
+}
+
+template <typename T>
+__device__ __forceinline__ float load_score(const T* p);
+template <>
+__device__ __forceinline__ float load_score<float>(const float* p) { return *p; }
+template <>
+__device__ __forceinline__ float load_score<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+
+// sorts the 4096 (value, index) slots: best first
+__device__ void bitonic_sort_desc(float* val, long long* idx, int tid) {
+    for (int size = 2; size <= kTopkSlots; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int t = tid; t < kTopkSlots / 2; t += kTopkThreads) {
+                const int lo = 2 * t - (t & (stride - 1));       // index with bit `stride` clear
+                const int hi = lo + stride;
+                const bool up = (lo & size) == 0;                 // this run sorts best-first, the next one worst-first
+                const float va = val[lo], vb = val[hi];
+                const long long ia = idx[lo], ib = idx[hi];
+                const bool a_first = before(va, ia, vb, ib);
+                if (a_first != up) {
+                    val[lo] = vb; val[hi] = va;
+                    idx[lo] = ib; idx[hi] = ia;
+                }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(kTopkThreads) void topk_merge_kernel(const T* __restrict__ scores, int64_t ld, int64_t cols,
+                                                                  int64_t col0, int k, float* __restrict__ best_val,
+                                                                  long long* __restrict__ best_idx, int first) {
+    __shared__ float s_val[kTopkSlots];
+    __shared__ long long s_idx[kTopkSlots];
+    __shared__ int s_count;
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const T* srow = scores + row * ld;
+    // slots [0, k): winners so far; [kTopkMaxK, kTopkMaxK + count): candidates; everything else: (-inf, max index)
+    for (int i = tid; i < kTopkSlots; i += kTopkThreads) {
+        float v = -INFINITY;
+        long long ix = 0x7fffffffffffffffLL;
+        if (i < k && !first) {
+            v = best_val[row * k + i];
+            ix = best_idx[row * k + i];
+        }
+        s_val[i] = v;
+        s_idx[i] = ix;
+    }
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    float tv = s_val[k - 1];
+    long long ti = s_idx[k - 1];
+    for (int64_t c0 = 0; c0 < cols; c0 += kTopkSeg) {
+        const int64_t cend = c0 + kTopkSeg < cols ? c0 + kTopkSeg : cols;
+        for (int64_t c = c0 + tid; c < cend; c += kTopkThreads) {
+            const float v = load_score<T>(srow + c);
+            const long long ix = col0 + c;
+            if (before(v, ix, tv, ti)) {
+                const int pos = atomicAdd(&s_count, 1);          // < kTopkCap by construction
+                s_val[kTopkMaxK + pos] = v;
+                s_idx[kTopkMaxK + pos] = ix;
+            }
+        }
+        __syncthreads();
+        const int count = s_count;
+        const bool last = cend == cols;
+        if (count > kTopkCap - kTopkSeg || (last && count > 0)) {
+            bitonic_sort_desc(s_val, s_idx, tid);                 // winners + candidates (+ padding) -> best first
+            for (int i = k + tid; i < kTopkSlots; i += kTopkThreads) {   // drop everything past the k-th
+                s_val[i] = -INFINITY;
+                s_idx[i] = 0x7fffffffffffffffLL;
+            }
+            if (tid == 0) s_count = 0;
+            __syncthreads();
+            tv = s_val[k - 1];
+            ti = s_idx[k - 1];
+        }
+    }
+    for (int i = tid; i < k; i += kTopkThreads) {
+        best_val[row * k + i] = s_val[i];
+        best_idx[row * k + i] = s_idx[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype,
+                              float* best_val, int64_t* best_idx, int first, rpo_stream_t stream) {
+    if (!scores || !best_val || !best_idx || rows <= 0 || cols <= 0 || ld < cols || k <= 0 || col0 < 0)
+        return RPO_ERR_INVALID_ARG;
+    if (k > kTopkMaxK || rows > INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == RPO_DT_F32)
+        RPO_LAUNCH(topk_merge_kernel<float>, dim3((unsigned)rows), dim3(kTopkThreads), 0, st, (const float*)scores, ld, cols,
+                   col0, k, best_val, (long long*)best_idx, first);
+    else if (dtype == RPO_DT_BF16)
+        RPO_LAUNCH(topk_merge_kernel<bf16_t>, dim3((unsigned)rows), dim3(kTopkThreads), 0, st, (const bf16_t*)scores, ld,
+                   cols, col0, k, best_val, (long long*)best_idx, first);
+    else
+        return RPO_ERR_INVALID_ARG;
+    return rpo_launch_status();
+}

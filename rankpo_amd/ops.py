@@ -565,7 +565,37 @@ def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scal
     return _FlashAttnVarlenQKV.apply(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale)
 
 
-__all__ = ["pool_normalize", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
+# ------------------------------------------------------------------------------------------------
+# (8) exact top-k over score chunks (retrieval, "next" row f3)
+# ------------------------------------------------------------------------------------------------
+TOPK_MAX_K = 1024
+
+
+def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
+    """Merges the top-k of `scores` ([rows, cols] f32 / bf16, the chunk of corpus rows [col0, col0 + cols)) into the winners so
+    far (`best_val` f32 [rows, k], `best_idx` int64 [rows, k]; None: start).  Order: value descending, ties by the smaller
+    corpus index.  Returns (best_val, best_idx), updated in place when given."""
+    _need_gpu(scores)
+    lib = _lib.load()
+    if scores.dim() != 2 or scores.stride(1) != 1:
+        raise ValueError("topk_merge: scores must be [rows, cols] with contiguous columns")
+    if not 0 < k <= TOPK_MAX_K:
+        raise ValueError(f"topk_merge: k must be in 1..{TOPK_MAX_K}")
+    rows, cols = scores.shape
+    first = best_val is None
+    if first:
+        best_val = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+        best_idx = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
+    elif best_val.shape != (rows, k) or best_idx.shape != (rows, k) or not best_val.is_contiguous() \
+            or not best_idx.is_contiguous() or best_val.dtype != torch.float32 or best_idx.dtype != torch.int64:
+        raise ValueError("topk_merge: best_val / best_idx must be contiguous f32 / int64 [rows, k]")
+    with torch.cuda.device(scores.device):
+        check(lib.rpo_topk_merge(scores.data_ptr(), scores.stride(0), rows, cols, int(col0), k, _dt(scores),
+                                 best_val.data_ptr(), best_idx.data_ptr(), int(first), _stream(scores)), "rpo_topk_merge")
+    return best_val, best_idx
+
+
+__all__ = ["pool_normalize", "topk_merge", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
            "flash_attn_varlen", "flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
            "attn_key_tile_table"]

@@ -1,9 +1,10 @@
 """Exact inner-product retrieval + ranking metrics ("next" row f3 of SURVEY.md §8; reference: src/utils.py:38-153,
 used by src/evaluate.py and src/get_hard_negatives.py through FAISS `IndexFlatIP`).
 
-`topk_search` is the flat-index search: scores = Q C^T computed by the HIP similarity kernel of the hot path (f32 storage
--> exact f32 FMA chains on the f32 MFMA, like FAISS' sgemm), top-k per query row by torch.topk (a hand-written
-selection kernel is future work).  `compute_metrics` follows the reference's definitions exactly, including its
+`FlatIPIndex.search` is the flat-index search: the corpus is walked in chunks; scores = Q C_chunk^T come from the HIP
+similarity kernel of the hot path (f32 storage -> f32 MFMA, like FAISS' sgemm) and `rpo_topk_merge` folds every chunk's
+scores into the k winners per query (value descending, ties by the smaller corpus index) -- the [nq, ntotal] score matrix is
+never materialised, so the corpus size is bounded by the embeddings alone (288 GB of HBM: ~35 M rows of d = 2048 in f32).  `compute_metrics` follows the reference's definitions exactly, including its
 non-standard Recall denominator `max(min(cutoff, len(pred), len(label)), 1)` and the flattened "naive AUC".
 """
 from __future__ import annotations
@@ -19,17 +20,23 @@ from . import ops
 class FlatIPIndex:
     """Stands where the reference builds `faiss.IndexFlatIP` (utils.py:38-51): keeps the corpus embeddings on the GPU."""
 
-    def __init__(self, embeddings, device="cuda:0", dtype=torch.float32):
+    def __init__(self, embeddings, device="cuda:0", dtype=torch.float32, chunk_rows: int = 262144):
         e = torch.as_tensor(np.asarray(embeddings, dtype=np.float32) if not torch.is_tensor(embeddings) else embeddings)
         self.emb = e.to(device=device, dtype=dtype).contiguous()
         self.ntotal = self.emb.shape[0]
+        self.chunk_rows = chunk_rows
 
     def search(self, queries, k: int):
+        """(scores f32 [nq, k], corpus indices int64 [nq, k]), best first; k is clamped to the corpus size."""
         q = torch.as_tensor(np.asarray(queries, dtype=np.float32) if not torch.is_tensor(queries) else queries)
         q = q.to(device=self.emb.device, dtype=self.emb.dtype).contiguous()
-        scores = ops.similarity(q, self.emb)                       # [nq, ntotal]  (HIP MFMA kernel)
         k = min(k, self.ntotal)
-        top, idx = torch.topk(scores.float(), k, dim=1, largest=True, sorted=True)
+        if k > ops.TOPK_MAX_K:
+            raise ValueError(f"FlatIPIndex.search: k <= {ops.TOPK_MAX_K}")
+        top = idx = None
+        for c0 in range(0, self.ntotal, self.chunk_rows):
+            scores = ops.similarity(q, self.emb[c0:c0 + self.chunk_rows])      # [nq, chunk]  (HIP MFMA kernel)
+            top, idx = ops.topk_merge(scores, c0, top, idx, k)                  # HIP selection kernel
         return top, idx
 
 

@@ -402,3 +402,73 @@ def test_infonce_backward_gemm_form(dtype, Q, P, d, win):
     tol = 3e-4 if dtype == torch.float32 else 2.0 ** -6      # bf16: dS itself is rounded to bf16 before the GEMM
     assert relmax(npf(ql.grad), dq_ref) < tol
     assert relmax(npf(pl.grad), dp_ref) < tol
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# exact top-k selection (rpo_topk_merge), bit-exact against oracle.topk_ref
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols,k,chunk", [(3, 50, 7, 50), (5, 5000, 100, 1300), (2, 70000, 1024, 16384),
+                                               (4, 1024, 1, 1024), (1, 9, 9, 4), (6, 3333, 200, 3333)])
+def test_topk_merge_matches_oracle(rows, cols, k, chunk):
+    from oracle.scoring_ref import topk_ref
+    from rankpo_amd import ops
+    rs = np.random.RandomState(rows * 1000 + cols)
+    s = rs.randn(rows, cols).astype(np.float32)
+    st = torch.tensor(s, device=DEV)
+    bv = bi = None
+    for c0 in range(0, cols, chunk):
+        bv, bi = ops.topk_merge(st[:, c0:c0 + chunk], c0, bv, bi, k)
+    rv, ri = topk_ref(s, k)
+    assert np.array_equal(bi.cpu().numpy(), ri)
+    assert np.array_equal(bv.cpu().numpy(), rv)
+
+
+def test_topk_merge_ties_and_order_independence():
+    """Heavy ties (quantised scores): the winners are the stable-argsort winners whatever the chunking, also when the
+    chunks arrive in a different order (the merge compares (value, corpus index), it does not rely on arrival order)."""
+    from oracle.scoring_ref import topk_ref
+    from rankpo_amd import ops
+    rs = np.random.RandomState(5)
+    s = rs.randint(0, 12, size=(7, 6000)).astype(np.float32)        # ~500 copies of every value
+    st = torch.tensor(s, device=DEV)
+    rv, ri = topk_ref(s, 300)
+    for order in ([0, 1, 2, 3], [3, 1, 0, 2]):
+        bv = bi = None
+        for j in order:
+            bv, bi = ops.topk_merge(st[:, 1500 * j:1500 * (j + 1)], 1500 * j, bv, bi, 300)
+        assert np.array_equal(bi.cpu().numpy(), ri) and np.array_equal(bv.cpu().numpy(), rv)
+    # bf16 scores (the storage dtype of ops.similarity on bf16 embeddings): same rule on the widened values
+    sb = torch.tensor(rs.randn(3, 4096).astype(np.float32), device=DEV).to(torch.bfloat16)
+    bv, bi = ops.topk_merge(sb, 0, None, None, 64)
+    rv, ri = topk_ref(sb.float().cpu().numpy(), 64)
+    assert np.array_equal(bi.cpu().numpy(), ri) and np.array_equal(bv.cpu().numpy(), rv)
+    # fewer columns than k: the tail stays (-inf, INT64_MAX) until later chunks fill it
+    bv, bi = ops.topk_merge(st[:, :5], 0, None, None, 8)
+    assert torch.isinf(bv[:, 5:]).all() and (bi[:, 5:] == torch.iinfo(torch.int64).max).all()
+    bv, bi = ops.topk_merge(st[:, 5:40], 5, bv, bi, 8)
+    rv, ri = topk_ref(s[:, :40], 8)
+    assert np.array_equal(bi.cpu().numpy(), ri)
+    with pytest.raises(ValueError):
+        ops.topk_merge(st, 0, None, None, 2000)
+
+
+def test_flat_index_search_chunked_equals_unchunked():
+    """retrieval.FlatIPIndex.search: chunked corpus walk == one chunk == oracle on the same f32 scores; size-independent
+    property at a corpus of 200 k rows: the k-th score bounds every non-selected score."""
+    from oracle.scoring_ref import topk_ref
+    from rankpo_amd import ops
+    from rankpo_amd.retrieval import FlatIPIndex
+    rs = np.random.RandomState(21)
+    corpus = rs.randn(200_000, 64).astype(np.float32)
+    queries = rs.randn(33, 64).astype(np.float32)
+    a = FlatIPIndex(corpus, device=DEV, chunk_rows=65536)
+    b = FlatIPIndex(corpus, device=DEV, chunk_rows=1 << 30)
+    sa, ia = a.search(queries, 100)
+    sb, ib = b.search(queries, 100)
+    assert torch.equal(ia, ib) and torch.equal(sa, sb)
+    full = ops.similarity(torch.tensor(queries, device=DEV), a.emb).cpu().numpy()
+    rv, ri = topk_ref(full, 100)
+    assert np.array_equal(ia.cpu().numpy(), ri) and np.array_equal(sa.cpu().numpy(), rv)
+    mask = np.ones_like(full, dtype=bool)
+    np.put_along_axis(mask, ri, False, 1)
+    assert (full[mask].reshape(33, -1).max(1) <= rv[:, -1]).all()
