@@ -30,11 +30,12 @@ template <>
 __device__ __forceinline__ float load_score<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
 
 // sorts the 4096 (value, index) slots: best first
+template <int NT>
 __device__ void bitonic_sort_desc(float* val, long long* idx, int tid) {
     for (int size = 2; size <= kTopkSlots; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int t = tid; t < kTopkSlots / 2; t += kTopkThreads) {
+            for (int t = tid; t < kTopkSlots / 2; t += NT) {
                 const int lo = 2 * t - (t & (stride - 1));       // index with bit `stride` clear
                 const int hi = lo + stride;
                 const bool up = (lo & size) == 0;                 // this run sorts best-first, the next one worst-first
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(kTopkThreads) void topk_merge_kernel(const T* __res
         const int count = s_count;
         const bool last = cend == cols;
         if (count > kTopkCap - kTopkSeg || (last && count > 0)) {
-            bitonic_sort_desc(s_val, s_idx, tid);                 // winners + candidates (+ padding) -> best first
+            bitonic_sort_desc<kTopkThreads>(s_val, s_idx, tid);   // winners + candidates (+ padding) -> best first
             for (int i = k + tid; i < kTopkSlots; i += kTopkThreads) {   // drop everything past the k-th
                 s_val[i] = -INFINITY;
                 s_idx[i] = 0x7fffffffffffffffLL;
@@ -108,6 +109,124 @@ __global__ __launch_bounds__(kTopkThreads) void topk_merge_kernel(const T* __res
     }
 }
 
+// ---- streaming path: 1024 threads per row, one 16-byte vector per thread and segment, kFastDepth segments in flight --
+// Requires 16-byte aligned rows (ld and the chunk base multiples of the vector length).  A segment is 1024 vectors
+// (4096 f32 / 8192 bf16 columns); candidates are appended under the same filter, a re-selection runs whenever the list is
+// more than half full, and a segment that overflows the list (only possible while the k-th winner is still weak: the first
+// columns of the first chunk) is replayed from its registers in quarters with a re-selection after each.
+constexpr int kFastThreads = 1024;
+constexpr int kFastDepth = 4;
+
+template <typename T>
+__global__ __launch_bounds__(kFastThreads) void topk_merge_fast_kernel(const T* __restrict__ scores, int64_t ld, int64_t cols,
+                                                                       int64_t col0, int k, float* __restrict__ best_val,
+                                                                       long long* __restrict__ best_idx, int first) {
+    constexpr int V = Elem<T>::kVec;
+    constexpr int SEG = kFastThreads * V;
+    __shared__ float s_val[kTopkSlots];
+    __shared__ long long s_idx[kTopkSlots];
+    __shared__ int s_count;
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    const T* srow = scores + row * ld;
+    for (int i = tid; i < kTopkSlots; i += kFastThreads) {
+        float v = -INFINITY;
+        long long ix = 0x7fffffffffffffffLL;
+        if (i < k && !first) {
+            v = best_val[row * k + i];
+            ix = best_idx[row * k + i];
+        }
+        s_val[i] = v;
+        s_idx[i] = ix;
+    }
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    float tv = s_val[k - 1];
+    long long ti = s_idx[k - 1];
+    auto reselect = [&]() {                                   // winners + candidates -> k winners, list emptied
+        bitonic_sort_desc<kFastThreads>(s_val, s_idx, tid);
+        for (int i = k + tid; i < kTopkSlots; i += kFastThreads) {
+            s_val[i] = -INFINITY;
+            s_idx[i] = 0x7fffffffffffffffLL;
+        }
+        if (tid == 0) s_count = 0;
+        __syncthreads();
+        tv = s_val[k - 1];
+        ti = s_idx[k - 1];
+    };
+    const int64_t nseg = (cols + SEG - 1) / SEG;
+    Vec16<T> reg[kFastDepth];
+    auto fetch = [&](int64_t sg, Vec16<T>& r) {
+        const int64_t c = sg * SEG + (int64_t)tid * V;
+        if (c + V <= cols) {
+            r.load_nt(srow + c);
+        } else {                                              // ragged tail: element-wise, -inf / never-selected padding
+#pragma unroll
+            for (int j = 0; j < V; ++j) r.v[j] = c + j < cols ? load_score<T>(srow + c + j) : -INFINITY;
+        }
+    };
+    for (int64_t s0 = 0; s0 < nseg; s0 += kFastDepth) {
+#pragma unroll
+        for (int u = 0; u < kFastDepth; ++u)
+            if (s0 + u < nseg) fetch(s0 + u, reg[u]);
+#pragma unroll
+        for (int u = 0; u < kFastDepth; ++u) {
+            if (s0 + u >= nseg) break;
+            const int64_t c = (s0 + u) * SEG + (int64_t)tid * V;
+            const int before_count = s_count;                 // uniform: read after the barrier that ended the last step
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const long long ix = col0 + c + j;
+                if (c + j < cols && before(reg[u].v[j], ix, tv, ti)) {
+                    const int pos = atomicAdd(&s_count, 1);
+                    if (pos < kTopkCap) {
+                        s_val[kTopkMaxK + pos] = reg[u].v[j];
+                        s_idx[kTopkMaxK + pos] = ix;
+                    }
+                }
+            }
+            __syncthreads();
+            int count = s_count;
+            if (count > kTopkCap) {
+                // overflow: drop this segment's appends, settle what was there, replay the segment in quarters
+                __syncthreads();
+                if (tid == 0) s_count = before_count;
+                __syncthreads();
+                for (int i = kTopkMaxK + before_count + tid; i < kTopkMaxK + kTopkCap; i += kFastThreads) {
+                    s_val[i] = -INFINITY;
+                    s_idx[i] = 0x7fffffffffffffffLL;
+                }
+                __syncthreads();
+                reselect();
+                for (int part = 0; part < 4; ++part) {
+                    if ((tid >> 8) == part) {
+#pragma unroll
+                        for (int j = 0; j < V; ++j) {
+                            const long long ix = col0 + c + j;
+                            if (c + j < cols && before(reg[u].v[j], ix, tv, ti)) {
+                                const int pos = atomicAdd(&s_count, 1);       // <= 256 V <= kTopkCap
+                                s_val[kTopkMaxK + pos] = reg[u].v[j];
+                                s_idx[kTopkMaxK + pos] = ix;
+                            }
+                        }
+                    }
+                    __syncthreads();
+                    if (s_count > 0) reselect();
+                }
+            } else if (count > kTopkCap / 2) {
+                reselect();
+            }
+        }
+    }
+    __syncthreads();
+    if (s_count > 0) reselect();
+    for (int i = tid; i < k; i += kFastThreads) {
+        best_val[row * k + i] = s_val[i];
+        best_idx[row * k + i] = s_idx[i];
+    }
+}
+
 }  // namespace
 
 extern "C" int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype,
@@ -116,6 +235,16 @@ extern "C" int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int6
         return RPO_ERR_INVALID_ARG;
     if (k > kTopkMaxK || rows > INT32_MAX) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
+    const int V = dtype == RPO_DT_BF16 ? 8 : 4;
+    if ((dtype == RPO_DT_F32 || dtype == RPO_DT_BF16) && ld % V == 0 && rpo_aligned16(scores) && cols >= 4096) {
+        if (dtype == RPO_DT_F32)
+            RPO_LAUNCH(topk_merge_fast_kernel<float>, dim3((unsigned)rows), dim3(kFastThreads), 0, st, (const float*)scores,
+                       ld, cols, col0, k, best_val, (long long*)best_idx, first);
+        else
+            RPO_LAUNCH(topk_merge_fast_kernel<bf16_t>, dim3((unsigned)rows), dim3(kFastThreads), 0, st,
+                       (const bf16_t*)scores, ld, cols, col0, k, best_val, (long long*)best_idx, first);
+        return rpo_launch_status();
+    }
     if (dtype == RPO_DT_F32)
         RPO_LAUNCH(topk_merge_kernel<float>, dim3((unsigned)rows), dim3(kTopkThreads), 0, st, (const float*)scores, ld, cols,
                    col0, k, best_val, (long long*)best_idx, first);

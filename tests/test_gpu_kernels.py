@@ -437,6 +437,15 @@ def test_topk_merge_ties_and_order_independence():
         for j in order:
             bv, bi = ops.topk_merge(st[:, 1500 * j:1500 * (j + 1)], 1500 * j, bv, bi, 300)
         assert np.array_equal(bi.cpu().numpy(), ri) and np.array_equal(bv.cpu().numpy(), rv)
+    bv, bi = ops.topk_merge(st, 0, None, None, 300)                 # one 6000-column chunk: the streaming kernel
+    assert np.array_equal(bi.cpu().numpy(), ri) and np.array_equal(bv.cpu().numpy(), rv)
+    big = np.tile(s, (1, 5))[:, :29999]                              # ragged width, 5 x the ties, k = 1024: overflow replay path
+    rvb, rib = topk_ref(big, 1024)
+    bv, bi = ops.topk_merge(torch.tensor(big, device=DEV)[:, :29996], 0, None, None, 1024)   # row stride 29999: unaligned -> scalar
+    assert np.array_equal(bi.cpu().numpy(), topk_ref(big[:, :29996], 1024)[1])
+    bigc = torch.tensor(np.ascontiguousarray(np.pad(big, ((0, 0), (0, 1)))), device=DEV)        # row stride 30000: aligned
+    bv, bi = ops.topk_merge(bigc[:, :29999], 0, None, None, 1024)
+    assert np.array_equal(bi.cpu().numpy(), rib) and np.array_equal(bv.cpu().numpy(), rvb)
     # bf16 scores (the storage dtype of ops.similarity on bf16 embeddings): same rule on the widened values
     sb = torch.tensor(rs.randn(3, 4096).astype(np.float32), device=DEV).to(torch.bfloat16)
     bv, bi = ops.topk_merge(sb, 0, None, None, 64)
