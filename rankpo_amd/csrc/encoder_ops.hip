@@ -181,6 +181,19 @@ namespace {
 
 constexpr int kNormThreads = 256, kNormWaves = kNormThreads / 64;
 
+// 16 bytes of T kept PACKED in registers (4 VGPRs) and widened element by element at the point of use: half the registers
+// of Vec16<bf16_t> for operands that are only read once per row (weight, incoming residual gradient)
+template <typename T> struct Raw16 {
+    uint4_t r;
+    __device__ __forceinline__ void load_nt(const T* p) { r = __builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(p)); }
+    __device__ __forceinline__ void load(const T* p) { r = *reinterpret_cast<const uint4_t*>(p); }
+    __device__ __forceinline__ float get(int e) const;
+};
+template <> __device__ __forceinline__ float Raw16<float>::get(int e) const { return __uint_as_float(r[e]); }
+template <> __device__ __forceinline__ float Raw16<bf16_t>::get(int e) const {
+    return (e & 1) ? __uint_as_float(r[e >> 1] & 0xffff0000u) : __uint_as_float(r[e >> 1] << 16);
+}
+
 template <typename T, int KMAX>
 __global__ __launch_bounds__(kNormThreads) void add_rmsnorm_fwd_kernel(const T* __restrict__ x, const T* __restrict__ delta,
                                                                        const T* __restrict__ w, float eps,
@@ -250,53 +263,63 @@ __global__ __launch_bounds__(kNormThreads) void add_rmsnorm_bwd_kernel(const T* 
     const int lane = threadIdx.x & 63;
     const int64_t wave = (int64_t)blockIdx.x * kNormWaves + (threadIdx.x >> 6);
     const int nvec = d / V;
-    float wv[KMAX][V], dwa[KMAX][V];
+    float dwa[KMAX][V];
+    Raw16<T> wv[KMAX];
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
         const int vi = lane + 64 * k;
 #pragma unroll
         for (int e = 0; e < V; ++e) dwa[k][e] = 0.f;
-        if (vi < nvec) {
-            Vec16<T> t;
-            t.load(w + vi * V);
-#pragma unroll
-            for (int e = 0; e < V; ++e) wv[k][e] = t.v[e];
-        }
+        if (vi < nvec) wv[k].load(w + vi * V);
     }
     const int64_t r0 = wave * rows_per_wave, r1 = r0 + rows_per_wave < rows ? r0 + rows_per_wave : rows;
     const float inv_d = 1.0f / (float)d;
     for (int64_t r = r0; r < r1; ++r) {
         const float rstd = rstd_in[r];
-        Vec16<T> gv[KMAX], xh[KMAX];
+        Raw16<T> gv[KMAX], xv[KMAX], rv[KMAX];                // dy, x_new, incoming residual gradient: packed
         float c = 0.f;
+        // all three streams of the row are requested before anything is consumed: ONE memory round trip per row
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int vi = lane + 64 * k;
             if (vi < nvec) {
                 gv[k].load_nt(dy + r * d + vi * V);
-                xh[k].load_nt(xn + r * d + vi * V);
+                xv[k].load_nt(xn + r * d + vi * V);
+                if (dres) rv[k].load_nt(dres + r * d + vi * V);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) {
+            const int vi = lane + 64 * k;
+            if (vi < nvec) {
 #pragma unroll
                 for (int e = 0; e < V; ++e) {
-                    xh[k].v[e] *= rstd;                               // xhat
-                    dwa[k][e] = fmaf(gv[k].v[e], xh[k].v[e], dwa[k][e]);
-                    gv[k].v[e] *= wv[k][e];                           // g = dy * w
-                    c = fmaf(gv[k].v[e], xh[k].v[e], c);
+                    const float xh = xv[k].get(e) * rstd;             // xhat
+                    const float dyv = gv[k].get(e);
+                    dwa[k][e] = fmaf(dyv, xh, dwa[k][e]);
+                    c = fmaf(dyv * wv[k].get(e), xh, c);              // g = dy * w
                 }
             }
         }
         c = wave_sum(c) * inv_d;
+        // keep the operands PACKED across the reduction: without this hipcc carries the widened x-hat / g / w values of the
+        // first pass over to the second one (196 VGPRs, 2 waves per SIMD instead of 3)
+#pragma unroll
+        for (int k = 0; k < KMAX; ++k) asm volatile("" : "+v"(gv[k].r), "+v"(xv[k].r), "+v"(wv[k].r));
 #pragma unroll
         for (int k = 0; k < KMAX; ++k) {
             const int vi = lane + 64 * k;
             if (vi < nvec) {
                 Vec16<T> o;
 #pragma unroll
-                for (int e = 0; e < V; ++e) o.v[e] = (gv[k].v[e] - xh[k].v[e] * c) * rstd;
+                for (int e = 0; e < V; ++e) {
+                    const float xh = xv[k].get(e) * rstd;
+                    const float g = gv[k].get(e) * wv[k].get(e);
+                    o.v[e] = (g - xh * c) * rstd;
+                }
                 if (dres) {
-                    Vec16<T> rv;
-                    rv.load_nt(dres + r * d + vi * V);
 #pragma unroll
-                    for (int e = 0; e < V; ++e) o.v[e] += rv.v[e];
+                    for (int e = 0; e < V; ++e) o.v[e] += rv[k].get(e);
                 }
                 o.store(dx + r * d + vi * V);
             }
