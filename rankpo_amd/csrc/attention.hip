@@ -280,9 +280,13 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 //                        images that serve the row reads (chunk ^= row & 7 is conflict-free for both kinds of read).
 // P is recomputed from the saved lse: P = exp(scale s - lse).
 // ------------------------------------------------------------------------------------------------------------------
+// Writes the two per-(head, query) row constants of the backward, NEGATED so that they can be the initial accumulators of the
+// S and dP MFMA chains:  nd[h][t] = -delta = -sum_d dO O   and   nl[h][t] = -lse / scale, so that S' = Q K^T - lse / scale
+// gives p = exp2(scale log2(e) S') with no subtraction, and dP' = dO V^T - delta is dS / (p scale) as it leaves the chain.
 __global__ __launch_bounds__(256) void fa_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
                                                        int64_t so, int64_t sdo, int nh, int64_t T,
-                                                       float* __restrict__ delta) {
+                                                       const float* __restrict__ lse, float inv_scale,
+                                                       float* __restrict__ nd, float* __restrict__ nl) {
     // one wave per (token, 8 heads): lane = (head in group of 8, 16-byte chunk)
     const int64_t t = blockIdx.x;
     for (int hc = threadIdx.x; hc < nh * 8; hc += 256) {
@@ -296,7 +300,10 @@ __global__ __launch_bounds__(256) void fa_delta_kernel(const bf16_t* __restrict_
         acc += __shfl_xor(acc, 1, 64);
         acc += __shfl_xor(acc, 2, 64);
         acc += __shfl_xor(acc, 4, 64);
-        if (ch == 0) delta[(int64_t)h * T + t] = acc;
+        if (ch == 0) {
+            nd[(int64_t)h * T + t] = -acc;
+            nl[(int64_t)h * T + t] = -lse[(int64_t)h * T + t] * inv_scale;
+        }
     }
 }
 
@@ -332,8 +339,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
             bdo[n][ks] = ok ? *reinterpret_cast<const short8_t*>(dout + (t0 + qi) * sdo + h * kFaHD + 32 * ks + 8 * g)
                             : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
-        lq[n] = ok ? lse[(int64_t)h * T + t0 + qi] * 1.4426950408889634f : 0.f;
-        dl[n] = ok ? delta[(int64_t)h * T + t0 + qi] : 0.f;
+        lq[n] = ok ? lse[(int64_t)h * T + t0 + qi] : 0.f;      // -lse / scale (fa_delta_kernel)
+        dl[n] = ok ? delta[(int64_t)h * T + t0 + qi] : 0.f;    // -delta
     }
     const int last_q = min(q0 + kFaBM - 1, len - 1);
     const int nkt = last_q / kFaBN + 1;
@@ -403,13 +410,14 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
                 RPO_TR4(x4, x5, y4, y5, a2, 0, 2048, 4096, 6144);
                 RPO_TR4(x6, x7, y6, y7, a3, 0, 2048, 4096, 6144);
             }
+            // the row constants (query = lane column: one scalar per lane and query tile) are the initial accumulators
             float4_t s[4][2], dp[4][2];
 #pragma unroll
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    s[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
-                    dp[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+                    s[m][n] = float4_t{lq[n], lq[n], lq[n], lq[n]};
+                    dp[m][n] = float4_t{dl[n], dl[n], dl[n], dl[n]};
                 }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
@@ -434,12 +442,12 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -lq[n]));
+                        float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
                         if (need_mask) {
                             const int key = kbase + 16 * m + r;
                             if (key > qi || key >= len || qi >= len) pv = 0.f;
                         }
-                        s[m][n][r] = pv * (dp[m][n][r] - dl[n]);          // dS / scale (scale: epilogue)
+                        s[m][n][r] = pv * dp[m][n][r];                    // dS / scale (scale: epilogue)
                     }
                 dsf[0][n] = pack_frag(s[0][n], s[1][n]);
                 dsf[1][n] = pack_frag(s[2][n], s[3][n]);
@@ -545,7 +553,7 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
     // lane l carries row 8u + (l >> 3), physical chunk l & 7 = logical chunk (l & 7) ^ (row & 7).
     const int srow = lane >> 3, lchunk = (lane & 7) ^ srow;
     const int lrow = 64 * (wave8 & 1) + lane;              // lse / delta row of this lane (waves 4..7 repeat 0..3)
-    const float* ld_src = ((wave8 >> 1) & 1) ? delta : lse;
+    const float* ld_src = ((wave8 >> 1) & 1) ? delta : lse;   // -delta : -lse / scale (fa_delta_kernel)
     // addresses = wave-uniform base of (sequence, q head) + a 32-bit lane offset inside the sequence (< 2^31: a sequence
     // is at most 2^31 / row-stride-bytes rows, checked by the host wrapper)
     const unsigned sqb = (unsigned)sq * 2u, sdob = (unsigned)sdo * 2u;
@@ -643,20 +651,19 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
                 RPO_TR2(d4, d5, a2, 16384, 18432);
                 RPO_TR2(d6, d7, a3, 16384, 18432);
             }
-            float4_t lr[2], dr[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                lr[m] = *reinterpret_cast<const float4_t*>(Ls + 32 * wave + 16 * m + 4 * g) * 1.4426950408889634f;
-                dr[m] = *reinterpret_cast<const float4_t*>(Dl + 32 * wave + 16 * m + 4 * g);
-            }
+            // the row constants -lse / scale and -delta (rows = queries 4g + r of the accumulator tile) are the initial
+            // accumulators of the S and dP chains: no subtraction per element afterwards
             float4_t s[2][2], dp[2][2];                       // [query tile m][key tile n]; rows = queries 4g + r
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m) {
+                const float4_t lr = *reinterpret_cast<const float4_t*>(Ls + 32 * wave + 16 * m + 4 * g);
+                const float4_t dr = *reinterpret_cast<const float4_t*>(Dl + 32 * wave + 16 * m + 4 * g);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
-                    s[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
-                    dp[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+                    s[m][n] = lr;
+                    dp[m][n] = dr;
                 }
+            }
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -688,10 +695,10 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
                     const int key = k0 + 16 * n + fr;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -lr[m][r]));
+                        float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
                         if (need_mask && (key > qr0 + r || key >= len || qr0 + r >= len)) pv = 0.f;
                         s[m][n][r] = pv;                                       // P
-                        dp[m][n][r] = pv * (dp[m][n][r] - dr[m][r]);            // dS / scale (scale: epilogue)
+                        dp[m][n][r] = pv * dp[m][n][r];                         // dS / scale (scale: epilogue)
                     }
                 }
             }
@@ -815,13 +822,15 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
         return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const float log2e = 1.4426950408889634f;
+    float* nd = delta;                                       // scratch [2][num_heads][T]: -delta | -lse / scale
+    float* nl = delta + num_heads * total_tokens;
     RPO_LAUNCH(fa_delta_kernel, dim3((unsigned)total_tokens), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout,
-               out_stride, dout_stride, (int)num_heads, total_tokens, delta);
+               out_stride, dout_stride, (int)num_heads, total_tokens, lse, 1.0f / scale, nd, nl);
     int rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
     RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, (unsigned)num_heads), dim3(kFaThreads), 0, st,
                (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
-               dout_stride, cu_seqlens, q_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse, delta,
+               dout_stride, cu_seqlens, q_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd,
                total_tokens, (bf16_t*)dq, dq_stride);
     rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
@@ -833,7 +842,7 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     (void)attr_set;
     RPO_LAUNCH(fa_bwd_dkdv_kernel, dim3(dkdv_grid), dim3(kFaDkdvThreads), kDmaLds, st, (const bf16_t*)q, (const bf16_t*)k,
                (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
-               (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse, delta, total_tokens, (bf16_t*)dk,
+               (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
                (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles);
     return rpo_launch_status();
 }
