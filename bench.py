@@ -343,20 +343,21 @@ def main():
     tok_pad = B * Lq + B * (1 + K) * Lp
     ckpt = args.ckpt_layers
     if ckpt == -2:
-        ckpt = -1
-        if hasattr(enc, "layers"):
-            # activation bytes kept per token per un-checkpointed block: x, norm(x), q, k, v, attn out, x', norm(x'),
-            # gate, up (the SwiGLU product is recomputed) = s (6.5 d + 2 ff) upper bound; measured 44 KB for
-            # Llama-3.2-1B bf16 (0.75 of the bound).  States: 16 B/param.
-            es = 2 if dtype == torch.bfloat16 else 4
-            per_tok = int(0.8 * es * (6.5 * cfg.hidden_size + 2 * cfg.intermediate_size))
-            toks = tok_pad     # budget for the worst case (every row at full length), also in packed mode
-            per_layer = toks * per_tok
-            nparam = sum(p.numel() for p in enc.parameters())
-            total = torch.cuda.get_device_properties(device).total_memory
-            budget = 0.72 * total - nparam * (es * 2 + 12) - toks * cfg.hidden_size * es * len(enc.layers) - 2 * per_layer
-            free_layers = max(0, min(len(enc.layers), int(budget // per_layer)))
-            ckpt = len(enc.layers) - free_layers
+        # activation bytes kept per token per un-checkpointed block: x, norm(x), q, k, v, attn out, x', norm(x'),
+        # gate, up (the SwiGLU product is recomputed) = s (6.5 d + 2 ff) upper bound; measured 44 KB for
+        # Llama-3.2-1B bf16 (0.75 of the bound).  States: 16 B/param.
+        es = 2 if dtype == torch.bfloat16 else 4
+        nl = cfg.num_hidden_layers
+        per_tok = int(0.8 * es * (6.5 * cfg.hidden_size + 2 * cfg.intermediate_size))
+        toks = tok_pad     # budget for the worst case (every row at full length), also in packed mode
+        per_layer = toks * per_tok
+        nparam = sum(p.numel() for p in enc.parameters())
+        total = torch.cuda.get_device_properties(device).total_memory
+        budget = 0.72 * total - nparam * (es * 2 + 12) - toks * cfg.hidden_size * es * nl - 2 * per_layer
+        free_layers = max(0, min(nl, int(budget // per_layer)))
+        ckpt = nl - free_layers
+        if not hasattr(enc, "layers"):          # encoders without per-block control: all blocks or none
+            ckpt = 0 if free_layers == nl else -1
     if ckpt != 0 and hasattr(enc, "layers"):
         model.gradient_checkpointing_enable(layers=None if ckpt < 0 else ckpt)
     elif ckpt != 0:
