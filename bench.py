@@ -268,10 +268,10 @@ def cpu_baseline(model, cfg, temperature, sample=(160, 512, 2)):
     E.contrastive_step(w, cd, warm, temperature)[0].backward()
     batch = {"query": mk(1, Lq_s), "passage": mk(G_s, Lp_s)}
     t0 = time.perf_counter()
-    loss = E.contrastive_step(w, cd, batch, temperature)[0]
+    loss, scores = E.contrastive_step(w, cd, batch, temperature)[:2]
     loss.backward()
     dt = time.perf_counter() - t0
-    return dt, Lq_s + G_s * Lp_s, cores
+    return dt, Lq_s + G_s * Lp_s, cores, batch, (float(loss.detach()), scores.detach().float().flatten().tolist())
 
 
 class _StdoutToStderr:
@@ -474,7 +474,21 @@ def main():
             note("sweep done")
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")
-            dt, toks, cores = cpu_baseline(model, cfg, temperature)
+            dt, toks, cores, sample_batch, (oracle_loss, oracle_scores) = cpu_baseline(model, cfg, temperature)
+            # step-loss parity on identical tokens: the same sample through the HIP path with the same weights
+            # (storage dtype of the run here, float32 in the oracle)
+            with torch.no_grad():
+                dev_batch = {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in sample_batch.items()}
+                hip_out = model(**dev_batch)
+                hip_loss = float(hip_out["loss"])
+                hip_scores = hip_out["scores"].float().flatten().cpu().tolist()
+            cos_diff = max(abs(a - b) for a, b in zip(oracle_scores, hip_scores)) * temperature
+            out["step_loss_parity"] = {"oracle_f32": round(oracle_loss, 6), "hip": round(hip_loss, 6),
+                                       "abs_diff": round(abs(oracle_loss - hip_loss), 6),
+                                       "max_cosine_abs_diff": round(cos_diff, 6),
+                                       "note": "same tokens and weights as the cpu_baseline sample; storage dtype "
+                                               f"{dtn} on the GPU, float32 in the oracle; logits = cosine / "
+                                               f"{temperature}, so a cosine difference d moves the loss by up to d / {temperature}"}
             toks_per_pair = Lp + Lq / (1 + K)
             out["cpu_baseline"] = {"value": round(toks / dt / toks_per_pair, 5), "unit": "pairs/s", "cores": cores,
                                    "kind": "port",
