@@ -643,7 +643,8 @@ def save_encoder(enc: nn.Module, path: str):
     """Write the INNER encoder in HF layout (what the reference's save_model does: contrastive_trainer.py:964-1027)."""
     from safetensors.torch import save_file
     os.makedirs(path, exist_ok=True)
-    sd = {k: v.detach().contiguous().cpu() for k, v in enc.state_dict().items()}
+    # a private host copy of every tensor: parameters may be views of ONE flat optimizer buffer (train_step.FlatAdamW)
+    sd = {k: v.detach().to("cpu", copy=True).contiguous() for k, v in enc.state_dict().items()}
     save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
     with open(os.path.join(path, "config.json"), "w") as f:
         json.dump({k: v for k, v in enc.config.to_dict().items()}, f, indent=2, default=str)
