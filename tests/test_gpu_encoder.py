@@ -360,3 +360,34 @@ def test_multi_step_training_loss_parity_vs_oracle(gas):
     # parameters after training agree too
     wq = w["layers.0.self_attn.q_proj.weight"].detach()
     assert (enc.layers[0].self_attn.q_proj.weight.detach().cpu() - wq).abs().max() < 5e-3 * wq.abs().max()
+
+
+def test_checkpoint_round_trip_after_flat_optimizer_step(tmp_path):
+    """f4 after f2: once FlatAdamW has moved the parameters into ONE flat buffer (views, fuse groups back to back),
+    save_encoder must still write an HF-layout checkpoint that load_encoder (and the zero-copy fused weights) reproduce."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    from rankpo_amd.train_step import TrainStep
+    torch.manual_seed(21)
+    cfg = PE.llama_config(vocab_size=200, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, pad_token_id=0)
+    enc = PE.LlamaEncoder(cfg).to(DEV)
+    model = rankpo_amd.ModelForTraining(encoder=enc, temperature=0.05).train()
+    ts = TrainStep(model.parameters(), lambda b: model(**b)["loss"], lr=1e-2, total_steps=4)
+    rs = np.random.RandomState(22)
+    qi, qm = _batch(rs, 4, 12, 200)
+    pi, pm = _batch(rs, 8, 20, 200)
+    batch = {"query": {"input_ids": qi.to(DEV), "attention_mask": qm.to(DEV)},
+             "passage": {"input_ids": pi.to(DEV), "attention_mask": pm.to(DEV)}}
+    ts.step(batch)
+    att = enc.layers[0].self_attn
+    w = PE.fused_weight([att.q_proj.weight, att.k_proj.weight, att.v_proj.weight])
+    assert w.data_ptr() == att.q_proj.weight.data_ptr()            # zero-copy view of the flat parameter buffer
+    PE.save_encoder(enc, str(tmp_path / "ckpt"))
+    enc2 = PE.load_encoder(str(tmp_path / "ckpt")).to(DEV)
+    for (k, a), (_, b) in zip(enc.state_dict().items(), enc2.state_dict().items()):
+        assert torch.equal(a, b), k
+    with torch.no_grad():
+        h1 = enc(input_ids=pi.to(DEV), attention_mask=pm.to(DEV)).last_hidden_state
+        h2 = enc2(input_ids=pi.to(DEV), attention_mask=pm.to(DEV)).last_hidden_state
+    assert torch.equal(h1, h2)
