@@ -211,7 +211,7 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
 
 /* Backward of rpo_flash_attn_fwd (three launches, no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
  * forward with lse_max_len == 0; delta: f32 [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale, the initial accumulators of the dP and S chains).  q_tiles as in the
- * forward; k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a 64-key tile) sorted by (sequence, head, key).
+ * forward; k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a 256-key block) sorted by (sequence, head, key).
  * dq: [T, num_heads, 64], dk / dv: [T, num_kv_heads, 64] (token strides given), every valid row is written. */
 int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, int64_t q_stride,
                        int64_t k_stride, int64_t v_stride, int64_t out_stride, int64_t dout_stride,

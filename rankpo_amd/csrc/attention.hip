@@ -769,6 +769,1308 @@ __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
     }
 }
 
+// ---- dK / dV, one wave per SIMD ------------------------------------------------------------------------------------------
+// Block = 4 waves = 256 keys of one (sequence, kv head); wave w owns keys [kb0 + 64 w, + 64) entirely: its K / V fragments
+// (64 VGPRs) and its dK^T / dV^T accumulators (128 registers) stay in the register file for the whole sweep over the
+// group's q heads x 32-row query slices, so there is no cross-wave sum and nothing but the 8 KB Q / dO slice (+ its 64 row
+// constants) is shared.  One wave per SIMD (up to 512 registers): the two waves of the 8-wave kernel above leave every
+// barrier together and then want the same unit at the same time (profiles/r01_fa_dkdv_stamps.md); here a SIMD's MFMA, VALU
+// and LDS work belong to ONE instruction stream, and the bytes through the L1 -> LDS path per MFMA drop 4x.
+// Slices arrive by global_load_lds into a ring of 8 images, 4 slices ahead, one raw barrier per slice, counted vmcnt.
+// Accumulator-file map (literal registers in the asm statements; hipcc must not touch AGPRs in this kernel -- its
+// resource line must read 0 spills and the .s no v_accvgpr_* outside ASMSTART / ASMEND):
+//   dva[c][n] = a[16c + 4n ..+3] (0..63), dka[c][n] = a[64 + 16c + 4n ..+3], bk[n][ks] = a[128 + 8n + 4ks ..+3],
+//   bv[n][ks] = a[160 + 8n + 4ks ..+3].
+constexpr int kSl = 32;                                      // query rows per slice
+constexpr int kSlImg = 2 * kSl * 128 + 2 * kSl * 4;          // Q | dO | -lse/scale | -delta = 8448 B
+constexpr int kSlRing = 8, kSlAhead = 4;
+constexpr int kDkdv4Lds = kSlRing * kSlImg;                  // 67584 B
+
+// MFMA statements of the one-wave-per-SIMD dK/dV kernel with literal accumulator-file registers (map: see the kernel)
+#define RPO_D4_M1_KS0(M, AQ, AD)                                                                              \
+    asm volatile(                                                                                            \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %0, %8, a[128:131], %0\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %4, %9, a[160:163], %4\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %1, %8, a[136:139], %1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %5, %9, a[168:171], %5\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %2, %8, a[144:147], %2\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %6, %9, a[176:179], %6\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %3, %8, a[152:155], %3\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %7, %9, a[184:187], %7" \
+        : "+v"(s[M][0]), "+v"(s[M][1]), "+v"(s[M][2]), "+v"(s[M][3]), "+v"(dp[M][0]), "+v"(dp[M][1]),         \
+          "+v"(dp[M][2]), "+v"(dp[M][3])                                                                        \
+        : "v"(AQ), "v"(AD)                                                                                   \
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#define RPO_D4_M1_KS1(M, AQ, AD)                                                                              \
+    asm volatile(                                                                                            \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %0, %8, a[132:135], %0\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %4, %9, a[164:167], %4\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %1, %8, a[140:143], %1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %5, %9, a[172:175], %5\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %2, %8, a[148:151], %2\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %6, %9, a[180:183], %6\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %3, %8, a[156:159], %3\n\t" \
+        "v_mfma_f32_16x16x32_bf16 %7, %9, a[188:191], %7" \
+        : "+v"(s[M][0]), "+v"(s[M][1]), "+v"(s[M][2]), "+v"(s[M][3]), "+v"(dp[M][0]), "+v"(dp[M][1]),         \
+          "+v"(dp[M][2]), "+v"(dp[M][3])                                                                        \
+        : "v"(AQ), "v"(AD)                                                                                   \
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#define RPO_D4_M2_N0(ATD, ATQ, PF, DS)                                                                        \
+    asm volatile(                                                                                            \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[0:3], %0, %8, a[0:3]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[64:67], %4, %9, a[64:67]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[16:19], %1, %8, a[16:19]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[80:83], %5, %9, a[80:83]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[32:35], %2, %8, a[32:35]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[96:99], %6, %9, a[96:99]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[48:51], %3, %8, a[48:51]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[112:115], %7, %9, a[112:115]" \
+        :                                                                                                    \
+        : "v"(ATD[0]), "v"(ATD[1]), "v"(ATD[2]), "v"(ATD[3]), "v"(ATQ[0]), "v"(ATQ[1]), "v"(ATQ[2]), "v"(ATQ[3]), \
+          "v"(PF[0]), "v"(DS[0])                                                                            \
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#define RPO_D4_M2_N1(ATD, ATQ, PF, DS)                                                                        \
+    asm volatile(                                                                                            \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[4:7], %0, %8, a[4:7]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[68:71], %4, %9, a[68:71]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[20:23], %1, %8, a[20:23]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[84:87], %5, %9, a[84:87]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[36:39], %2, %8, a[36:39]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[100:103], %6, %9, a[100:103]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[52:55], %3, %8, a[52:55]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[116:119], %7, %9, a[116:119]" \
+        :                                                                                                    \
+        : "v"(ATD[0]), "v"(ATD[1]), "v"(ATD[2]), "v"(ATD[3]), "v"(ATQ[0]), "v"(ATQ[1]), "v"(ATQ[2]), "v"(ATQ[3]), \
+          "v"(PF[1]), "v"(DS[1])                                                                            \
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#define RPO_D4_M2_N2(ATD, ATQ, PF, DS)                                                                        \
+    asm volatile(                                                                                            \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[8:11], %0, %8, a[8:11]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[72:75], %4, %9, a[72:75]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[24:27], %1, %8, a[24:27]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[88:91], %5, %9, a[88:91]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[40:43], %2, %8, a[40:43]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[104:107], %6, %9, a[104:107]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[56:59], %3, %8, a[56:59]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[120:123], %7, %9, a[120:123]" \
+        :                                                                                                    \
+        : "v"(ATD[0]), "v"(ATD[1]), "v"(ATD[2]), "v"(ATD[3]), "v"(ATQ[0]), "v"(ATQ[1]), "v"(ATQ[2]), "v"(ATQ[3]), \
+          "v"(PF[2]), "v"(DS[2])                                                                            \
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#define RPO_D4_M2_N3(ATD, ATQ, PF, DS)                                                                        \
+    asm volatile(                                                                                            \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[12:15], %0, %8, a[12:15]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[76:79], %4, %9, a[76:79]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[28:31], %1, %8, a[28:31]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[92:95], %5, %9, a[92:95]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[44:47], %2, %8, a[44:47]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[108:111], %6, %9, a[108:111]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[60:63], %3, %8, a[60:63]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[124:127], %7, %9, a[124:127]" \
+        :                                                                                                    \
+        : "v"(ATD[0]), "v"(ATD[1]), "v"(ATD[2]), "v"(ATD[3]), "v"(ATQ[0]), "v"(ATQ[1]), "v"(ATQ[2]), "v"(ATQ[3]), \
+          "v"(PF[3]), "v"(DS[3])                                                                            \
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+// generated by tools/gen/gen_dkdv4_body.py (register map and operand list there); 238 instructions
+#define RPO_D4_SLICE_BODY_LOAD(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD) \
+    asm volatile( \
+        "ds_read_b128 v[160:163], %2\n\t" \
+        "ds_read_b128 v[168:171], %2 offset:128\n\t" \
+        "ds_read_b128 v[128:131], %0\n\t" \
+        "ds_read_b128 v[132:135], %0 offset:4096\n\t" \
+        "ds_read_b128 v[164:167], %2 offset:64\n\t" \
+        "ds_read_b128 v[172:175], %2 offset:192\n\t" \
+        "ds_read_b128 v[136:139], %0 offset:2048\n\t" \
+        "ds_read_b128 v[140:143], %0 offset:6144\n\t" \
+        "ds_read_b128 v[144:147], %1\n\t" \
+        "ds_read_b128 v[148:151], %1 offset:4096\n\t" \
+        "ds_read_b128 v[152:155], %1 offset:2048\n\t" \
+        "ds_read_b128 v[156:159], %1 offset:6144\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "ds_read_b64_tr_b16 v[176:177], %3 offset:4096\n\t" \
+        "ds_read_b64_tr_b16 v[178:179], %3 offset:6144\n\t" \
+        "ds_read_b64_tr_b16 v[192:193], %3\n\t" \
+        "ds_read_b64_tr_b16 v[194:195], %3 offset:2048\n\t" \
+        "ds_read_b64_tr_b16 v[180:181], %4 offset:4096\n\t" \
+        "ds_read_b64_tr_b16 v[182:183], %4 offset:6144\n\t" \
+        "ds_read_b64_tr_b16 v[196:197], %4\n\t" \
+        "ds_read_b64_tr_b16 v[198:199], %4 offset:2048\n\t" \
+        "ds_read_b64_tr_b16 v[184:185], %5 offset:4096\n\t" \
+        "ds_read_b64_tr_b16 v[186:187], %5 offset:6144\n\t" \
+        "ds_read_b64_tr_b16 v[200:201], %5\n\t" \
+        "ds_read_b64_tr_b16 v[202:203], %5 offset:2048\n\t" \
+        "ds_read_b64_tr_b16 v[188:189], %6 offset:4096\n\t" \
+        "ds_read_b64_tr_b16 v[190:191], %6 offset:6144\n\t" \
+        "ds_read_b64_tr_b16 v[204:205], %6\n\t" \
+        "ds_read_b64_tr_b16 v[206:207], %6 offset:2048\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[128:131], a[128:131], v[160:163]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[136:139], a[128:131], v[164:167]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[132:135], a[160:163], v[168:171]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[140:143], a[160:163], v[172:175]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[144:147], a[132:135], v[64:67]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[152:155], a[132:135], v[80:83]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[148:151], a[164:167], v[96:99]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[156:159], a[164:167], v[112:115]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[128:131], a[136:139], v[160:163]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[136:139], a[136:139], v[164:167]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[132:135], a[168:171], v[168:171]\n\t" \
+        "v_mul_f32 v64, %7, v64\n\t" \
+        "v_mul_f32 v65, %7, v65\n\t" \
+        "v_mul_f32 v66, %7, v66\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[140:143], a[168:171], v[172:175]\n\t" \
+        "v_mul_f32 v67, %7, v67\n\t" \
+        "v_mul_f32 v80, %7, v80\n\t" \
+        "v_mul_f32 v81, %7, v81\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[144:147], a[140:143], v[68:71]\n\t" \
+        "v_mul_f32 v82, %7, v82\n\t" \
+        "v_mul_f32 v83, %7, v83\n\t" \
+        "v_exp_f32 v64, v64\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[152:155], a[140:143], v[84:87]\n\t" \
+        "v_exp_f32 v65, v65\n\t" \
+        "v_exp_f32 v66, v66\n\t" \
+        "v_exp_f32 v67, v67\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[148:151], a[172:175], v[100:103]\n\t" \
+        "v_exp_f32 v80, v80\n\t" \
+        "v_exp_f32 v81, v81\n\t" \
+        "v_exp_f32 v82, v82\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[156:159], a[172:175], v[116:119]\n\t" \
+        "v_exp_f32 v83, v83\n\t" \
+        "v_mul_f32 v96, v64, v96\n\t" \
+        "v_mul_f32 v97, v65, v97\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[128:131], a[144:147], v[160:163]\n\t" \
+        "v_mul_f32 v98, v66, v98\n\t" \
+        "v_mul_f32 v99, v67, v99\n\t" \
+        "v_mul_f32 v112, v80, v112\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[136:139], a[144:147], v[164:167]\n\t" \
+        "v_mul_f32 v113, v81, v113\n\t" \
+        "v_mul_f32 v114, v82, v114\n\t" \
+        "v_mul_f32 v115, v83, v115\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[132:135], a[176:179], v[168:171]\n\t" \
+        "v_cvt_pk_bf16_f32 v208, v64, v65\n\t" \
+        "v_cvt_pk_bf16_f32 v209, v66, v67\n\t" \
+        "v_cvt_pk_bf16_f32 v210, v80, v81\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[140:143], a[176:179], v[172:175]\n\t" \
+        "v_cvt_pk_bf16_f32 v211, v82, v83\n\t" \
+        "v_cvt_pk_bf16_f32 v224, v96, v97\n\t" \
+        "v_cvt_pk_bf16_f32 v225, v98, v99\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[144:147], a[148:151], v[72:75]\n\t" \
+        "v_cvt_pk_bf16_f32 v226, v112, v113\n\t" \
+        "v_cvt_pk_bf16_f32 v227, v114, v115\n\t" \
+        "v_mul_f32 v68, %7, v68\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[152:155], a[148:151], v[88:91]\n\t" \
+        "v_mul_f32 v69, %7, v69\n\t" \
+        "v_mul_f32 v70, %7, v70\n\t" \
+        "v_mul_f32 v71, %7, v71\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[148:151], a[180:183], v[104:107]\n\t" \
+        "v_mul_f32 v84, %7, v84\n\t" \
+        "v_mul_f32 v85, %7, v85\n\t" \
+        "v_mul_f32 v86, %7, v86\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[156:159], a[180:183], v[120:123]\n\t" \
+        "v_mul_f32 v87, %7, v87\n\t" \
+        "v_exp_f32 v68, v68\n\t" \
+        "v_exp_f32 v69, v69\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[128:131], a[152:155], v[160:163]\n\t" \
+        "v_exp_f32 v70, v70\n\t" \
+        "v_exp_f32 v71, v71\n\t" \
+        "v_exp_f32 v84, v84\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[136:139], a[152:155], v[164:167]\n\t" \
+        "v_exp_f32 v85, v85\n\t" \
+        "v_exp_f32 v86, v86\n\t" \
+        "v_exp_f32 v87, v87\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[132:135], a[184:187], v[168:171]\n\t" \
+        "v_mul_f32 v100, v68, v100\n\t" \
+        "v_mul_f32 v101, v69, v101\n\t" \
+        "v_mul_f32 v102, v70, v102\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[140:143], a[184:187], v[172:175]\n\t" \
+        "v_mul_f32 v103, v71, v103\n\t" \
+        "v_mul_f32 v116, v84, v116\n\t" \
+        "v_mul_f32 v117, v85, v117\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[144:147], a[156:159], v[76:79]\n\t" \
+        "v_mul_f32 v118, v86, v118\n\t" \
+        "v_mul_f32 v119, v87, v119\n\t" \
+        "v_cvt_pk_bf16_f32 v212, v68, v69\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[152:155], a[156:159], v[92:95]\n\t" \
+        "v_cvt_pk_bf16_f32 v213, v70, v71\n\t" \
+        "v_cvt_pk_bf16_f32 v214, v84, v85\n\t" \
+        "v_cvt_pk_bf16_f32 v215, v86, v87\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[148:151], a[188:191], v[108:111]\n\t" \
+        "v_cvt_pk_bf16_f32 v228, v100, v101\n\t" \
+        "v_cvt_pk_bf16_f32 v229, v102, v103\n\t" \
+        "v_cvt_pk_bf16_f32 v230, v116, v117\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[156:159], a[188:191], v[124:127]\n\t" \
+        "v_cvt_pk_bf16_f32 v231, v118, v119\n\t" \
+        "v_mul_f32 v72, %7, v72\n\t" \
+        "v_mul_f32 v73, %7, v73\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "ds_read_b128 v[160:163], %10\n\t" \
+        "ds_read_b128 v[168:171], %10 offset:128\n\t" \
+        "ds_read_b128 v[128:131], %8\n\t" \
+        "ds_read_b128 v[132:135], %8 offset:4096\n\t" \
+        "ds_read_b128 v[164:167], %10 offset:64\n\t" \
+        "ds_read_b128 v[172:175], %10 offset:192\n\t" \
+        "ds_read_b128 v[136:139], %8 offset:2048\n\t" \
+        "ds_read_b128 v[140:143], %8 offset:6144\n\t" \
+        "ds_read_b128 v[144:147], %9\n\t" \
+        "ds_read_b128 v[148:151], %9 offset:4096\n\t" \
+        "ds_read_b128 v[152:155], %9 offset:2048\n\t" \
+        "ds_read_b128 v[156:159], %9 offset:6144\n\t" \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[0:3], v[176:179], v[208:211], a[0:3]\n\t" \
+        "v_mul_f32 v74, %7, v74\n\t" \
+        "v_mul_f32 v75, %7, v75\n\t" \
+        "v_mul_f32 v88, %7, v88\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[64:67], v[192:195], v[224:227], a[64:67]\n\t" \
+        "v_mul_f32 v89, %7, v89\n\t" \
+        "v_mul_f32 v90, %7, v90\n\t" \
+        "v_mul_f32 v91, %7, v91\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[16:19], v[180:183], v[208:211], a[16:19]\n\t" \
+        "v_exp_f32 v72, v72\n\t" \
+        "v_exp_f32 v73, v73\n\t" \
+        "v_exp_f32 v74, v74\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[80:83], v[196:199], v[224:227], a[80:83]\n\t" \
+        "v_exp_f32 v75, v75\n\t" \
+        "v_exp_f32 v88, v88\n\t" \
+        "v_exp_f32 v89, v89\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[32:35], v[184:187], v[208:211], a[32:35]\n\t" \
+        "v_exp_f32 v90, v90\n\t" \
+        "v_exp_f32 v91, v91\n\t" \
+        "v_mul_f32 v104, v72, v104\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[96:99], v[200:203], v[224:227], a[96:99]\n\t" \
+        "v_mul_f32 v105, v73, v105\n\t" \
+        "v_mul_f32 v106, v74, v106\n\t" \
+        "v_mul_f32 v107, v75, v107\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[48:51], v[188:191], v[208:211], a[48:51]\n\t" \
+        "v_mul_f32 v120, v88, v120\n\t" \
+        "v_mul_f32 v121, v89, v121\n\t" \
+        "v_mul_f32 v122, v90, v122\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[112:115], v[204:207], v[224:227], a[112:115]\n\t" \
+        "v_mul_f32 v123, v91, v123\n\t" \
+        "v_cvt_pk_bf16_f32 v216, v72, v73\n\t" \
+        "v_cvt_pk_bf16_f32 v217, v74, v75\n\t" \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[4:7], v[176:179], v[212:215], a[4:7]\n\t" \
+        "v_cvt_pk_bf16_f32 v218, v88, v89\n\t" \
+        "v_cvt_pk_bf16_f32 v219, v90, v91\n\t" \
+        "v_cvt_pk_bf16_f32 v232, v104, v105\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[68:71], v[192:195], v[228:231], a[68:71]\n\t" \
+        "v_cvt_pk_bf16_f32 v233, v106, v107\n\t" \
+        "v_cvt_pk_bf16_f32 v234, v120, v121\n\t" \
+        "v_cvt_pk_bf16_f32 v235, v122, v123\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[20:23], v[180:183], v[212:215], a[20:23]\n\t" \
+        "v_mul_f32 v76, %7, v76\n\t" \
+        "v_mul_f32 v77, %7, v77\n\t" \
+        "v_mul_f32 v78, %7, v78\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[84:87], v[196:199], v[228:231], a[84:87]\n\t" \
+        "v_mul_f32 v79, %7, v79\n\t" \
+        "v_mul_f32 v92, %7, v92\n\t" \
+        "v_mul_f32 v93, %7, v93\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[36:39], v[184:187], v[212:215], a[36:39]\n\t" \
+        "v_mul_f32 v94, %7, v94\n\t" \
+        "v_mul_f32 v95, %7, v95\n\t" \
+        "v_exp_f32 v76, v76\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[100:103], v[200:203], v[228:231], a[100:103]\n\t" \
+        "v_exp_f32 v77, v77\n\t" \
+        "v_exp_f32 v78, v78\n\t" \
+        "v_exp_f32 v79, v79\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[52:55], v[188:191], v[212:215], a[52:55]\n\t" \
+        "v_exp_f32 v92, v92\n\t" \
+        "v_exp_f32 v93, v93\n\t" \
+        "v_exp_f32 v94, v94\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[116:119], v[204:207], v[228:231], a[116:119]\n\t" \
+        "v_exp_f32 v95, v95\n\t" \
+        "v_mul_f32 v108, v76, v108\n\t" \
+        "v_mul_f32 v109, v77, v109\n\t" \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[8:11], v[176:179], v[216:219], a[8:11]\n\t" \
+        "v_mul_f32 v110, v78, v110\n\t" \
+        "v_mul_f32 v111, v79, v111\n\t" \
+        "v_mul_f32 v124, v92, v124\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[72:75], v[192:195], v[232:235], a[72:75]\n\t" \
+        "v_mul_f32 v125, v93, v125\n\t" \
+        "v_mul_f32 v126, v94, v126\n\t" \
+        "v_mul_f32 v127, v95, v127\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[24:27], v[180:183], v[216:219], a[24:27]\n\t" \
+        "v_cvt_pk_bf16_f32 v220, v76, v77\n\t" \
+        "v_cvt_pk_bf16_f32 v221, v78, v79\n\t" \
+        "v_cvt_pk_bf16_f32 v222, v92, v93\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[88:91], v[196:199], v[232:235], a[88:91]\n\t" \
+        "v_cvt_pk_bf16_f32 v223, v94, v95\n\t" \
+        "v_cvt_pk_bf16_f32 v236, v108, v109\n\t" \
+        "v_cvt_pk_bf16_f32 v237, v110, v111\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[40:43], v[184:187], v[216:219], a[40:43]\n\t" \
+        "v_cvt_pk_bf16_f32 v238, v124, v125\n\t" \
+        "v_cvt_pk_bf16_f32 v239, v126, v127\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[104:107], v[200:203], v[232:235], a[104:107]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[56:59], v[188:191], v[216:219], a[56:59]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[120:123], v[204:207], v[232:235], a[120:123]\n\t" \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[12:15], v[176:179], v[220:223], a[12:15]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[76:79], v[192:195], v[236:239], a[76:79]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[28:31], v[180:183], v[220:223], a[28:31]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[92:95], v[196:199], v[236:239], a[92:95]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[44:47], v[184:187], v[220:223], a[44:47]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[108:111], v[200:203], v[236:239], a[108:111]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[60:63], v[188:191], v[220:223], a[60:63]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[124:127], v[204:207], v[236:239], a[124:127]" \
+        : \
+        : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1), \
+          "v"(NLRD) \
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "memory")
+// generated by tools/gen/gen_dkdv4_body.py (register map and operand list there); 226 instructions
+#define RPO_D4_SLICE_BODY_HOT(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD) \
+    asm volatile( \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "ds_read_b64_tr_b16 v[176:177], %3 offset:4096\n\t" \
+        "ds_read_b64_tr_b16 v[178:179], %3 offset:6144\n\t" \
+        "ds_read_b64_tr_b16 v[192:193], %3\n\t" \
+        "ds_read_b64_tr_b16 v[194:195], %3 offset:2048\n\t" \
+        "ds_read_b64_tr_b16 v[180:181], %4 offset:4096\n\t" \
+        "ds_read_b64_tr_b16 v[182:183], %4 offset:6144\n\t" \
+        "ds_read_b64_tr_b16 v[196:197], %4\n\t" \
+        "ds_read_b64_tr_b16 v[198:199], %4 offset:2048\n\t" \
+        "ds_read_b64_tr_b16 v[184:185], %5 offset:4096\n\t" \
+        "ds_read_b64_tr_b16 v[186:187], %5 offset:6144\n\t" \
+        "ds_read_b64_tr_b16 v[200:201], %5\n\t" \
+        "ds_read_b64_tr_b16 v[202:203], %5 offset:2048\n\t" \
+        "ds_read_b64_tr_b16 v[188:189], %6 offset:4096\n\t" \
+        "ds_read_b64_tr_b16 v[190:191], %6 offset:6144\n\t" \
+        "ds_read_b64_tr_b16 v[204:205], %6\n\t" \
+        "ds_read_b64_tr_b16 v[206:207], %6 offset:2048\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[128:131], a[128:131], v[160:163]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[136:139], a[128:131], v[164:167]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[132:135], a[160:163], v[168:171]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[140:143], a[160:163], v[172:175]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[144:147], a[132:135], v[64:67]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[152:155], a[132:135], v[80:83]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[148:151], a[164:167], v[96:99]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[156:159], a[164:167], v[112:115]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[128:131], a[136:139], v[160:163]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[136:139], a[136:139], v[164:167]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[132:135], a[168:171], v[168:171]\n\t" \
+        "v_mul_f32 v64, %7, v64\n\t" \
+        "v_mul_f32 v65, %7, v65\n\t" \
+        "v_mul_f32 v66, %7, v66\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[140:143], a[168:171], v[172:175]\n\t" \
+        "v_mul_f32 v67, %7, v67\n\t" \
+        "v_mul_f32 v80, %7, v80\n\t" \
+        "v_mul_f32 v81, %7, v81\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[144:147], a[140:143], v[68:71]\n\t" \
+        "v_mul_f32 v82, %7, v82\n\t" \
+        "v_mul_f32 v83, %7, v83\n\t" \
+        "v_exp_f32 v64, v64\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[152:155], a[140:143], v[84:87]\n\t" \
+        "v_exp_f32 v65, v65\n\t" \
+        "v_exp_f32 v66, v66\n\t" \
+        "v_exp_f32 v67, v67\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[148:151], a[172:175], v[100:103]\n\t" \
+        "v_exp_f32 v80, v80\n\t" \
+        "v_exp_f32 v81, v81\n\t" \
+        "v_exp_f32 v82, v82\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[156:159], a[172:175], v[116:119]\n\t" \
+        "v_exp_f32 v83, v83\n\t" \
+        "v_mul_f32 v96, v64, v96\n\t" \
+        "v_mul_f32 v97, v65, v97\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[128:131], a[144:147], v[160:163]\n\t" \
+        "v_mul_f32 v98, v66, v98\n\t" \
+        "v_mul_f32 v99, v67, v99\n\t" \
+        "v_mul_f32 v112, v80, v112\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[136:139], a[144:147], v[164:167]\n\t" \
+        "v_mul_f32 v113, v81, v113\n\t" \
+        "v_mul_f32 v114, v82, v114\n\t" \
+        "v_mul_f32 v115, v83, v115\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[132:135], a[176:179], v[168:171]\n\t" \
+        "v_cvt_pk_bf16_f32 v208, v64, v65\n\t" \
+        "v_cvt_pk_bf16_f32 v209, v66, v67\n\t" \
+        "v_cvt_pk_bf16_f32 v210, v80, v81\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[140:143], a[176:179], v[172:175]\n\t" \
+        "v_cvt_pk_bf16_f32 v211, v82, v83\n\t" \
+        "v_cvt_pk_bf16_f32 v224, v96, v97\n\t" \
+        "v_cvt_pk_bf16_f32 v225, v98, v99\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[144:147], a[148:151], v[72:75]\n\t" \
+        "v_cvt_pk_bf16_f32 v226, v112, v113\n\t" \
+        "v_cvt_pk_bf16_f32 v227, v114, v115\n\t" \
+        "v_mul_f32 v68, %7, v68\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[152:155], a[148:151], v[88:91]\n\t" \
+        "v_mul_f32 v69, %7, v69\n\t" \
+        "v_mul_f32 v70, %7, v70\n\t" \
+        "v_mul_f32 v71, %7, v71\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[148:151], a[180:183], v[104:107]\n\t" \
+        "v_mul_f32 v84, %7, v84\n\t" \
+        "v_mul_f32 v85, %7, v85\n\t" \
+        "v_mul_f32 v86, %7, v86\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[156:159], a[180:183], v[120:123]\n\t" \
+        "v_mul_f32 v87, %7, v87\n\t" \
+        "v_exp_f32 v68, v68\n\t" \
+        "v_exp_f32 v69, v69\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[128:131], a[152:155], v[160:163]\n\t" \
+        "v_exp_f32 v70, v70\n\t" \
+        "v_exp_f32 v71, v71\n\t" \
+        "v_exp_f32 v84, v84\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[136:139], a[152:155], v[164:167]\n\t" \
+        "v_exp_f32 v85, v85\n\t" \
+        "v_exp_f32 v86, v86\n\t" \
+        "v_exp_f32 v87, v87\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[132:135], a[184:187], v[168:171]\n\t" \
+        "v_mul_f32 v100, v68, v100\n\t" \
+        "v_mul_f32 v101, v69, v101\n\t" \
+        "v_mul_f32 v102, v70, v102\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[140:143], a[184:187], v[172:175]\n\t" \
+        "v_mul_f32 v103, v71, v103\n\t" \
+        "v_mul_f32 v116, v84, v116\n\t" \
+        "v_mul_f32 v117, v85, v117\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[144:147], a[156:159], v[76:79]\n\t" \
+        "v_mul_f32 v118, v86, v118\n\t" \
+        "v_mul_f32 v119, v87, v119\n\t" \
+        "v_cvt_pk_bf16_f32 v212, v68, v69\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[152:155], a[156:159], v[92:95]\n\t" \
+        "v_cvt_pk_bf16_f32 v213, v70, v71\n\t" \
+        "v_cvt_pk_bf16_f32 v214, v84, v85\n\t" \
+        "v_cvt_pk_bf16_f32 v215, v86, v87\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[148:151], a[188:191], v[108:111]\n\t" \
+        "v_cvt_pk_bf16_f32 v228, v100, v101\n\t" \
+        "v_cvt_pk_bf16_f32 v229, v102, v103\n\t" \
+        "v_cvt_pk_bf16_f32 v230, v116, v117\n\t" \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[156:159], a[188:191], v[124:127]\n\t" \
+        "v_cvt_pk_bf16_f32 v231, v118, v119\n\t" \
+        "v_mul_f32 v72, %7, v72\n\t" \
+        "v_mul_f32 v73, %7, v73\n\t" \
+        "s_waitcnt lgkmcnt(0)\n\t" \
+        "ds_read_b128 v[160:163], %10\n\t" \
+        "ds_read_b128 v[168:171], %10 offset:128\n\t" \
+        "ds_read_b128 v[128:131], %8\n\t" \
+        "ds_read_b128 v[132:135], %8 offset:4096\n\t" \
+        "ds_read_b128 v[164:167], %10 offset:64\n\t" \
+        "ds_read_b128 v[172:175], %10 offset:192\n\t" \
+        "ds_read_b128 v[136:139], %8 offset:2048\n\t" \
+        "ds_read_b128 v[140:143], %8 offset:6144\n\t" \
+        "ds_read_b128 v[144:147], %9\n\t" \
+        "ds_read_b128 v[148:151], %9 offset:4096\n\t" \
+        "ds_read_b128 v[152:155], %9 offset:2048\n\t" \
+        "ds_read_b128 v[156:159], %9 offset:6144\n\t" \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[0:3], v[176:179], v[208:211], a[0:3]\n\t" \
+        "v_mul_f32 v74, %7, v74\n\t" \
+        "v_mul_f32 v75, %7, v75\n\t" \
+        "v_mul_f32 v88, %7, v88\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[64:67], v[192:195], v[224:227], a[64:67]\n\t" \
+        "v_mul_f32 v89, %7, v89\n\t" \
+        "v_mul_f32 v90, %7, v90\n\t" \
+        "v_mul_f32 v91, %7, v91\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[16:19], v[180:183], v[208:211], a[16:19]\n\t" \
+        "v_exp_f32 v72, v72\n\t" \
+        "v_exp_f32 v73, v73\n\t" \
+        "v_exp_f32 v74, v74\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[80:83], v[196:199], v[224:227], a[80:83]\n\t" \
+        "v_exp_f32 v75, v75\n\t" \
+        "v_exp_f32 v88, v88\n\t" \
+        "v_exp_f32 v89, v89\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[32:35], v[184:187], v[208:211], a[32:35]\n\t" \
+        "v_exp_f32 v90, v90\n\t" \
+        "v_exp_f32 v91, v91\n\t" \
+        "v_mul_f32 v104, v72, v104\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[96:99], v[200:203], v[224:227], a[96:99]\n\t" \
+        "v_mul_f32 v105, v73, v105\n\t" \
+        "v_mul_f32 v106, v74, v106\n\t" \
+        "v_mul_f32 v107, v75, v107\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[48:51], v[188:191], v[208:211], a[48:51]\n\t" \
+        "v_mul_f32 v120, v88, v120\n\t" \
+        "v_mul_f32 v121, v89, v121\n\t" \
+        "v_mul_f32 v122, v90, v122\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[112:115], v[204:207], v[224:227], a[112:115]\n\t" \
+        "v_mul_f32 v123, v91, v123\n\t" \
+        "v_cvt_pk_bf16_f32 v216, v72, v73\n\t" \
+        "v_cvt_pk_bf16_f32 v217, v74, v75\n\t" \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[4:7], v[176:179], v[212:215], a[4:7]\n\t" \
+        "v_cvt_pk_bf16_f32 v218, v88, v89\n\t" \
+        "v_cvt_pk_bf16_f32 v219, v90, v91\n\t" \
+        "v_cvt_pk_bf16_f32 v232, v104, v105\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[68:71], v[192:195], v[228:231], a[68:71]\n\t" \
+        "v_cvt_pk_bf16_f32 v233, v106, v107\n\t" \
+        "v_cvt_pk_bf16_f32 v234, v120, v121\n\t" \
+        "v_cvt_pk_bf16_f32 v235, v122, v123\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[20:23], v[180:183], v[212:215], a[20:23]\n\t" \
+        "v_mul_f32 v76, %7, v76\n\t" \
+        "v_mul_f32 v77, %7, v77\n\t" \
+        "v_mul_f32 v78, %7, v78\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[84:87], v[196:199], v[228:231], a[84:87]\n\t" \
+        "v_mul_f32 v79, %7, v79\n\t" \
+        "v_mul_f32 v92, %7, v92\n\t" \
+        "v_mul_f32 v93, %7, v93\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[36:39], v[184:187], v[212:215], a[36:39]\n\t" \
+        "v_mul_f32 v94, %7, v94\n\t" \
+        "v_mul_f32 v95, %7, v95\n\t" \
+        "v_exp_f32 v76, v76\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[100:103], v[200:203], v[228:231], a[100:103]\n\t" \
+        "v_exp_f32 v77, v77\n\t" \
+        "v_exp_f32 v78, v78\n\t" \
+        "v_exp_f32 v79, v79\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[52:55], v[188:191], v[212:215], a[52:55]\n\t" \
+        "v_exp_f32 v92, v92\n\t" \
+        "v_exp_f32 v93, v93\n\t" \
+        "v_exp_f32 v94, v94\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[116:119], v[204:207], v[228:231], a[116:119]\n\t" \
+        "v_exp_f32 v95, v95\n\t" \
+        "v_mul_f32 v108, v76, v108\n\t" \
+        "v_mul_f32 v109, v77, v109\n\t" \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[8:11], v[176:179], v[216:219], a[8:11]\n\t" \
+        "v_mul_f32 v110, v78, v110\n\t" \
+        "v_mul_f32 v111, v79, v111\n\t" \
+        "v_mul_f32 v124, v92, v124\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[72:75], v[192:195], v[232:235], a[72:75]\n\t" \
+        "v_mul_f32 v125, v93, v125\n\t" \
+        "v_mul_f32 v126, v94, v126\n\t" \
+        "v_mul_f32 v127, v95, v127\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[24:27], v[180:183], v[216:219], a[24:27]\n\t" \
+        "v_cvt_pk_bf16_f32 v220, v76, v77\n\t" \
+        "v_cvt_pk_bf16_f32 v221, v78, v79\n\t" \
+        "v_cvt_pk_bf16_f32 v222, v92, v93\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[88:91], v[196:199], v[232:235], a[88:91]\n\t" \
+        "v_cvt_pk_bf16_f32 v223, v94, v95\n\t" \
+        "v_cvt_pk_bf16_f32 v236, v108, v109\n\t" \
+        "v_cvt_pk_bf16_f32 v237, v110, v111\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[40:43], v[184:187], v[216:219], a[40:43]\n\t" \
+        "v_cvt_pk_bf16_f32 v238, v124, v125\n\t" \
+        "v_cvt_pk_bf16_f32 v239, v126, v127\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[104:107], v[200:203], v[232:235], a[104:107]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[56:59], v[188:191], v[216:219], a[56:59]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[120:123], v[204:207], v[232:235], a[120:123]\n\t" \
+        "s_nop 1\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[12:15], v[176:179], v[220:223], a[12:15]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[76:79], v[192:195], v[236:239], a[76:79]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[28:31], v[180:183], v[220:223], a[28:31]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[92:95], v[196:199], v[236:239], a[92:95]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[44:47], v[184:187], v[220:223], a[44:47]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[108:111], v[200:203], v[236:239], a[108:111]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[60:63], v[188:191], v[220:223], a[60:63]\n\t" \
+        "v_mfma_f32_16x16x32_bf16 a[124:127], v[204:207], v[236:239], a[124:127]" \
+        : \
+        : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1), \
+          "v"(NLRD) \
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "memory")
+
+__global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
+    const int* __restrict__ ktiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ nl,
+    const float* __restrict__ nd, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
+    int64_t sdv, int n_ktiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, fr = lane & 15;
+    const int per = (n_ktiles + 7) >> 3;
+    const int entry = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (entry >= n_ktiles) return;
+    const int seq = ktiles[3 * entry], hk = ktiles[3 * entry + 1], kb0 = ktiles[3 * entry + 2];
+    const int k0 = kb0 + 64 * wave;                        // this wave's 64 keys
+    const int group = nh / nkv;
+    const int64_t t0 = cu[seq];
+    const int len = cu[seq + 1] - (int)t0;
+    if (kb0 >= len) return;                                // padding entry of the table
+    const int qt0 = kb0;                                   // first query row that can see the block's keys (multiple of 32)
+    const int nsl = (len - qt0 + kSl - 1) / kSl;
+    const int niter = nsl * group;
+
+    short8_t bk[4][2], bv[4][2];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int key = k0 + 16 * n + fr;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bk[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(k + (t0 + key) * sk + hk * kFaHD + 32 * ks + 8 * g)
+                                  : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            bv[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(v + (t0 + key) * sv + hk * kFaHD + 32 * ks + 8 * g)
+                                  : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    // staging: wave w moves rows 8w .. 8w + 7 of the Q and of the dO slice (one 1-KiB DMA each; lane l carries row
+    // 8w + (l >> 3), physical chunk l & 7 = logical chunk (l & 7) ^ (row & 7)); wave 0 also moves the 64 row constants
+    // (lanes 0..31: -lse / scale, lanes 32..63: -delta).
+    const int srow = 8 * wave + (lane >> 3), lchunk = (lane & 7) ^ (lane >> 3);
+    const unsigned sqb = (unsigned)sq * 2u, sdob = (unsigned)sdo * 2u;
+    const float* rc_src = lane < 32 ? nl : nd;
+    auto stage = [&](int hq, int qb, int buf) {
+        char* base = smem + buf * kSlImg;
+        const char* qsrc = reinterpret_cast<const char*>(q + t0 * sq + hq * kFaHD);
+        const char* dsrc = reinterpret_cast<const char*>(dout + t0 * sdo + hq * kFaHD);
+        const unsigned row = (unsigned)min(qb + srow, len - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc + (row * sqb + lchunk * 16)),
+                                         (__attribute__((address_space(3))) void*)(base + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + (row * sdob + lchunk * 16)),
+                                         (__attribute__((address_space(3))) void*)(base + kSl * 128 + wave * 1024), 16, 0, 0);
+        if (wave == 0) {
+            const float* src = rc_src + (int64_t)hq * T + t0 + (unsigned)min(qb + (lane & 31), len - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + 2 * kSl * 128), 4, 0, 0);
+        }
+    };
+    // (q head, slice) of the next stage to issue, advanced incrementally
+    int st_h = hk * group, st_s = 0, st_buf = 0, st_n = 0;
+    auto stage_next = [&]() {
+        stage(st_h, qt0 + st_s * kSl, st_buf);
+        ++st_n;
+        st_buf = (st_buf + 1) & (kSlRing - 1);
+        if (++st_s == nsl) { st_s = 0; ++st_h; }
+    };
+#pragma unroll 1
+    for (int i = 0; i < kSlAhead && i < niter; ++i) stage_next();
+    // the K / V fragments move to a[128:191] (this also places hipcc's wait for their loads in front of the loop)
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bk[0][0]);
+        asm volatile("v_accvgpr_write_b32 a128, %0\n\tv_accvgpr_write_b32 a129, %1\n\t"
+                     "v_accvgpr_write_b32 a130, %2\n\tv_accvgpr_write_b32 a131, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a128", "a129", "a130", "a131");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bk[0][1]);
+        asm volatile("v_accvgpr_write_b32 a132, %0\n\tv_accvgpr_write_b32 a133, %1\n\t"
+                     "v_accvgpr_write_b32 a134, %2\n\tv_accvgpr_write_b32 a135, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a132", "a133", "a134", "a135");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bk[1][0]);
+        asm volatile("v_accvgpr_write_b32 a136, %0\n\tv_accvgpr_write_b32 a137, %1\n\t"
+                     "v_accvgpr_write_b32 a138, %2\n\tv_accvgpr_write_b32 a139, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a136", "a137", "a138", "a139");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bk[1][1]);
+        asm volatile("v_accvgpr_write_b32 a140, %0\n\tv_accvgpr_write_b32 a141, %1\n\t"
+                     "v_accvgpr_write_b32 a142, %2\n\tv_accvgpr_write_b32 a143, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a140", "a141", "a142", "a143");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bk[2][0]);
+        asm volatile("v_accvgpr_write_b32 a144, %0\n\tv_accvgpr_write_b32 a145, %1\n\t"
+                     "v_accvgpr_write_b32 a146, %2\n\tv_accvgpr_write_b32 a147, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a144", "a145", "a146", "a147");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bk[2][1]);
+        asm volatile("v_accvgpr_write_b32 a148, %0\n\tv_accvgpr_write_b32 a149, %1\n\t"
+                     "v_accvgpr_write_b32 a150, %2\n\tv_accvgpr_write_b32 a151, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a148", "a149", "a150", "a151");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bk[3][0]);
+        asm volatile("v_accvgpr_write_b32 a152, %0\n\tv_accvgpr_write_b32 a153, %1\n\t"
+                     "v_accvgpr_write_b32 a154, %2\n\tv_accvgpr_write_b32 a155, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a152", "a153", "a154", "a155");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bk[3][1]);
+        asm volatile("v_accvgpr_write_b32 a156, %0\n\tv_accvgpr_write_b32 a157, %1\n\t"
+                     "v_accvgpr_write_b32 a158, %2\n\tv_accvgpr_write_b32 a159, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a156", "a157", "a158", "a159");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bv[0][0]);
+        asm volatile("v_accvgpr_write_b32 a160, %0\n\tv_accvgpr_write_b32 a161, %1\n\t"
+                     "v_accvgpr_write_b32 a162, %2\n\tv_accvgpr_write_b32 a163, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a160", "a161", "a162", "a163");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bv[0][1]);
+        asm volatile("v_accvgpr_write_b32 a164, %0\n\tv_accvgpr_write_b32 a165, %1\n\t"
+                     "v_accvgpr_write_b32 a166, %2\n\tv_accvgpr_write_b32 a167, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a164", "a165", "a166", "a167");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bv[1][0]);
+        asm volatile("v_accvgpr_write_b32 a168, %0\n\tv_accvgpr_write_b32 a169, %1\n\t"
+                     "v_accvgpr_write_b32 a170, %2\n\tv_accvgpr_write_b32 a171, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a168", "a169", "a170", "a171");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bv[1][1]);
+        asm volatile("v_accvgpr_write_b32 a172, %0\n\tv_accvgpr_write_b32 a173, %1\n\t"
+                     "v_accvgpr_write_b32 a174, %2\n\tv_accvgpr_write_b32 a175, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a172", "a173", "a174", "a175");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bv[2][0]);
+        asm volatile("v_accvgpr_write_b32 a176, %0\n\tv_accvgpr_write_b32 a177, %1\n\t"
+                     "v_accvgpr_write_b32 a178, %2\n\tv_accvgpr_write_b32 a179, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a176", "a177", "a178", "a179");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bv[2][1]);
+        asm volatile("v_accvgpr_write_b32 a180, %0\n\tv_accvgpr_write_b32 a181, %1\n\t"
+                     "v_accvgpr_write_b32 a182, %2\n\tv_accvgpr_write_b32 a183, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a180", "a181", "a182", "a183");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bv[3][0]);
+        asm volatile("v_accvgpr_write_b32 a184, %0\n\tv_accvgpr_write_b32 a185, %1\n\t"
+                     "v_accvgpr_write_b32 a186, %2\n\tv_accvgpr_write_b32 a187, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a184", "a185", "a186", "a187");
+    }
+    {
+        const uint4_t w_ = __builtin_bit_cast(uint4_t, bv[3][1]);
+        asm volatile("v_accvgpr_write_b32 a188, %0\n\tv_accvgpr_write_b32 a189, %1\n\t"
+                     "v_accvgpr_write_b32 a190, %2\n\tv_accvgpr_write_b32 a191, %3"
+                     :
+                     : "v"(w_[0]), "v"(w_[1]), "v"(w_[2]), "v"(w_[3])
+                     : "a188", "a189", "a190", "a191");
+    }
+    // dK^T / dV^T accumulators: a[0:127], zeroed here (AGPR map in the comment above the kernel)
+    asm volatile(
+        "v_accvgpr_write_b32 a0, 0\n\t"
+        "v_accvgpr_write_b32 a1, 0\n\t"
+        "v_accvgpr_write_b32 a2, 0\n\t"
+        "v_accvgpr_write_b32 a3, 0\n\t"
+        "v_accvgpr_write_b32 a4, 0\n\t"
+        "v_accvgpr_write_b32 a5, 0\n\t"
+        "v_accvgpr_write_b32 a6, 0\n\t"
+        "v_accvgpr_write_b32 a7, 0\n\t"
+        "v_accvgpr_write_b32 a8, 0\n\t"
+        "v_accvgpr_write_b32 a9, 0\n\t"
+        "v_accvgpr_write_b32 a10, 0\n\t"
+        "v_accvgpr_write_b32 a11, 0\n\t"
+        "v_accvgpr_write_b32 a12, 0\n\t"
+        "v_accvgpr_write_b32 a13, 0\n\t"
+        "v_accvgpr_write_b32 a14, 0\n\t"
+        "v_accvgpr_write_b32 a15, 0\n\t"
+        "v_accvgpr_write_b32 a16, 0\n\t"
+        "v_accvgpr_write_b32 a17, 0\n\t"
+        "v_accvgpr_write_b32 a18, 0\n\t"
+        "v_accvgpr_write_b32 a19, 0\n\t"
+        "v_accvgpr_write_b32 a20, 0\n\t"
+        "v_accvgpr_write_b32 a21, 0\n\t"
+        "v_accvgpr_write_b32 a22, 0\n\t"
+        "v_accvgpr_write_b32 a23, 0\n\t"
+        "v_accvgpr_write_b32 a24, 0\n\t"
+        "v_accvgpr_write_b32 a25, 0\n\t"
+        "v_accvgpr_write_b32 a26, 0\n\t"
+        "v_accvgpr_write_b32 a27, 0\n\t"
+        "v_accvgpr_write_b32 a28, 0\n\t"
+        "v_accvgpr_write_b32 a29, 0\n\t"
+        "v_accvgpr_write_b32 a30, 0\n\t"
+        "v_accvgpr_write_b32 a31, 0\n\t"
+        "v_accvgpr_write_b32 a32, 0\n\t"
+        "v_accvgpr_write_b32 a33, 0\n\t"
+        "v_accvgpr_write_b32 a34, 0\n\t"
+        "v_accvgpr_write_b32 a35, 0\n\t"
+        "v_accvgpr_write_b32 a36, 0\n\t"
+        "v_accvgpr_write_b32 a37, 0\n\t"
+        "v_accvgpr_write_b32 a38, 0\n\t"
+        "v_accvgpr_write_b32 a39, 0\n\t"
+        "v_accvgpr_write_b32 a40, 0\n\t"
+        "v_accvgpr_write_b32 a41, 0\n\t"
+        "v_accvgpr_write_b32 a42, 0\n\t"
+        "v_accvgpr_write_b32 a43, 0\n\t"
+        "v_accvgpr_write_b32 a44, 0\n\t"
+        "v_accvgpr_write_b32 a45, 0\n\t"
+        "v_accvgpr_write_b32 a46, 0\n\t"
+        "v_accvgpr_write_b32 a47, 0\n\t"
+        "v_accvgpr_write_b32 a48, 0\n\t"
+        "v_accvgpr_write_b32 a49, 0\n\t"
+        "v_accvgpr_write_b32 a50, 0\n\t"
+        "v_accvgpr_write_b32 a51, 0\n\t"
+        "v_accvgpr_write_b32 a52, 0\n\t"
+        "v_accvgpr_write_b32 a53, 0\n\t"
+        "v_accvgpr_write_b32 a54, 0\n\t"
+        "v_accvgpr_write_b32 a55, 0\n\t"
+        "v_accvgpr_write_b32 a56, 0\n\t"
+        "v_accvgpr_write_b32 a57, 0\n\t"
+        "v_accvgpr_write_b32 a58, 0\n\t"
+        "v_accvgpr_write_b32 a59, 0\n\t"
+        "v_accvgpr_write_b32 a60, 0\n\t"
+        "v_accvgpr_write_b32 a61, 0\n\t"
+        "v_accvgpr_write_b32 a62, 0\n\t"
+        "v_accvgpr_write_b32 a63, 0\n\t"
+        "v_accvgpr_write_b32 a64, 0\n\t"
+        "v_accvgpr_write_b32 a65, 0\n\t"
+        "v_accvgpr_write_b32 a66, 0\n\t"
+        "v_accvgpr_write_b32 a67, 0\n\t"
+        "v_accvgpr_write_b32 a68, 0\n\t"
+        "v_accvgpr_write_b32 a69, 0\n\t"
+        "v_accvgpr_write_b32 a70, 0\n\t"
+        "v_accvgpr_write_b32 a71, 0\n\t"
+        "v_accvgpr_write_b32 a72, 0\n\t"
+        "v_accvgpr_write_b32 a73, 0\n\t"
+        "v_accvgpr_write_b32 a74, 0\n\t"
+        "v_accvgpr_write_b32 a75, 0\n\t"
+        "v_accvgpr_write_b32 a76, 0\n\t"
+        "v_accvgpr_write_b32 a77, 0\n\t"
+        "v_accvgpr_write_b32 a78, 0\n\t"
+        "v_accvgpr_write_b32 a79, 0\n\t"
+        "v_accvgpr_write_b32 a80, 0\n\t"
+        "v_accvgpr_write_b32 a81, 0\n\t"
+        "v_accvgpr_write_b32 a82, 0\n\t"
+        "v_accvgpr_write_b32 a83, 0\n\t"
+        "v_accvgpr_write_b32 a84, 0\n\t"
+        "v_accvgpr_write_b32 a85, 0\n\t"
+        "v_accvgpr_write_b32 a86, 0\n\t"
+        "v_accvgpr_write_b32 a87, 0\n\t"
+        "v_accvgpr_write_b32 a88, 0\n\t"
+        "v_accvgpr_write_b32 a89, 0\n\t"
+        "v_accvgpr_write_b32 a90, 0\n\t"
+        "v_accvgpr_write_b32 a91, 0\n\t"
+        "v_accvgpr_write_b32 a92, 0\n\t"
+        "v_accvgpr_write_b32 a93, 0\n\t"
+        "v_accvgpr_write_b32 a94, 0\n\t"
+        "v_accvgpr_write_b32 a95, 0\n\t"
+        "v_accvgpr_write_b32 a96, 0\n\t"
+        "v_accvgpr_write_b32 a97, 0\n\t"
+        "v_accvgpr_write_b32 a98, 0\n\t"
+        "v_accvgpr_write_b32 a99, 0\n\t"
+        "v_accvgpr_write_b32 a100, 0\n\t"
+        "v_accvgpr_write_b32 a101, 0\n\t"
+        "v_accvgpr_write_b32 a102, 0\n\t"
+        "v_accvgpr_write_b32 a103, 0\n\t"
+        "v_accvgpr_write_b32 a104, 0\n\t"
+        "v_accvgpr_write_b32 a105, 0\n\t"
+        "v_accvgpr_write_b32 a106, 0\n\t"
+        "v_accvgpr_write_b32 a107, 0\n\t"
+        "v_accvgpr_write_b32 a108, 0\n\t"
+        "v_accvgpr_write_b32 a109, 0\n\t"
+        "v_accvgpr_write_b32 a110, 0\n\t"
+        "v_accvgpr_write_b32 a111, 0\n\t"
+        "v_accvgpr_write_b32 a112, 0\n\t"
+        "v_accvgpr_write_b32 a113, 0\n\t"
+        "v_accvgpr_write_b32 a114, 0\n\t"
+        "v_accvgpr_write_b32 a115, 0\n\t"
+        "v_accvgpr_write_b32 a116, 0\n\t"
+        "v_accvgpr_write_b32 a117, 0\n\t"
+        "v_accvgpr_write_b32 a118, 0\n\t"
+        "v_accvgpr_write_b32 a119, 0\n\t"
+        "v_accvgpr_write_b32 a120, 0\n\t"
+        "v_accvgpr_write_b32 a121, 0\n\t"
+        "v_accvgpr_write_b32 a122, 0\n\t"
+        "v_accvgpr_write_b32 a123, 0\n\t"
+        "v_accvgpr_write_b32 a124, 0\n\t"
+        "v_accvgpr_write_b32 a125, 0\n\t"
+        "v_accvgpr_write_b32 a126, 0\n\t"
+        "v_accvgpr_write_b32 a127, 0"
+        :
+        :
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+    const int qq = fr >> 2, pp = fr & 3;
+    const int xs = (pp >> 1) ^ (4 * (g & 1) + qq);
+    unsigned tr_off[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tr_off[c] = (4 * g + qq) * 128 + (((2 * c) ^ xs) << 4) + 8 * (pp & 1);
+    unsigned row_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) row_off[ks] = fr * 128 + (((4 * ks + g) ^ (fr & 7)) << 4);
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const int per_stage = wave == 0 ? 3 : 2;               // DMA instructions this wave issues per slice
+
+    // Loop: one raw barrier per slice, slice it + 4 issued behind it, then
+    //   common case (slice fully visible to the wave's keys, no masking): RPO_D4_SLICE_BODY_*, ONE hand-placed instruction
+    //   stream = M1 key-tile major, the exp2 / dS arithmetic of key tile n in the issue gaps of the MFMAs that follow its
+    //   chains, M2 key-tile major behind it, and the LDS reads of the NEXT slice's row operands under M2;
+    //   diagonal / last slices: the same steps as separate statements with hipcc's code for the masked arithmetic.
+    // hipcc must not spill into a[0:191] (it does not know them to be occupied): its resource line must show 0 scratch, and
+    // any v_accvgpr_* outside ASMSTART / ASMEND may only name a192 and up.
+    auto wait_landed = [&](int upto) {                        // every stage <= upto of THIS wave has landed
+        const int later = (st_n - 1 - upto) * per_stage;     // DMA instructions issued after it: 0 .. 9
+        if (later >= 9) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        else if (later == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (later == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (later == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else if (later == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    bool hot = false;      // v[128:175] hold the row fragments / row constants of slice `it` (prefetched by the previous body)
+    int cur = 0, sl = 0;
+    for (int it = 0; it < niter; ++it) {
+        // slices <= it + 1 have landed (the body prefetches from the next image).  Steady state (slices still being staged):
+        // exactly two later stages are in flight, one compare instead of the general ladder
+        if (st_n < niter) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            wait_landed(it + 1 < niter ? it + 1 : it);
+        }
+        __builtin_amdgcn_s_barrier();
+        if (st_n < niter) stage_next();                      // slice it + 4 -> the image of slice it - 4
+        const int qb = qt0 + sl * kSl;
+        const bool active = (qb + kSl - 1 >= k0) && (k0 < len);
+        const bool need_mask = (qb < k0 + 63) || (qb + kSl > len) || (k0 + 64 > len);
+        const unsigned img = smem_base + cur * kSlImg;
+        const unsigned next_img = smem_base + ((cur + 1) & (kSlRing - 1)) * kSlImg;
+        if (active && !need_mask) {
+            if (hot)
+                RPO_D4_SLICE_BODY_HOT(img + row_off[0], img + row_off[1], img + 2 * kSl * 128 + 16 * g, img + tr_off[0],
+                                      img + tr_off[1], img + tr_off[2], img + tr_off[3], scale_log2e,
+                                      next_img + row_off[0], next_img + row_off[1], next_img + 2 * kSl * 128 + 16 * g);
+            else
+                RPO_D4_SLICE_BODY_LOAD(img + row_off[0], img + row_off[1], img + 2 * kSl * 128 + 16 * g, img + tr_off[0],
+                                       img + tr_off[1], img + tr_off[2], img + tr_off[3], scale_log2e,
+                                       next_img + row_off[0], next_img + row_off[1], next_img + 2 * kSl * 128 + 16 * g);
+            hot = true;
+        } else if (active) {
+            hot = false;
+            // M1: S' = Q K^T - lse / scale, dP' = dO V^T - delta (row constants = initial accumulators)
+            float4_t s[2][4], dp[2][4];                       // rows = queries 16 m + 4 g + r, col = key 16 n + fr
+            const char* Qs = smem + cur * kSlImg;
+            const char* Ds = Qs + kSl * 128;
+            const float* Ls = reinterpret_cast<const float*>(Qs + 2 * kSl * 128);
+            const short8_t aq00 = *reinterpret_cast<const short8_t*>(Qs + row_off[0]);
+            const short8_t ad00 = *reinterpret_cast<const short8_t*>(Ds + row_off[0]);
+            const float4_t lr0 = *reinterpret_cast<const float4_t*>(Ls + 4 * g);
+            const float4_t dr0 = *reinterpret_cast<const float4_t*>(Ls + kSl + 4 * g);
+            const short8_t aq01 = *reinterpret_cast<const short8_t*>(Qs + row_off[0] + 2048);
+            const short8_t ad01 = *reinterpret_cast<const short8_t*>(Ds + row_off[0] + 2048);
+            const float4_t lr1 = *reinterpret_cast<const float4_t*>(Ls + 16 + 4 * g);
+            const float4_t dr1 = *reinterpret_cast<const float4_t*>(Ls + kSl + 16 + 4 * g);
+            const short8_t aq10 = *reinterpret_cast<const short8_t*>(Qs + row_off[1]);
+            const short8_t ad10 = *reinterpret_cast<const short8_t*>(Ds + row_off[1]);
+            const short8_t aq11 = *reinterpret_cast<const short8_t*>(Qs + row_off[1] + 2048);
+            const short8_t ad11 = *reinterpret_cast<const short8_t*>(Ds + row_off[1] + 2048);
+            // transposed fragments of the slice (A operands of M2): dO^T at image offset 4096, queries 16..31 at + 2048
+            u32x2 d0, d1, d2, d3, d4, d5, d6, d7, e0, e1, e2, e3, e4, e5, e6, e7;
+            {
+                const unsigned a0 = img + tr_off[0], a1 = img + tr_off[1], a2 = img + tr_off[2], a3 = img + tr_off[3];
+                RPO_TR2(d0, d1, a0, 4096, 6144);
+                RPO_TR2(d2, d3, a1, 4096, 6144);
+                RPO_TR2(d4, d5, a2, 4096, 6144);
+                RPO_TR2(d6, d7, a3, 4096, 6144);
+                RPO_TR2(e0, e1, a0, 0, 2048);
+                RPO_TR2(e2, e3, a1, 0, 2048);
+                RPO_TR2(e4, e5, a2, 0, 2048);
+                RPO_TR2(e6, e7, a3, 0, 2048);
+            }
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                s[0][n] = lr0;
+                dp[0][n] = dr0;
+                s[1][n] = lr1;
+                dp[1][n] = dr1;
+            }
+            RPO_D4_M1_KS0(0, aq00, ad00);
+            RPO_D4_M1_KS0(1, aq01, ad01);
+            RPO_D4_M1_KS1(0, aq10, ad10);
+            RPO_D4_M1_KS1(1, aq11, ad11);
+            // an MFMA result is readable by the VALU 12 states after issue
+            asm volatile("s_nop 11"
+                         : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[0][2]), "+v"(s[0][3]), "+v"(s[1][0]), "+v"(s[1][1]),
+                           "+v"(s[1][2]), "+v"(s[1][3]), "+v"(dp[0][0]), "+v"(dp[0][1]), "+v"(dp[0][2]), "+v"(dp[0][3]),
+                           "+v"(dp[1][0]), "+v"(dp[1][1]), "+v"(dp[1][2]), "+v"(dp[1][3]));
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const int qr0 = qb + 16 * m + 4 * g;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) {
+                    const int key = k0 + 16 * n + fr;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
+                        pv = (key > qr0 + r || key >= len || qr0 + r >= len) ? 0.f : pv;      // select, no branch
+                        s[m][n][r] = pv;
+                        dp[m][n][r] = pv * dp[m][n][r];
+                    }
+                }
+            }
+            short8_t pf[4], dsf[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                pf[n] = pack_frag(s[0][n], s[1][n]);      // k-slots = queries {4g + j, 16 + 4g + (j - 4)} of the slice
+                dsf[n] = pack_frag(dp[0][n], dp[1][n]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(e0),
+                           "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7)
+                         :
+                         : "memory");
+            const short8_t atd[4] = {join_tr(d0, d1), join_tr(d2, d3), join_tr(d4, d5), join_tr(d6, d7)};
+            const short8_t atq[4] = {join_tr(e0, e1), join_tr(e2, e3), join_tr(e4, e5), join_tr(e6, e7)};
+            RPO_D4_M2_N0(atd, atq, pf, dsf);
+            RPO_D4_M2_N1(atd, atq, pf, dsf);
+            RPO_D4_M2_N2(atd, atq, pf, dsf);
+            RPO_D4_M2_N3(atd, atq, pf, dsf);
+        } else {
+            hot = false;
+        }
+        cur = (cur + 1) & (kSlRing - 1);
+        if (++sl == nsl) sl = 0;
+    }
+    // epilogue: dK[key][16 c + 4 g + r] = scale * dka, dV likewise (unscaled); the wave owns its keys: no reduction
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last MFMAs' results are readable
+    float4_t dka[4][4], dva[4][4];
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a0\n\tv_accvgpr_read_b32 %1, a1\n\t"
+                     "v_accvgpr_read_b32 %2, a2\n\tv_accvgpr_read_b32 %3, a3"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[0][0] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a64\n\tv_accvgpr_read_b32 %1, a65\n\t"
+                     "v_accvgpr_read_b32 %2, a66\n\tv_accvgpr_read_b32 %3, a67"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[0][0] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a4\n\tv_accvgpr_read_b32 %1, a5\n\t"
+                     "v_accvgpr_read_b32 %2, a6\n\tv_accvgpr_read_b32 %3, a7"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[0][1] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a68\n\tv_accvgpr_read_b32 %1, a69\n\t"
+                     "v_accvgpr_read_b32 %2, a70\n\tv_accvgpr_read_b32 %3, a71"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[0][1] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a8\n\tv_accvgpr_read_b32 %1, a9\n\t"
+                     "v_accvgpr_read_b32 %2, a10\n\tv_accvgpr_read_b32 %3, a11"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[0][2] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a72\n\tv_accvgpr_read_b32 %1, a73\n\t"
+                     "v_accvgpr_read_b32 %2, a74\n\tv_accvgpr_read_b32 %3, a75"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[0][2] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a12\n\tv_accvgpr_read_b32 %1, a13\n\t"
+                     "v_accvgpr_read_b32 %2, a14\n\tv_accvgpr_read_b32 %3, a15"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[0][3] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a76\n\tv_accvgpr_read_b32 %1, a77\n\t"
+                     "v_accvgpr_read_b32 %2, a78\n\tv_accvgpr_read_b32 %3, a79"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[0][3] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a16\n\tv_accvgpr_read_b32 %1, a17\n\t"
+                     "v_accvgpr_read_b32 %2, a18\n\tv_accvgpr_read_b32 %3, a19"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[1][0] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a80\n\tv_accvgpr_read_b32 %1, a81\n\t"
+                     "v_accvgpr_read_b32 %2, a82\n\tv_accvgpr_read_b32 %3, a83"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[1][0] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a20\n\tv_accvgpr_read_b32 %1, a21\n\t"
+                     "v_accvgpr_read_b32 %2, a22\n\tv_accvgpr_read_b32 %3, a23"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[1][1] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a84\n\tv_accvgpr_read_b32 %1, a85\n\t"
+                     "v_accvgpr_read_b32 %2, a86\n\tv_accvgpr_read_b32 %3, a87"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[1][1] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a24\n\tv_accvgpr_read_b32 %1, a25\n\t"
+                     "v_accvgpr_read_b32 %2, a26\n\tv_accvgpr_read_b32 %3, a27"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[1][2] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a88\n\tv_accvgpr_read_b32 %1, a89\n\t"
+                     "v_accvgpr_read_b32 %2, a90\n\tv_accvgpr_read_b32 %3, a91"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[1][2] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a28\n\tv_accvgpr_read_b32 %1, a29\n\t"
+                     "v_accvgpr_read_b32 %2, a30\n\tv_accvgpr_read_b32 %3, a31"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[1][3] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a92\n\tv_accvgpr_read_b32 %1, a93\n\t"
+                     "v_accvgpr_read_b32 %2, a94\n\tv_accvgpr_read_b32 %3, a95"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[1][3] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a32\n\tv_accvgpr_read_b32 %1, a33\n\t"
+                     "v_accvgpr_read_b32 %2, a34\n\tv_accvgpr_read_b32 %3, a35"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[2][0] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a96\n\tv_accvgpr_read_b32 %1, a97\n\t"
+                     "v_accvgpr_read_b32 %2, a98\n\tv_accvgpr_read_b32 %3, a99"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[2][0] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a36\n\tv_accvgpr_read_b32 %1, a37\n\t"
+                     "v_accvgpr_read_b32 %2, a38\n\tv_accvgpr_read_b32 %3, a39"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[2][1] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a100\n\tv_accvgpr_read_b32 %1, a101\n\t"
+                     "v_accvgpr_read_b32 %2, a102\n\tv_accvgpr_read_b32 %3, a103"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[2][1] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a40\n\tv_accvgpr_read_b32 %1, a41\n\t"
+                     "v_accvgpr_read_b32 %2, a42\n\tv_accvgpr_read_b32 %3, a43"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[2][2] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a104\n\tv_accvgpr_read_b32 %1, a105\n\t"
+                     "v_accvgpr_read_b32 %2, a106\n\tv_accvgpr_read_b32 %3, a107"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[2][2] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a44\n\tv_accvgpr_read_b32 %1, a45\n\t"
+                     "v_accvgpr_read_b32 %2, a46\n\tv_accvgpr_read_b32 %3, a47"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[2][3] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a108\n\tv_accvgpr_read_b32 %1, a109\n\t"
+                     "v_accvgpr_read_b32 %2, a110\n\tv_accvgpr_read_b32 %3, a111"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[2][3] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a48\n\tv_accvgpr_read_b32 %1, a49\n\t"
+                     "v_accvgpr_read_b32 %2, a50\n\tv_accvgpr_read_b32 %3, a51"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[3][0] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a112\n\tv_accvgpr_read_b32 %1, a113\n\t"
+                     "v_accvgpr_read_b32 %2, a114\n\tv_accvgpr_read_b32 %3, a115"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[3][0] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a52\n\tv_accvgpr_read_b32 %1, a53\n\t"
+                     "v_accvgpr_read_b32 %2, a54\n\tv_accvgpr_read_b32 %3, a55"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[3][1] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a116\n\tv_accvgpr_read_b32 %1, a117\n\t"
+                     "v_accvgpr_read_b32 %2, a118\n\tv_accvgpr_read_b32 %3, a119"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[3][1] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a56\n\tv_accvgpr_read_b32 %1, a57\n\t"
+                     "v_accvgpr_read_b32 %2, a58\n\tv_accvgpr_read_b32 %3, a59"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[3][2] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a120\n\tv_accvgpr_read_b32 %1, a121\n\t"
+                     "v_accvgpr_read_b32 %2, a122\n\tv_accvgpr_read_b32 %3, a123"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[3][2] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a60\n\tv_accvgpr_read_b32 %1, a61\n\t"
+                     "v_accvgpr_read_b32 %2, a62\n\tv_accvgpr_read_b32 %3, a63"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dva[3][3] = float4_t{f0_, f1_, f2_, f3_};
+    }
+    {
+        float f0_, f1_, f2_, f3_;
+        asm volatile("v_accvgpr_read_b32 %0, a124\n\tv_accvgpr_read_b32 %1, a125\n\t"
+                     "v_accvgpr_read_b32 %2, a126\n\tv_accvgpr_read_b32 %3, a127"
+                     : "=v"(f0_), "=v"(f1_), "=v"(f2_), "=v"(f3_));
+        dka[3][3] = float4_t{f0_, f1_, f2_, f3_};
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int key = k0 + 16 * n + fr;
+        if (key >= len) continue;
+        bf16_t* krow = dk + (t0 + key) * sdk + hk * kFaHD + 4 * g;
+        bf16_t* vrow = dv + (t0 + key) * sdv + hk * kFaHD + 4 * g;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint2 w;
+            w.x = pack_bf16(dka[c][n][0] * scale, dka[c][n][1] * scale);
+            w.y = pack_bf16(dka[c][n][2] * scale, dka[c][n][3] * scale);
+            *reinterpret_cast<uint2*>(krow + 16 * c) = w;
+            w.x = pack_bf16(dva[c][n][0], dva[c][n][1]);
+            w.y = pack_bf16(dva[c][n][2], dva[c][n][3]);
+            *reinterpret_cast<uint2*>(vrow + 16 * c) = w;
+        }
+    }
+}
+
 }  // namespace
 
 #ifdef RPO_FA_STAMP
@@ -835,14 +2137,26 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
     const unsigned dkdv_grid = (unsigned)(((n_k_tiles + 7) / 8) * 8);
+    static const bool use_v1 = [] {                           // RPO_FA_DKDV=v1: the 8-wave kernel (A/B)
+        const char* e = getenv("RPO_FA_DKDV");
+        return e && !strcmp(e, "v1");
+    }();
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds);
+        (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDkdv4Lds);
         return true;
     }();
     (void)attr_set;
-    RPO_LAUNCH(fa_bwd_dkdv_kernel, dim3(dkdv_grid), dim3(kFaDkdvThreads), kDmaLds, st, (const bf16_t*)q, (const bf16_t*)k,
-               (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
-               (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
-               (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles);
+    if (use_v1) {
+        RPO_LAUNCH(fa_bwd_dkdv_kernel, dim3(dkdv_grid), dim3(kFaDkdvThreads), kDmaLds, st, (const bf16_t*)q, (const bf16_t*)k,
+                   (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
+                   (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
+                   (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles);
+    } else {
+        RPO_LAUNCH(fa_bwd_dkdv4_kernel, dim3(dkdv_grid), dim3(256), kDkdv4Lds, st, (const bf16_t*)q, (const bf16_t*)k,
+                   (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
+                   (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
+                   (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles);
+    }
     return rpo_launch_status();
 }

@@ -457,16 +457,40 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
     return out, lse
 
 
-def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 64):
-    """int32 [n, 3] = (sequence id, kv head, first key of a 64-key tile), sorted by (sequence, head, key): key tiles of one
-    (sequence, kv head) read the same Q / dO rows and are placed on one XCD by the kernel's block -> entry map."""
+def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 0):
+    """int32 [n, 3] = (sequence id, kv head, first key of a key block), sorted by (sequence, head, key): the key blocks of one
+    (sequence, kv head) read the same Q / dO rows and are placed on one XCD by the kernel's block -> entry map.  Block =
+    256 keys (the one-wave-per-SIMD dK/dV kernel); 64 when RPO_FA_DKDV=v1 selects the 8-wave kernel (A/B)."""
+    import os
+    if block_n <= 0:
+        block_n = 64 if os.environ.get("RPO_FA_DKDV") == "v1" else 256
     import numpy as np
-    parts = []
-    for s, n in enumerate(lens):
-        k0 = np.arange(0, n, block_n, dtype=np.int32)
+    if block_n != 256:
+        parts = []
+        for s, n in enumerate(lens):
+            k0 = np.arange(0, n, block_n, dtype=np.int32)
+            for h in range(num_kv_heads):
+                parts.append(np.stack([np.full_like(k0, s), np.full_like(k0, h), k0], 1))
+        return torch.from_numpy(np.concatenate(parts, 0)).to(device, non_blocking=True)
+    # The kernel gives XCD x (blocks x, x + 8, ...) the x-th eighth of the table, in order.  One workgroup per CU and work
+    # per block ~ (len - first key): balance the eighths (longest (sequence, head) groups first, each to the least loaded
+    # XCD), keep a group's blocks adjacent (they share Q / dO rows in that XCD's L2), heaviest block first, and pad the
+    # eighths to equal length with entries whose first key lies past every sequence (such a workgroup exits at once).
+    groups = sorted(((n, s) for s, n in enumerate(lens)), reverse=True)
+    load, chunks = [0.0] * 8, [[] for _ in range(8)]
+    for n, s in groups:
         for h in range(num_kv_heads):
-            parts.append(np.stack([np.full_like(k0, s), np.full_like(k0, h), k0], 1))
-    return torch.from_numpy(np.concatenate(parts, 0)).to(device, non_blocking=True)
+            x = min(range(8), key=load.__getitem__)
+            k0 = np.arange(0, n, block_n, dtype=np.int32)
+            load[x] += float((n - k0).sum())
+            chunks[x].append(np.stack([np.full_like(k0, s), np.full_like(k0, h), k0], 1))
+    per = max(sum(len(c) for c in ch) for ch in chunks)
+    pad = np.array([[0, 0, 1 << 30]], dtype=np.int32)
+    out = []
+    for ch in chunks:
+        rows = np.concatenate(ch, 0) if ch else np.zeros((0, 3), np.int32)
+        out.append(np.concatenate([rows, np.repeat(pad, per - len(rows), 0)], 0))
+    return torch.from_numpy(np.concatenate(out, 0)).to(device, non_blocking=True)
 
 
 def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale, grads=None):

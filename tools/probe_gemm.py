@@ -36,8 +36,12 @@ for name, k, n in shapes:
     t_f = bench(lambda: torch.nn.functional.linear(x, w))
     t_d = bench(lambda: gy @ w)
     t_w = bench(lambda: gy.t() @ x)
+    t_w2 = bench(lambda: (x.t() @ gy).t())                 # same product, the other operand order (result is a view)
+    out_w = torch.empty(n, k, device=dev, dtype=torch.bfloat16)
+    t_w3 = bench(lambda: torch.mm(gy.t(), x, out=out_w))
     tot += t_f + t_d + t_w
     print(f"{name:8s} T={T} k={k} n={n}: fwd {t_f*1e3:7.3f} ms {fl/t_f/1e12:7.1f} TF | dgrad {t_d*1e3:7.3f} ms "
-          f"{fl/t_d/1e12:7.1f} TF | wgrad {t_w*1e3:7.3f} ms {fl/t_w/1e12:7.1f} TF", flush=True)
+          f"{fl/t_d/1e12:7.1f} TF | wgrad {t_w*1e3:7.3f} ms {fl/t_w/1e12:7.1f} TF | wgrad as (x^T dy)^T {t_w2*1e3:7.3f} ms "
+          f"{fl/t_w2/1e12:7.1f} TF | mm(out=) {t_w3*1e3:7.3f} ms", flush=True)
     del x, w, gy
 print(f"sum per layer {tot*1e3:.2f} ms; x16 = {tot*16e3:.1f} ms  (tunableop={os.environ.get('PYTORCH_TUNABLEOP_ENABLED', '0')})")
