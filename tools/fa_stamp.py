@@ -39,12 +39,12 @@ ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, 0.125)
 torch.cuda.synchronize()
 lib.rpo_debug_fa_stamps(buf, 0)
 a = np.array(list(buf), dtype=np.float64).reshape(8, 8)
-names = ["vmcnt wait", "barrier", "stage issue", "reads+M1 issue", "Q^T rd+VALU+wait", "M2 issue", "active iters", "iters"]
+names = ["vmcnt wait", "barrier", "stage issue", "slice body (fast path)", "-", "-", "fast iters", "iters"]
 print("per-iteration cycles (sum over all waves of that role / iterations); role = wave8 (kh = w >> 2, qg = w & 3)")
 print("%-18s" % "segment" + "".join("%9s" % f"w{w}" for w in range(8)))
-for i in range(6):
+for i in range(4):
     den = a[:, 7] if i < 3 else a[:, 6]
     print("%-18s" % names[i] + "".join("%9.0f" % (a[w, i] / den[w]) for w in range(8)))
 print("%-18s" % "active / iters" + "".join("%9.3f" % (a[w, 6] / a[w, 7]) for w in range(8)))
-tot = a[:, :6].sum(1) / a[:, 7]
+tot = a[:, :4].sum(1) / a[:, 7]
 print("%-18s" % "sum / iter" + "".join("%9.0f" % t for t in tot))

@@ -83,13 +83,20 @@ READY = lambda n: 8 * (n + 1) + 2      # two MFMAs of the next group have issued
 RATE = 3                               # VALU instructions per MFMA gap
 
 
+import os
+NO_VALU = os.environ.get("GEN_NO_VALU") == "1"      # timing experiments only (results are wrong)
+NO_TR = os.environ.get("GEN_NO_TR") == "1"
+NO_PREFETCH = os.environ.get("GEN_NO_PREFETCH") == "1"
+
+
 def build(hot):
     out = []
     if not hot:
         out += loads
     out.append("s_waitcnt lgkmcnt(0)")             # row fragments / row constants of this slice are in v[128:175]
-    out += tr
-    queue = [(op, READY(n), n) for n in range(4) for op in chunks[n]]
+    if not NO_TR:
+        out += tr
+    queue = [] if NO_VALU else [(op, READY(n), n) for n in range(4) for op in chunks[n]]
     vi = 0
     for k, ins in enumerate(mfma):
         if k >= 32 and (k - 32) % 8 == 0:
@@ -98,7 +105,8 @@ def build(hot):
                 out.append(queue[vi][0]); vi += 1
             if k == 32:
                 out.append("s_waitcnt lgkmcnt(0)")  # the transposed fragments (issued ~500 cycles ago)
-                out.extend(prefetch)                # M1 is done with v[128:175]: the next slice's operands, all of M2 to land
+                if not NO_PREFETCH:
+                    out.extend(prefetch)            # M1 is done with v[128:175]: the next slice's operands, all of M2 to land
             out.append("s_nop 1")                  # VALU-written VGPR -> MFMA operand
         out.append(ins)
         took = 0
