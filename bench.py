@@ -460,10 +460,21 @@ def main():
             except Exception:
                 pass
             if top["bound"] == "mfma":
+                mtraffic, msrc = None, None
+                try:
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                    if top["entry"] in pmc:
+                        ratio = pmc[top["entry"]]["traffic_over_algorithmic"]
+                        mtraffic = int(top["algo_bytes"] * ratio)
+                        msrc = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH "
+                                "x2 gfx950 correction) of this entry point's kernels on the cfg-2 passage batch, ratio %.2f "
+                                "applied to this run's algorithmic bytes" % ratio)
+                except Exception:
+                    pass
                 out["roofline"] = {"kernel": top["entry"], "bound": "mfma", "achieved": top["achieved_TFLOPs"],
-                                   "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_mfma"], "traffic": None,
-                                   "avg_us": top["avg_us"], "algo_flops": top["algo_flops"],
-                                   "algo_bytes": top["algo_bytes"]}
+                                   "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_mfma"],
+                                   "traffic": mtraffic, "traffic_source": msrc, "avg_us": top["avg_us"],
+                                   "algo_flops": top["algo_flops"], "algo_bytes": top["algo_bytes"]}
             else:
                 out["roofline"] = {"kernel": top["entry"], "bound": "hbm", "achieved": top["achieved_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": traffic,
