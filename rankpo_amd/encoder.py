@@ -267,7 +267,7 @@ class LlamaAttention(nn.Module):
         qkv = self._fused(x, (self.q_proj, self.k_proj, self.v_proj))            # [N, L, nq + 2 nk]
         fused = _ops.fused_encoder_ops_ok(x, self.hd)
         if fused:       # one in-place HIP pass over the q and k heads instead of neg / cat / 2 mul / add per tensor
-            qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd)
+            qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd, grad_inplace=True)
         q, k, v = qkv.split([nq, nk, nk], dim=-1)
         if (isinstance(attn_mask, VarlenCtx) and fused and attn_mask.k_tiles is not None and self.hd == 64
                 and x.dtype == torch.bfloat16):
@@ -346,7 +346,7 @@ class LlamaLayer(nn.Module):
         rope_last = rope.select(last_idx)
         if _ops.fused_encoder_ops_ok(x, att.hd):
             q = _ops.rope_(q, rope_last.cos32, rope_last.sin32, att.nh, att.hd)
-            kv = _ops.rope_(kv, rope.cos32, rope.sin32, att.nkv, att.hd)     # rotates the k heads only
+            kv = _ops.rope_(kv, rope.cos32, rope.sin32, att.nkv, att.hd, grad_inplace=True)   # rotates the k heads only
             k, v = kv.split([nk, nk], dim=-1)
             q, k = q.view(-1, att.nh, att.hd), k.view(T, att.nkv, att.hd)
         else:
