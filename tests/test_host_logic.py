@@ -233,3 +233,18 @@ def test_fused_weight_is_a_view_of_the_flat_buffer():
     assert torch.equal(w2, torch.cat([a, b], 0))
     w2.sum().backward()
     assert torch.equal(a.grad, torch.ones_like(a)) and torch.equal(b.grad, torch.ones_like(b))
+
+
+def test_generated_dkdv_slice_body_is_in_sync():
+    """The hand-placed slice body of fa_bwd_dkdv4_kernel in attention.hip is generated text: it must be what
+    tools/gen/gen_dkdv4_body.py emits today (edit the generator, not the macro)."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_dkdv4_body.py")], capture_output=True,
+                         text=True, check=True).stdout
+    src = open(os.path.join(root, "rankpo_amd", "csrc", "attention.hip")).read()
+    norm = lambda t: [re.sub(r"\s*\\$", "", ln.rstrip()) for ln in t.splitlines() if ln.strip()]
+    a = src.index("// generated by tools/gen/gen_dkdv4_body.py")
+    b = src.index("__global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(")
+    assert norm(src[a:b]) == norm(gen)
