@@ -450,22 +450,42 @@ class LlamaEncoder(nn.Module):
         the final RMSNorm runs on the N pooled rows only.  Returns None when the mask is not a right-padded 0/1
         mask with at least one token per row (the caller then takes the general padded path).
         One host sync per call (sequence lengths), none per layer."""
-        m = attention_mask
-        N, L = m.shape
-        lens_d = m.sum(-1)
-        ok = (m[:, 1:] <= m[:, :-1]).all() & (lens_d > 0).all() & ((m == 0) | (m == 1)).all()
-        info = torch.cat([lens_d.to(torch.int64), ok.to(torch.int64)[None]]).tolist()      # the one sync
-        if not info[-1] or getattr(self.config, "padding_side", "right") != "right":
+        out = self.pooled_last_token_multi([(input_ids, attention_mask)])
+        return None if out is None else out[0]
+
+    def pooled_last_token_multi(self, batches):
+        """`pooled_last_token` for several (input_ids, attention_mask) batches of different padded widths in ONE packed pass
+        (e.g. the query and the passage batch of a training step: sequences are independent, so every pooled row is what the
+        separate calls give, but the small batch no longer runs as its own set of under-filled GEMMs and launches).
+        Returns a list of [N_i, d] tensors, or None if any batch is not right-padded 0/1 with at least one token per row."""
+        if getattr(self.config, "padding_side", "right") != "right":
             return None
-        lens = info[:-1]
-        T = sum(lens)
-        keep = m.reshape(-1).to(torch.bool)
-        flat = torch.nonzero(keep, as_tuple=False).squeeze(1)                              # [T] (size known: no surprise)
-        ids = input_ids.reshape(-1)[flat]
+        stats = []
+        for _, m in batches:
+            lens_d = m.sum(-1)
+            ok = (m[:, 1:] <= m[:, :-1]).all() & (lens_d > 0).all() & ((m == 0) | (m == 1)).all()
+            stats.append(torch.cat([lens_d.to(torch.int64), ok.to(torch.int64)[None]]))
+        info = torch.cat(stats).tolist()                                                   # the one sync
+        lens, o = [], 0
+        for _, m in batches:
+            n = m.shape[0]
+            if not info[o + n]:
+                return None
+            lens += info[o:o + n]
+            o += n + 1
+        ids_parts, pos_parts = [], []
+        for ids, m in batches:
+            L = m.shape[1]
+            flat = torch.nonzero(m.reshape(-1).to(torch.bool), as_tuple=False).squeeze(1)  # size known: no surprise
+            ids_parts.append(ids.reshape(-1)[flat])
+            pos_parts.append(flat % L)
+        ids = ids_parts[0] if len(batches) == 1 else torch.cat(ids_parts)
+        pos = pos_parts[0] if len(batches) == 1 else torch.cat(pos_parts)
         x = self.embed_tokens(ids)[None]                                                   # [1, T, d]
-        rope = self._rope(flat % L)                                                        # per-token angles [T, hd/2]
+        rope = self._rope(pos)                                                             # per-token angles [T, hd/2]
+        N = len(lens)
         cu = torch.zeros(N + 1, dtype=torch.int32, device=x.device)
-        cu[1:] = lens_d.cumsum(0).to(torch.int32)
+        cu[1:] = torch.tensor(lens, dtype=torch.int64).cumsum(0).to(torch.int32).to(x.device, non_blocking=True)
         tiles = k_tiles = None
         if x.is_cuda and self.config.head_dim == 64 and x.dtype == torch.bfloat16:     # hand-written flash attention
             tiles = _ops.attn_tile_table(lens, x.device)
@@ -481,7 +501,8 @@ class LlamaEncoder(nn.Module):
             last = checkpoint(self.layers[li].forward_last_rows, x, delta, rope, ctx, last_idx, use_reentrant=False)
         else:
             last = self.layers[li].forward_last_rows(x, delta, rope, ctx, last_idx)         # [N, d]
-        return self.norm(last)
+        pooled = self.norm(last)
+        return list(pooled.split([m.shape[0] for _, m in batches], 0))
 
 
 # ----------------------------------------------------------------------------------------------------

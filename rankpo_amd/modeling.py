@@ -125,6 +125,19 @@ class ModelForTraining(nn.Module):
         attention_mask = inputs["attention_mask"]
         return ops.pool_normalize(last_hidden_state, attention_mask, self.pooling_mode, self.normalize_embeddings)
 
+    def embed_pair(self, query, passage):
+        """embed(query), embed(passage) -- through ONE packed encoder pass when both batches qualify for the unpadded path
+        (sequences are independent, so the rows are the ones the two separate calls produce)."""
+        if (query is not None and passage is not None and self.unpad and self.pooling_mode == "last"
+                and hasattr(self.model, "pooled_last_token_multi")):
+            pooled = self.model.pooled_last_token_multi([(query["input_ids"], query["attention_mask"]),
+                                                        (passage["input_ids"], passage["attention_mask"])])
+            if pooled is not None:
+                both = ops.pool_normalize(torch.cat(pooled, 0)[:, None, :], None, "cls", self.normalize_embeddings)
+                nq = pooled[0].shape[0]
+                return both[:nq].contiguous(), both[nq:].contiguous()
+        return self.embed(query), self.embed(passage)
+
     def compute_similarity(self, q_reps, p_reps):
         """modeling.py:240-252: `q @ p.transpose(-2, -1)`; 2-D inputs use the MFMA similarity kernel."""
         if q_reps.dim() == 2 and p_reps.dim() == 2 and q_reps.is_cuda and not (
@@ -136,15 +149,12 @@ class ModelForTraining(nn.Module):
         """modeling.py:254-328.  Keyword names `query` / `passage` are the collator's keys."""
         gathers = None
         if self.training and self.negatives_cross_device and self.use_inbatch_neg and passage is not None:
-            # The passage tower is the big one: encode it first and let its RCCL all-gather run over xGMI
-            # while the query tower is being encoded (results do not depend on the encode order).
-            p_reps = self.embed(passage)
-            gp = EmbeddingGather(p_reps)
-            q_reps = self.embed(query)
-            gathers = (EmbeddingGather(q_reps), gp)
+            # both towers in one packed encoder pass, then the two (tiny: [B, d] and [B G, d]) RCCL all-gathers are issued
+            # together and waited for just before the scoring kernel
+            q_reps, p_reps = self.embed_pair(query, passage)
+            gathers = (EmbeddingGather(q_reps), EmbeddingGather(p_reps))
         else:
-            q_reps = self.embed(query)
-            p_reps = self.embed(passage)
+            q_reps, p_reps = self.embed_pair(query, passage)
 
         if self.training:
             q_all = p_all = None
