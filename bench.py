@@ -56,10 +56,11 @@ def _es(dt):
 _ATTN_PAIRS = {}    # packed token count -> sum over sequences of len (len + 1) / 2, registered by register_attn_batch()
 
 
-def register_attn_batch(attention_mask):
+def register_attn_batch(*attention_masks):
     """Flash attention's algorithmic flops depend on the sequence lengths, which its C arguments only hold on the device:
-    the bench registers every synthetic batch here, keyed by its packed token count."""
-    lens = attention_mask.sum(1).to(torch.int64).cpu()
+    the bench registers every synthetic batch here, keyed by its packed token count (several masks: the batches that
+    go through one packed encoder pass together)."""
+    lens = torch.cat([m.sum(1).to(torch.int64).cpu() for m in attention_masks])
     _ATTN_PAIRS[int(lens.sum())] = int((lens * (lens + 1) // 2).sum())
 
 
@@ -203,7 +204,9 @@ def synth_batch(cfg, B, K, Lq, Lp, seed, device):
         ids = ids * m + pad * (1 - m)
         register_attn_batch(m)
         return {"input_ids": ids.to(device), "attention_mask": m.to(device)}
-    return {"query": side(B, Lq), "passage": side(B * (1 + K), Lp)}
+    out = {"query": side(B, Lq), "passage": side(B * (1 + K), Lp)}
+    register_attn_batch(out["query"]["attention_mask"].cpu(), out["passage"]["attention_mask"].cpu())   # one packed pass
+    return out
 
 
 def sweep(lib_timed, device):
