@@ -478,28 +478,31 @@ def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 0):
                 parts.append(np.stack([np.full_like(k0, s), np.full_like(k0, h), k0], 1))
         return torch.from_numpy(np.concatenate(parts, 0)).to(device, non_blocking=True)
     # The kernel gives XCD x (blocks x, x + 8, ...) the x-th eighth of the table, in order.  One workgroup per CU and work
-    # per block ~ (len - first key): balance the eighths (longest (sequence, head) groups first, each to the least loaded
-    # XCD; a group stays on ONE XCD, whose L2 then serves its Q / dO rows), run the heaviest blocks of an eighth first
-    # (the tail of a launch is one light block, not one heavy one), and pad the eighths to equal length with entries whose
-    # first key lies past every sequence (such a workgroup exits at once).
-    groups = sorted(((n, s) for s, n in enumerate(lens)), reverse=True)
-    load, chunks = [0.0] * 8, [[] for _ in range(8)]
-    for n, s in groups:
-        for h in range(num_kv_heads):
-            x = min(range(8), key=load.__getitem__)
-            k0 = np.arange(0, n, block_n, dtype=np.int32)
-            load[x] += float((n - k0).sum())
-            chunks[x].append(np.stack([np.full_like(k0, s), np.full_like(k0, h), k0], 1))
-    per = max(sum(len(c) for c in ch) for ch in chunks)
-    pad = np.array([[0, 0, 1 << 30]], dtype=np.int32)
+    # per block ~ (len - first key): deal the (sequence, kv head) groups, longest first, round-robin to the 8 XCDs (equal
+    # eighths when there are 8 kv heads: one head of every sequence each; a group stays on ONE XCD), run the heaviest
+    # blocks of an eighth first (the tail of a launch is one light block, not one heavy one), and pad the eighths to equal
+    # length with entries whose first key lies past every sequence (such a workgroup exits at once).  Vectorised: this runs
+    # on the host between the length sync and the first launch of every step.
     lens_np = np.asarray(lens, dtype=np.int64)
-    out = []
-    for ch in chunks:
-        rows = np.concatenate(ch, 0) if ch else np.zeros((0, 3), np.int32)
-        if len(rows):                               # heaviest block first inside the XCD (measured: 8.9 -> 8.2 ms backward)
-            work = lens_np[rows[:, 0]] - rows[:, 2]
-            rows = rows[np.argsort(-work, kind="stable")]
-        out.append(np.concatenate([rows, np.repeat(pad, per - len(rows), 0)], 0))
+    order = np.argsort(-lens_np, kind="stable")                        # sequences, longest first
+    nblk = (lens_np[order] + block_n - 1) // block_n                     # key blocks per sequence
+    seq_rep = np.repeat(order, nblk)                                     # one row per (sequence, key block)
+    first = np.concatenate([np.arange(0, n, block_n) for n in lens_np[order]]) if len(order) else np.zeros(0, np.int64)
+    rank_rep = np.repeat(np.arange(len(order)), nblk)                    # rank of the sequence in the sorted order
+    H = num_kv_heads
+    seqs = np.tile(seq_rep, H)
+    heads = np.repeat(np.arange(H), len(seq_rep))
+    k0s = np.tile(first, H)
+    xcd = (np.tile(rank_rep, H) * H + heads) % 8                          # group index (rank, head), dealt round-robin
+    work = lens_np[seqs] - k0s
+    chunks = []
+    for x in range(8):
+        sel = np.nonzero(xcd == x)[0]
+        sel = sel[np.argsort(-work[sel], kind="stable")]
+        chunks.append(np.stack([seqs[sel], heads[sel], k0s[sel]], 1).astype(np.int32))
+    per = max(len(c) for c in chunks)
+    pad = np.array([[0, 0, 1 << 30]], dtype=np.int32)
+    out = [np.concatenate([c, np.repeat(pad, per - len(c), 0)], 0) for c in chunks]
     return torch.from_numpy(np.concatenate(out, 0)).to(device, non_blocking=True)
 
 

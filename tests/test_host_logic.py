@@ -248,3 +248,26 @@ def test_generated_dkdv_slice_body_is_in_sync():
     a = src.index("// generated by tools/gen/gen_dkdv4_body.py")
     b = src.index("__global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(")
     assert norm(src[a:b]) == norm(gen)
+
+
+def test_key_block_table_properties():
+    """ops.attn_key_tile_table (the dK/dV kernel's work list): every (sequence, kv head, 256-key block) exactly once, a
+    (sequence, head) group on ONE XCD eighth, heaviest blocks first inside an eighth, eighths padded to equal length with
+    entries that the kernel skips."""
+    from rankpo_amd import ops
+    rs = np.random.RandomState(0)
+    for nkv, lens in ((8, rs.randint(1, 4097, size=37).tolist()), (2, [5, 300, 257, 256, 1]), (1, [1000])):
+        t = ops.attn_key_tile_table(lens, "cpu", nkv).numpy()
+        assert t.shape[0] % 8 == 0
+        per = t.shape[0] // 8
+        real = t[t[:, 2] < (1 << 30)]
+        want = {(s, h, k) for s, n in enumerate(lens) for h in range(nkv) for k in range(0, n, 256)}
+        assert len(real) == len(want) and set(map(tuple, real.tolist())) == want
+        owner = {}
+        for x in range(8):
+            chunk = t[x * per:(x + 1) * per]
+            work = [lens[s] - k for s, h, k in chunk.tolist() if k < (1 << 30)]
+            assert work == sorted(work, reverse=True)                      # heaviest first, padding last
+            assert (chunk[len(work):, 2] == (1 << 30)).all()
+            for s, h, k in chunk[:len(work)].tolist():
+                assert owner.setdefault((s, h), x) == x
