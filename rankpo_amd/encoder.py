@@ -259,7 +259,7 @@ class LlamaAttention(nn.Module):
         weights stay separate parameters (HF names); see `fused_weight`."""
         w = fused_weight([m.weight for m in mods])
         b = torch.cat([m.bias for m in mods], 0) if mods[0].bias is not None else None
-        return F.linear(x, w, b)
+        return _ops.linear(x, w, b)
 
     def forward(self, x, rope, attn_mask):
         N, L, _ = x.shape
@@ -275,7 +275,7 @@ class LlamaAttention(nn.Module):
             # backward writes one d(q|k|v) buffer (no split / cat copies)
             o = _ops.flash_attn_varlen_qkv(qkv.view(L, -1), self.nh, self.nkv, attn_mask.cu, attn_mask.tiles,
                                            attn_mask.k_tiles, 1.0 / math.sqrt(self.hd))
-            return self.o_proj(o.reshape(1, L, self.nh * self.hd))
+            return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
         if isinstance(attn_mask, VarlenCtx):
             # packed tokens [1, T, d]: variable-length causal flash attention, no pad tokens anywhere
             q, k, v = q.view(L, self.nh, self.hd), k.view(L, self.nkv, self.hd), v.view(L, self.nkv, self.hd)
@@ -284,7 +284,7 @@ class LlamaAttention(nn.Module):
                 q = q * cos + _rotate_half(q) * sin
                 k = k * cos + _rotate_half(k) * sin
             o = _varlen_causal_attention(q, k, v, attn_mask)
-            return self.o_proj(o.reshape(1, L, self.nh * self.hd))
+            return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
         q = q.view(N, L, self.nh, self.hd).transpose(1, 2)
         k = k.view(N, L, self.nkv, self.hd).transpose(1, 2)
         v = v.view(N, L, self.nkv, self.hd).transpose(1, 2)
@@ -311,7 +311,7 @@ class LlamaMLP(nn.Module):
     def forward(self, x):
         if self.down_proj.bias is None and self.gate_proj.bias is None and _ops.fused_encoder_ops_ok(x):
             # ONE gate|up projection GEMM; fused HIP silu*mul on its two halves, product not kept alive
-            gu = F.linear(x, fused_weight([self.gate_proj.weight, self.up_proj.weight]))
+            gu = _ops.linear(x, fused_weight([self.gate_proj.weight, self.up_proj.weight]))
             return _ops.swiglu_down(gu, self.down_proj.weight)
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
