@@ -53,15 +53,30 @@ def _es(dt):
     return 2 if dt == 1 else 4
 
 
-_ATTN_PAIRS = {}    # packed token count -> sum over sequences of len (len + 1) / 2, registered by register_attn_batch()
+_ATTN_PAIRS = {}    # packed token count T (as the C entry points receive it) -> sum over sequences of len (len + 1) / 2
 
 
-def register_attn_batch(*attention_masks):
-    """Flash attention's algorithmic flops depend on the sequence lengths, which its C arguments only hold on the device:
-    the bench registers every synthetic batch here, keyed by its packed token count (several masks: the batches that
-    go through one packed encoder pass together)."""
-    lens = torch.cat([m.sum(1).to(torch.int64).cpu() for m in attention_masks])
-    _ATTN_PAIRS[int(lens.sum())] = int((lens * (lens + 1) // 2).sum())
+def hook_attn_tables():
+    """Flash attention's algorithmic flops depend on the sequence lengths, which its C arguments only hold on the device.
+    Every packed encoder pass builds its query-tile table from the host copy of the lengths it hands to the kernels --
+    INCLUDING the filler sequence that rounds the packed token count up to a multiple of 256 (encoder.py,
+    `pooled_last_token_multi`) -- so the bench records them there, keyed by T = sum(lens), the `T` argument of
+    rpo_flash_attn_fwd / _bwd.  A miss is an error (`_algo`), not a silent 0 (round 1's driver line had exactly that)."""
+    from rankpo_amd import ops
+    real = ops.attn_tile_table
+
+    def recording(lens, device, *a, **kw):
+        n = np.asarray(lens, dtype=np.int64)
+        _ATTN_PAIRS[int(n.sum())] = int((n * (n + 1) // 2).sum())
+        return real(lens, device, *a, **kw)
+    ops.attn_tile_table = recording
+
+
+def _attn_pairs(T):
+    if T not in _ATTN_PAIRS:
+        raise KeyError(f"bench: no sequence lengths registered for a flash-attention call with T={T} packed tokens "
+                       f"(known: {sorted(_ATTN_PAIRS)}); its algorithmic flops would read 0")
+    return _ATTN_PAIRS[T]
 
 
 def _algo(name, a):
@@ -107,11 +122,11 @@ def _algo(name, a):
         return rows * d * _es(dt) * (4 if a[4] is not None else 3) + rows * 4, 8 * rows * d
     if name == "rpo_flash_attn_fwd":
         T, nh, nkv, hd = a[9], a[10], a[11], a[12]
-        pairs = _ATTN_PAIRS.get(T, 0)                     # causal (query, key) pairs of this packed batch
+        pairs = _attn_pairs(T)                            # causal (query, key) pairs of this packed batch
         return 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh, 4 * hd * pairs * nh
     if name == "rpo_flash_attn_bwd":
         T, nh, nkv, hd = a[15], a[16], a[17], a[18]
-        pairs = _ATTN_PAIRS.get(T, 0)
+        pairs = _attn_pairs(T)
         return 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, 10 * hd * pairs * nh
     if name == "rpo_topk_merge":
         rows, cols, k, dt = a[2], a[3], a[5], a[6]
@@ -202,10 +217,8 @@ def synth_batch(cfg, B, K, Lq, Lp, seed, device):
         lens[0] = L
         m = (torch.arange(L)[None, :] < lens[:, None]).long()
         ids = ids * m + pad * (1 - m)
-        register_attn_batch(m)
         return {"input_ids": ids.to(device), "attention_mask": m.to(device)}
     out = {"query": side(B, Lq), "passage": side(B * (1 + K), Lp)}
-    register_attn_batch(out["query"]["attention_mask"].cpu(), out["passage"]["attention_mask"].cpu())   # one packed pass
     return out
 
 
@@ -249,32 +262,103 @@ def sweep(lib_timed, device):
     return res
 
 
-def cpu_baseline(model, cfg, temperature, sample=(160, 512, 2)):
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model, cfg, temperature, sample=(40, 85, 4, 3), repeats=3):
     """The oracle's training micro-step (encoder fwd+bwd + scoring, float32, eager) on the host cores, on a bounded
-    sample of the workload: 1 query of Lq_s tokens + G_s passages of Lp_s tokens through the SAME architecture and
-    weights.  pairs/s is extrapolated linearly in tokens to the full-length pair (optimistic for the CPU: the
-    quadratic attention term is ignored)."""
+    sample of the workload: Q_s queries padded to Lq_s tokens + Q_s * G_s passages padded to Lp_s tokens (right-padded rows
+    of random length, first row full: the reference's padded batches) through the SAME architecture and weights; median of
+    `repeats` timed steps after one untimed step of the same shape, on every core this process may use.  pairs/s is
+    extrapolated linearly in (padded) tokens to the full-length pair (optimistic for the CPU: the quadratic attention term
+    is ignored)."""
     from oracle import encoder_ref as E
-    Lq_s, Lp_s, G_s = sample
+    Lq_s, Lp_s, Q_s, G_s = sample
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    cores = max(1, min(cores, 16))      # the GPU box gives one GPU's job a 16-core share; more threads only thrash
     torch.set_num_threads(cores)
     w = {k: v.detach().to("cpu", torch.float32).requires_grad_(True) for k, v in model.model.state_dict().items()}
     cd = cfg.to_dict()
     g = torch.Generator().manual_seed(7)
-    mk = lambda N, L: {"input_ids": torch.randint(1000, cfg.vocab_size - 1000, (N, L), generator=g),
-                       "attention_mask": torch.ones(N, L, dtype=torch.long)}
-    warm = {"query": mk(1, 16), "passage": mk(G_s, 16)}
-    E.contrastive_step(w, cd, warm, temperature)[0].backward()
-    batch = {"query": mk(1, Lq_s), "passage": mk(G_s, Lp_s)}
-    t0 = time.perf_counter()
-    loss, scores = E.contrastive_step(w, cd, batch, temperature)[:2]
-    loss.backward()
-    dt = time.perf_counter() - t0
-    return dt, Lq_s + G_s * Lp_s, cores, batch, (float(loss.detach()), scores.detach().float().flatten().tolist())
+    lo, hi = (1000, cfg.vocab_size - 1000) if cfg.vocab_size > 4000 else (1, cfg.vocab_size)
+    pad = cfg.pad_token_id if cfg.pad_token_id is not None else 0
+
+    def mk(N, L):
+        lens = torch.randint(L // 2, L + 1, (N,), generator=g)
+        lens[0] = L
+        m = (torch.arange(L)[None, :] < lens[:, None]).long()
+        ids = torch.randint(lo, hi, (N, L), generator=g)
+        return {"input_ids": ids * m + pad * (1 - m), "attention_mask": m}
+    batch = {"query": mk(Q_s, Lq_s), "passage": mk(Q_s * G_s, Lp_s)}
+    times = []
+    for i in range(repeats + 1):
+        for t in w.values():
+            t.grad = None
+        t0 = time.perf_counter()
+        loss, scores, q, p = E.contrastive_step(w, cd, batch, temperature)
+        loss.backward()
+        if i:                                   # step 0 warms the allocator and the thread pool
+            times.append(time.perf_counter() - t0)
+    grads = {k: w[k].grad.clone() for k in ("embed_tokens.weight", "layers.0.self_attn.q_proj.weight") if k in w}
+    ref = dict(loss=float(loss.detach()), scores=scores.detach().float(), q=q.detach(), p=p.detach(), grads=grads)
+    return sorted(times)[len(times) // 2], times, Q_s * (Lq_s + G_s * Lp_s), cores, batch, ref
+
+
+def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
+    """Step-loss parity on identical tokens: the cpu_baseline sample through (i) the product's fast path
+    (packed tokens, hand-written attention, fused ops, storage dtype of the run) and (ii) a CONTROL: the oracle's own eager
+    arithmetic (HF eager semantics, modeling.py:219) run in the same storage dtype on the GPU -- i.e. what the reference's
+    stock bf16 path produces from these weights.  Both are compared with the float32 oracle; the fast path passes when its
+    error is at most 1.5x the control's (the tolerance IS the reduced-precision error of the stock path, measured here,
+    not a guessed constant).  Statistics: RMS and max of the cosine errors over all [Q, P] scores, the loss, and the
+    relative error of two weight gradients."""
+    from oracle import encoder_ref as E
+    dev_batch = {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in sample_batch.items()}
+    names = list(ref["grads"])
+    params = dict(model.model.named_parameters())
+
+    def stats(loss, scores, grads):
+        dc = (scores.float().cpu() - ref["scores"]) * temperature
+        out = {"loss": float(loss), "loss_abs_err": abs(float(loss) - ref["loss"]),
+               "cos_rms_err": float(dc.pow(2).mean().sqrt()), "cos_max_err": float(dc.abs().max())}
+        for n in names:
+            gr = ref["grads"][n]
+            out["grad_rel_err:" + n] = float((grads[n].float().cpu() - gr).norm() / gr.norm().clamp_min(1e-30))
+        return out
+
+    was = [p.grad for p in params.values()]
+    for p in params.values():
+        p.grad = None
+    out = model(**dev_batch)
+    got = torch.autograd.grad(out["loss"], [params[n] for n in names])
+    fast = stats(out["loss"].detach(), out["scores"].detach(), dict(zip(names, got)))
+    for p, g in zip(params.values(), was):
+        p.grad = g
+    wd = {k: v.detach().to(device, dtype).requires_grad_(k in names) for k, v in model.model.state_dict().items()}
+    loss_c, s_c = E.contrastive_step(wd, cfg.to_dict(), dev_batch, temperature, dtype=dtype)[:2]
+    got_c = torch.autograd.grad(loss_c, [wd[n] for n in names])
+    ctrl = stats(loss_c.detach(), s_c.detach(), dict(zip(names, got_c)))
+    # floors: float32 round-off (both paths are then ~1e-7 on a cosine and the ratio of two round-off errors means nothing)
+    tol = {"cos_rms_err": 1.5 * ctrl["cos_rms_err"] + 5e-6, "cos_max_err": 1.5 * ctrl["cos_max_err"] + 5e-6,
+           "loss_abs_err": 1.5 * max(ctrl["loss_abs_err"], ctrl["cos_rms_err"] / temperature) + 5e-6 / temperature}
+    for n in names:
+        tol["grad_rel_err:" + n] = 1.5 * ctrl["grad_rel_err:" + n] + 1e-4
+    failed = [k for k, t in tol.items() if not fast[k] <= t]
+    rnd = lambda d: {k: round(v, 7) for k, v in d.items()}
+    return {"oracle_f32_loss": round(ref["loss"], 6), "fast_path": rnd(fast), "control_stock_eager": rnd(ctrl),
+            "tolerance": rnd(tol), "pass": not failed, "failed": failed,
+            "rule": "fast-path error <= 1.5 x the error of the stock eager path in the same storage dtype, both against "
+                    "the float32 oracle on the same tokens and weights (loss: 1.5 x max(control loss error, control cosine "
+                    "RMS error / T))"}
 
 
 class _StdoutToStderr:
@@ -292,6 +376,36 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
+def self_launch(n):
+    """Spawn `n` rank processes of this script under torch.distributed.run (one per GPU, RCCL rendezvous on 127.0.0.1) and
+    relay their output; rank 0 prints the JSON line.  Returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def rehearse_launch(rank, world):
+    """What every rank does around the timed region, without a GPU: process group up (gloo), barrier, MAX over ranks."""
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29655")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dist.barrier()
+    t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"rehearsal": "launch", "n_gpus": world, "max_over_ranks": t.item()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,14 +420,26 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="rehearsal: take the N > 1 code path (RCCL init, cross-device gather, grad all-reduce) at N = 1")
+    ap.add_argument("--gas", type=int, default=1,
+                    help="micro-batches per optimizer step (the reference's scripts use 4; negatives are per micro-batch). "
+                         "A timed step is then `gas` micro-steps + one gradient all-reduce + one AdamW launch")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="CPU rehearsal of the N-rank launch only: gloo process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` by itself: start N fresh rank processes under torch.distributed.run.  This parent has
+        # made no GPU call (importing torch does not initialise HIP) and only waits for the children: a process that has
+        # touched the GPU is never re-exec'd.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
-                         f"--nproc-per-node {args.gpus}")
+                         f"--nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` outside torchrun")
+    if args.rehearse_launch:
+        return rehearse_launch(rank, world)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
@@ -340,7 +466,9 @@ def main():
     enc = enc.to(dtype)
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
                                         negatives_cross_device=multi, unpad=not args.padded).train()
-    nb = args.steps + args.warmup
+    hook_attn_tables()
+    gas = max(1, args.gas)
+    nb = (args.steps + args.warmup) * gas
     batches = [synth_batch(cfg, B, K, Lq, Lp, 1234 + rank * 1000 + i, device) for i in range(nb)]
     tok_real = [int(b["query"]["attention_mask"].sum()) + int(b["passage"]["attention_mask"].sum()) for b in batches]
     tok_pad = B * Lq + B * (1 + K) * Lp
@@ -378,11 +506,10 @@ def main():
     else:
         loss_fn = lambda b: model(**b)["loss"]
     ts = TrainStep(model.parameters(), loss_fn, lr=1e-5, max_grad_norm=1.0,
-                   gradient_accumulation_steps=1, total_steps=max(10, args.steps + args.warmup), warmup_ratio=0.1,
+                   gradient_accumulation_steps=gas, total_steps=max(10, args.steps + args.warmup), warmup_ratio=0.1,
                    force_collectives=args.force_dist)
+    micro = lambda i: batches[i] if gas == 1 else batches[i * gas:(i + 1) * gas]
 
-    nb = args.steps + args.warmup
-    batches = [synth_batch(cfg, B, K, Lq, Lp, 1234 + rank * 1000 + i, device) for i in range(nb)]
     def note(msg):
         if rank == 0:
             print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
@@ -395,11 +522,11 @@ def main():
         # calling hipMalloc inside the timed region) and proves that the worst case fits in HBM.
         full = {k: {"input_ids": v["input_ids"], "attention_mask": torch.ones_like(v["attention_mask"])}
                 for k, v in batches[0].items()}
-        ts.step(full)
+        ts.step(full if gas == 1 else [full] * gas)
         torch.cuda.synchronize()
         note(f"allocator pre-sized on a full-length batch, peak mem {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB")
     for i in range(args.warmup):
-        losses.append(ts.step(batches[i]))
+        losses.append(ts.step(micro(i)))
         torch.cuda.synchronize()
         note(f"warmup step {i} done, loss {float(losses[-1]):.4f}, peak mem {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB")
     torch.cuda.synchronize()
@@ -408,8 +535,8 @@ def main():
     torch.cuda.synchronize()
     timed.enabled = not args.no_kernel_timing
     t0 = time.perf_counter()
-    for i in range(args.warmup, nb):
-        losses.append(ts.step(batches[i]))
+    for i in range(args.warmup, args.warmup + args.steps):
+        losses.append(ts.step(micro(i)))
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -421,7 +548,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
-    pairs = world * B * (1 + K) * args.steps
+    pairs = world * B * (1 + K) * gas * args.steps
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
     if rank == 0:
@@ -435,8 +562,8 @@ def main():
                                     f"chosen+rejected, q_len={Lq}, p_len={Lp}, T={temperature}") if args.workload == "cfg4" else
                                    (f"{args.workload}: {arch} contrastive, B={B}/GPU, K={K}, q_len={Lq}, p_len={Lp}, "
                                     f"T={temperature}, in-batch negs" + (", cross-device negs" if multi else "")),
-                       "global_batch": world * B, "pairs_per_step": world * B * (1 + K),
-                       "parallelism": f"dp{world}", "optimizer": "AdamW(flat, HIP) + clip 1.0, GAS=1",
+                       "global_batch": world * B, "pairs_per_step": world * B * (1 + K) * gas,
+                       "parallelism": f"dp{world}", "optimizer": f"AdamW(flat, HIP) + clip 1.0, GAS={gas}", "micro_steps_per_step": gas,
                        "grad_checkpointing": "all blocks" if ckpt < 0 else f"first {ckpt} blocks",
                        "padding": "padded batches" if args.padded else "pad tokens skipped (packed varlen encoder)",
                        "tokens_per_step_per_gpu": {"padded": tok_pad, "real_mean": int(sum(tok_real) / len(tok_real))},
@@ -488,28 +615,22 @@ def main():
             note("sweep done")
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")
-            dt, toks, cores, sample_batch, (oracle_loss, oracle_scores) = cpu_baseline(model, cfg, temperature)
-            # step-loss parity on identical tokens: the same sample through the HIP path with the same weights
-            # (storage dtype of the run here, float32 in the oracle)
-            with torch.no_grad():
-                dev_batch = {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in sample_batch.items()}
-                hip_out = model(**dev_batch)
-                hip_loss = float(hip_out["loss"])
-                hip_scores = hip_out["scores"].float().flatten().cpu().tolist()
-            cos_diff = max(abs(a - b) for a, b in zip(oracle_scores, hip_scores)) * temperature
-            out["step_loss_parity"] = {"oracle_f32": round(oracle_loss, 6), "hip": round(hip_loss, 6),
-                                       "abs_diff": round(abs(oracle_loss - hip_loss), 6),
-                                       "max_cosine_abs_diff": round(cos_diff, 6),
-                                       "note": "same tokens and weights as the cpu_baseline sample; storage dtype "
-                                               f"{dtn} on the GPU, float32 in the oracle; logits = cosine / "
-                                               f"{temperature}, so a cosine difference d moves the loss by up to d / {temperature}"}
+            dt, times, toks, cores, sample_batch, ref = cpu_baseline(model, cfg, temperature)
+            note("step parity: fast path and stock-eager control vs the float32 oracle ...")
+            out["step_loss_parity"] = step_parity(model, cfg, temperature, sample_batch, ref, device, dtype)
             toks_per_pair = Lp + Lq / (1 + K)
+            nq_s, np_s = sample_batch["query"]["input_ids"].shape, sample_batch["passage"]["input_ids"].shape
             out["cpu_baseline"] = {"value": round(toks / dt / toks_per_pair, 5), "unit": "pairs/s", "cores": cores,
-                                   "kind": "port",
-                                   "sample": f"oracle (eager torch f32) fwd+bwd of 1 query x 160 tok + 2 passages x 512 tok "
-                                             f"through the same {arch} weights: {toks} tokens in {dt:.2f} s; pairs/s "
-                                             f"extrapolated linearly in tokens to {toks_per_pair:.0f} tokens per "
-                                             f"full-length pair"}
+                                   "kind": "port", "cpu_model": _cpu_model(),
+                                   "step_seconds": [round(t, 3) for t in times], "median_seconds": round(dt, 3),
+                                   "sample": f"oracle (eager torch f32, {cores} threads) fwd+bwd of {nq_s[0]} queries x {nq_s[1]} "
+                                             f"tok + {np_s[0]} passages x {np_s[1]} tok (padded, as the reference runs them) "
+                                             f"through the same {arch} weights: {toks} tokens, median of {len(times)} timed "
+                                             f"steps after 1 untimed; pairs/s extrapolated linearly in tokens to "
+                                             f"{toks_per_pair:.0f} tokens per full-length pair"}
+            if not out["step_loss_parity"]["pass"]:
+                print(json.dumps(out), flush=True)
+                raise SystemExit("step_loss_parity FAILED: " + ", ".join(out["step_loss_parity"]["failed"]))
         print(json.dumps(out), flush=True)
     if multi:
         dist.barrier()

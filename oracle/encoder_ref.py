@@ -1,6 +1,7 @@
 """CPU oracle for the encoder + full contrastive / RankPO step  --  TEST INFRASTRUCTURE, NOT PRODUCT.
 
-Plain eager torch (CPU, float32 or float64) restatement of what the reference gets from HF `AutoModel`
+Plain eager torch (CPU, float32 or float64; the SAME functions also run on a GPU in bf16 as the "stock reduced-precision
+path" control of the tolerance tests: tensors follow the device of the weights) restatement of what the reference gets from HF `AutoModel`
 (transformers `LlamaModel` / `BertModel`, eager attention; call sites modeling.py:175-178, 219;
 rankpo_trainer.py:402).  The encoder arithmetic lives in a third-party dependency that is not under
 /root/reference (transformers==4.45.2 pinned by the reference's requirements.txt); parity is therefore anchored on
@@ -37,8 +38,20 @@ def _rope_inv_freq(head_dim, theta, scaling=None):
     return inv
 
 
+_LOW = (torch.bfloat16, torch.float16)
+
+
 def _rms(x, w, eps):
+    # HF LlamaRMSNorm: statistics in float32, result cast back, then the weight
+    if x.dtype in _LOW:
+        x32 = x.float()
+        return w * (x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + eps)).to(x.dtype)
     return w * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+
+def _softmax(s):
+    # HF eager attention: softmax(dtype=float32).to(query dtype)
+    return torch.softmax(s.float(), dim=-1).to(s.dtype) if s.dtype in _LOW else torch.softmax(s, dim=-1)
 
 
 def llama_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: torch.Tensor, dtype=torch.float32):
@@ -50,14 +63,15 @@ def llama_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: t
     eps = cfg["rms_norm_eps"]
     N, L = input_ids.shape
     x = W("embed_tokens.weight")[input_ids]
+    dev = x.device           # follows the weights: the same arithmetic runs on a GPU as the reduced-precision control
     inv = _rope_inv_freq(hd, cfg.get("rope_theta", 10000.0), cfg.get("rope_scaling"))
     ang = torch.outer(torch.arange(L, dtype=torch.float64), inv).to(torch.float32)
     ang = torch.cat([ang, ang], -1)
-    cos, sin = ang.cos().to(dtype), ang.sin().to(dtype)
+    cos, sin = ang.cos().to(dev, dtype), ang.sin().to(dev, dtype)
     rot = lambda t: torch.cat([-t[..., hd // 2:], t[..., : hd // 2]], -1)
     neg = torch.finfo(dtype).min
-    allow = torch.ones(L, L, dtype=torch.bool).tril()[None, None] & attention_mask.bool()[:, None, None, :]
-    bias = torch.zeros(N, 1, L, L, dtype=dtype).masked_fill(~allow, neg)
+    allow = torch.ones(L, L, dtype=torch.bool, device=dev).tril()[None, None] & attention_mask.bool()[:, None, None, :]
+    bias = torch.zeros(N, 1, L, L, dtype=dtype, device=dev).masked_fill(~allow, neg)
     for i in range(cfg["num_hidden_layers"]):
         p = f"layers.{i}."
         h = _rms(x, W(p + "input_layernorm.weight"), eps)
@@ -68,7 +82,7 @@ def llama_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: t
         k = k * cos + rot(k) * sin
         k = k.repeat_interleave(nh // nkv, dim=1)
         v = v.repeat_interleave(nh // nkv, dim=1)
-        att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(hd) + bias, dim=-1)
+        att = _softmax(q @ k.transpose(-1, -2) / math.sqrt(hd) + bias)
         o = (att @ v).transpose(1, 2).reshape(N, L, nh * hd)
         x = x + o @ W(p + "self_attn.o_proj.weight").T
         h = _rms(x, W(p + "post_attention_layernorm.weight"), eps)
@@ -121,7 +135,7 @@ def embed(w, cfg, inputs, normalize=True, dtype=torch.float32, force_last=False)
     arch = (cfg.get("architectures") or ["Llama"])[0]
     if force_last or "Llama" in arch:
         idx = (m.argmin(-1) - 1) % m.shape[-1]
-        e = h[torch.arange(m.shape[0]), idx]
+        e = h[torch.arange(m.shape[0], device=h.device), idx]
     else:
         e = h[:, 0]
     if normalize:
@@ -137,11 +151,11 @@ def contrastive_step(w, cfg, batch, temperature, use_inbatch_neg=True, normalize
     G = p.shape[0] // Q
     if use_inbatch_neg:
         s = q @ p.T / temperature
-        t = torch.arange(Q) * G
+        t = torch.arange(Q, device=q.device) * G
     else:
         s = torch.einsum("bd,bgd->bg", q, p.view(Q, G, -1)) / temperature
-        t = torch.zeros(Q, dtype=torch.long)
-    loss = (torch.logsumexp(s, -1) - s[torch.arange(Q), t]).mean()
+        t = torch.zeros(Q, dtype=torch.long, device=q.device)
+    loss = (torch.logsumexp(s, -1) - s[torch.arange(Q, device=q.device), t]).mean()
     return loss, s, q, p
 
 

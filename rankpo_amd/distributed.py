@@ -3,9 +3,10 @@ on ROCm; "gloo" in the CPU tests).
 
 * `all_gather_with_local_grad`  -- reference `distributed_gather` semantics (modeling.py:331-404): rank-major
   concatenation; backward hands each rank the gradient of ITS OWN slice, no backward collective.
-* `EmbeddingGather` / `gather_embeddings` -- what `ModelForTraining.forward` uses: the gathered matrices are
-  constants for autograd (the InfoNCE kernel produces gradients for the local rows directly), so the gather is a
-  plain asynchronous collective that can be in flight while the other tower is still being encoded.
+* `FusedQPGather` / `EmbeddingGather` -- what `ModelForTraining.forward` uses: the gathered matrices are constants for
+  autograd (the InfoNCE kernel produces gradients for the local rows directly), so the gather is a plain asynchronous
+  collective: ONE all-gather of the `q ‖ p` block when both towers ran as one packed pass (the default), or the passage
+  gather in flight during the query tower when the towers run one after the other.
 * `FlatGradAllReducer` -- data-parallel gradient mean over flat buckets (replaces DeepSpeed ZeRO-1's reduction;
   SURVEY.md §8e): buckets are all-reduced asynchronously as soon as backward has produced them.
 """
@@ -59,10 +60,28 @@ class EmbeddingGather:
         return self.out.view((-1,) + tuple(self.x.shape[1:]))
 
 
+class FusedQPGather:
+    """The reference's two `distributed_gather` calls (modeling.py:289-290) as ONE collective: every rank contributes its
+    [B + B G, d] block `q ‖ p` (the packed encoder pass already emits the pooled rows in that order), the all-gather lands in
+    one [W, B + B G, d] buffer, and `wait()` returns the rank-major matrices the loss is computed on,
+    q_all [W B, d] and p_all [W B G, d] (two small copies out of the buffer: 32 KiB and 192 KiB per rank at cfg 3).
+    Asynchronous: issued on RCCL's stream, the launch stream only waits in `wait()`.  No autograd: the gathered matrices
+    are constants, the InfoNCE backward produces this rank's rows directly (modeling.py:374-377 semantics)."""
+
+    def __init__(self, qp: torch.Tensor, num_queries: int):
+        self.nq = int(num_queries)
+        self._g = EmbeddingGather(qp)
+
+    def wait(self):
+        out = self._g.out                                    # [W, B + B G, d]
+        self._g.wait()
+        d = out.shape[-1]
+        return out[:, :self.nq].reshape(-1, d), out[:, self.nq:].reshape(-1, d)
+
+
 def gather_embeddings(q: torch.Tensor, p: torch.Tensor):
-    """Gather q and p across ranks; returns (q_all [W*B, d], p_all [W*BG, d]) as autograd constants."""
-    gq, gp = EmbeddingGather(q), EmbeddingGather(p)
-    return gq.wait(), gp.wait()
+    """Gather q and p across ranks with one collective; returns (q_all [W*B, d], p_all [W*BG, d]) as autograd constants."""
+    return FusedQPGather(torch.cat([q.detach(), p.detach()], 0), q.shape[0]).wait()
 
 
 class FlatGradAllReducer:
@@ -115,6 +134,7 @@ class FlatGradAllReducer:
         self._pending = [0] * len(self.buckets)
         self._works = []
         self._armed = False
+        self.late_buckets = 0                      # buckets that finish() had to reduce (diagnostic)
         self._reduce = self.world > 1 or (force_collectives and dist.is_initialized())   # force: 1-rank rehearsal
         if self._reduce:
             for i, p in enumerate(order):
@@ -145,7 +165,19 @@ class FlatGradAllReducer:
 
     def finish(self):
         """Wait for the bucket all-reduces (stream wait, no host sync).  The 1/world mean factor is folded into
-        the optimizer's grad scale (returned)."""
+        the optimizer's grad scale (returned).
+        A bucket fires from the hooks only when EVERY parameter in it received a gradient in the armed backward; a
+        parameter without one (unused branch, frozen sub-path on this step) would otherwise leave its whole bucket
+        un-reduced and the ranks would diverge silently.  Such buckets are reduced here, in bucket order (their missing
+        gradients are the zeros the flat buffer holds).  The sequence of collectives stays identical on all ranks as long as
+        the ranks run the same graph -- the usual data-parallel contract."""
+        if self._armed:
+            for b, left in enumerate(self._pending):
+                if left > 0:
+                    s, e, _ = self.buckets[b]
+                    self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                    self._pending[b] = 0
+                    self.late_buckets += 1
         for w in self._works:
             w.wait()
         self._works = []

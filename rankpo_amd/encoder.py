@@ -5,9 +5,11 @@ hand-written HIP starts at the pooled embedding).  They stand where the referenc
 same parameter names as HF `LlamaModel` / `BertModel`, so checkpoints in HF safetensors layout load and save.
 
 MI355X notes
-  * Llama + right padding (what both reference collators produce, data_utils.py:64-70, 205-212): a causal model
+  * Llama + a right-padded MASK (what both reference collators produce, data_utils.py:64-70, 205-212): a causal model
     never lets a real token see the pad tokens behind it, so the padding mask is dropped and attention runs as
-    pure causal flash attention; only pad positions (never pooled) differ from a masked run.
+    pure causal flash attention; only pad positions (never pooled) differ from a masked run.  The decision is taken
+    from the mask's content (`LlamaEncoder._mask`), never from a config flag: any other mask (left padding, holes)
+    runs with HF's `causal & keep` mask.
   * `pooled_last_token`: tokens packed (no pad tokens), variable-length causal flash attention, the LAST block computes
     only K/V for all tokens and everything else for the pooled rows, final RMSNorm on the pooled rows only.
 """
@@ -410,11 +412,21 @@ class LlamaEncoder(nn.Module):
         return RopeTables(torch.outer(pos.to(torch.float32), self.inv_freq.to(device=pos.device, dtype=torch.float32)))
 
     def _mask(self, attention_mask, L, dtype):
-        if attention_mask is None or getattr(self.config, "padding_side", "right") == "right":
-            return None                                        # pure causal (module docstring)
-        keep = attention_mask.to(torch.bool)[:, None, None, :]
-        causal = torch.ones(L, L, dtype=torch.bool, device=attention_mask.device).tril()[None, None]
-        return keep & causal
+        """None (pure causal attention, module docstring) when the MASK ITSELF is right-padded -- every row is ones followed
+        by zeros -- else the boolean [N, 1, L, L] `causal & key-is-kept` mask HF builds from any attention_mask
+        (modeling.py:219).  Decided from the mask, never from the config: a left-padded or holed batch through a
+        default-config encoder must not attend to its pad tokens.  One host sync (this is the general padded path; the
+        packed training path has its own)."""
+        if attention_mask is None:
+            return None
+        m = attention_mask
+        if bool((m[:, 1:].ne(0) <= m[:, :-1].ne(0)).all()):
+            return None
+        keep = m.ne(0)[:, None, None, :]
+        causal = torch.ones(L, L, dtype=torch.bool, device=m.device).tril()[None, None]
+        # a pad token in front of the first real one has no key it may look at: it keeps itself (its row is never pooled
+        # nor read as a key), so that no softmax row is empty whatever the attention backend does with those
+        return (keep & causal) | torch.eye(L, dtype=torch.bool, device=m.device)[None, None]
 
     def hidden_states(self, input_ids, attention_mask=None):
         """Output of the last block, BEFORE the final RMSNorm."""
@@ -458,8 +470,6 @@ class LlamaEncoder(nn.Module):
         (e.g. the query and the passage batch of a training step: sequences are independent, so every pooled row is what the
         separate calls give, but the small batch no longer runs as its own set of under-filled GEMMs and launches).
         Returns a list of [N_i, d] tensors, or None if any batch is not right-padded 0/1 with at least one token per row."""
-        if getattr(self.config, "padding_side", "right") != "right":
-            return None
         stats = []
         for _, m in batches:
             lens_d = m.sum(-1)

@@ -18,7 +18,7 @@ import torch.distributed as dist
 from torch import Tensor, nn
 
 from . import ops
-from .distributed import EmbeddingGather, all_gather_with_local_grad
+from .distributed import EmbeddingGather, FusedQPGather, all_gather_with_local_grad
 from .encoder import build_encoder, load_encoder
 
 logger = logging.getLogger(__name__)
@@ -53,6 +53,14 @@ def _load_or_build(model_name_or_path, encoder, config, torch_dtype):
             f"model_name_or_path={model_name_or_path!r} is not a local directory; hub downloads are not available "
             "here.  Pass a directory in HF layout (config.json + model.safetensors), or encoder= / config=.")
     return load_encoder(model_name_or_path, torch_dtype)
+
+
+class _TwoGathers:
+    def __init__(self, gq, gp):
+        self.gq, self.gp = gq, gp
+
+    def wait(self):
+        return self.gq.wait(), self.gp.wait()
 
 
 class ModelForTraining(nn.Module):
@@ -125,17 +133,24 @@ class ModelForTraining(nn.Module):
         attention_mask = inputs["attention_mask"]
         return ops.pool_normalize(last_hidden_state, attention_mask, self.pooling_mode, self.normalize_embeddings)
 
-    def embed_pair(self, query, passage):
-        """embed(query), embed(passage) -- through ONE packed encoder pass when both batches qualify for the unpadded path
-        (sequences are independent, so the rows are the ones the two separate calls produce)."""
+    def _embed_both(self, query, passage):
+        """The normalised pooled rows of both batches as ONE [B + B G, d] block `q ‖ p` through ONE packed encoder pass, or
+        None when the batches do not qualify for the unpadded path (sequences are independent, so the rows are the ones the
+        two separate `embed` calls produce)."""
         if (query is not None and passage is not None and self.unpad and self.pooling_mode == "last"
                 and hasattr(self.model, "pooled_last_token_multi")):
             pooled = self.model.pooled_last_token_multi([(query["input_ids"], query["attention_mask"]),
                                                         (passage["input_ids"], passage["attention_mask"])])
             if pooled is not None:
-                both = ops.pool_normalize(torch.cat(pooled, 0)[:, None, :], None, "cls", self.normalize_embeddings)
-                nq = pooled[0].shape[0]
-                return both[:nq].contiguous(), both[nq:].contiguous()
+                return ops.pool_normalize(torch.cat(pooled, 0)[:, None, :], None, "cls", self.normalize_embeddings)
+        return None
+
+    def embed_pair(self, query, passage):
+        """embed(query), embed(passage) -- through ONE packed encoder pass when both batches qualify for the unpadded path."""
+        both = self._embed_both(query, passage)
+        if both is not None:
+            nq = query["input_ids"].shape[0]
+            return both[:nq], both[nq:]             # row blocks of a contiguous matrix: contiguous themselves
         return self.embed(query), self.embed(passage)
 
     def compute_similarity(self, q_reps, p_reps):
@@ -147,21 +162,32 @@ class ModelForTraining(nn.Module):
 
     def forward(self, query: Dict[str, Tensor] = None, passage: Dict[str, Tensor] = None):
         """modeling.py:254-328.  Keyword names `query` / `passage` are the collator's keys."""
-        gathers = None
+        gather = None
         if self.training and self.negatives_cross_device and self.use_inbatch_neg and passage is not None:
-            # both towers in one packed encoder pass, then the two (tiny: [B, d] and [B G, d]) RCCL all-gathers are issued
-            # together and waited for just before the scoring kernel
-            q_reps, p_reps = self.embed_pair(query, passage)
-            gathers = (EmbeddingGather(q_reps), EmbeddingGather(p_reps))
+            # modeling.py:287-290, MI355X-first: ONE all-gather of this rank's `q ‖ p` block instead of two collectives
+            # (xGMI is point-to-point: 2 x (W - 1) messages of 32 / 192 KiB become W - 1 of 224 KiB), issued on RCCL's
+            # stream as soon as the pooled rows exist and waited for just before the scoring kernel.
+            both = self._embed_both(query, passage)
+            if both is not None:
+                nq = query["input_ids"].shape[0]
+                q_reps, p_reps = both[:nq], both[nq:]
+                gather = FusedQPGather(both, nq)
+            else:
+                # towers one after the other (padded / CLS encoders): the passage gather is in flight during the query tower
+                p_reps = self.embed(passage)
+                gp = EmbeddingGather(p_reps)
+                q_reps = self.embed(query)
+                gq = EmbeddingGather(q_reps)
+                gather = _TwoGathers(gq, gp)
         else:
             q_reps, p_reps = self.embed_pair(query, passage)
 
         if self.training:
             q_all = p_all = None
             q_row0 = p_row0 = 0
-            if gathers is not None:                                           # modeling.py:287-290
+            if gather is not None:
                 # rank-major order; only this rank's rows receive gradients (modeling.py:374-377)
-                q_all, p_all = gathers[0].wait(), gathers[1].wait()
+                q_all, p_all = gather.wait()
                 q_row0 = self.process_rank * q_reps.shape[0]
                 p_row0 = self.process_rank * p_reps.shape[0]
             loss, scores = ops.infonce_loss(q_reps, p_reps, self.temperature, self.use_inbatch_neg,
@@ -223,9 +249,6 @@ class ModelForInference(nn.Module):
         self.config = self.model.config
         if not getattr(self.tokenizer, "pad_token", None):            # modeling.py:467-468
             raise ValueError("pad_token is not specified!")
-        side = getattr(self.tokenizer, "padding_side", "right")
-        if side != "right" and hasattr(self.config, "padding_side"):
-            self.config.padding_side = side        # left padding: the Llama encoder must honour the mask
         self.model = self.model.to(self.device)
 
     @torch.inference_mode()

@@ -62,18 +62,46 @@ def test_oracle_bert_vs_transformers():
     assert (got - ref)[m.bool()].abs().max() < 2e-5
 
 
+def _mixed_mask(rs, N, L):
+    """right-padded, left-padded, holed and all-ones rows in ONE batch (the mask shapes of golden pooling.npz)."""
+    m = np.ones((N, L), dtype=np.int64)
+    for i in range(N):
+        n = rs.randint(1, L)
+        kind = i % 4
+        if kind == 0:
+            m[i, n:] = 0
+        elif kind == 1:
+            m[i, : L - n] = 0
+        elif kind == 2:
+            m[i, rs.randint(1, L - 1)] = 0            # a hole in the middle
+    return m
+
+
 @pytest.mark.parametrize("ci", [0, 1])
-@pytest.mark.parametrize("side", ["right", "left"])
+@pytest.mark.parametrize("side", ["right", "left", "mixed"])
 def test_product_llama_vs_oracle(ci, side):
+    """DEFAULT config for every mask shape: the encoder decides from the mask's content (modeling.py:219: HF honours any
+    attention_mask), never from a config flag."""
     torch.manual_seed(10 + ci)
-    cfg = PE.llama_config(pad_token_id=0, padding_side=side, **LLAMA_CFGS[ci])
+    cfg = PE.llama_config(pad_token_id=0, **LLAMA_CFGS[ci])
     enc = PE.LlamaEncoder(cfg).eval()
-    ids, m = _batch(np.random.RandomState(ci + 5), 6, 33, 96, left=(side == "left"))
+    rs = np.random.RandomState(ci + 5)
+    ids, m = _batch(rs, 6, 33, 96, left=(side == "left"))
+    if side == "mixed":
+        m = torch.tensor(_mixed_mask(rs, 6, 33))
     with torch.no_grad():
         got = enc(input_ids=ids, attention_mask=m).last_hidden_state
         ref = E.llama_forward(E.state_dict_to_f32(enc), cfg.to_dict(), ids, m)
-    # right padding runs WITHOUT the padding mask (pure causal): identical on every real token
+    # a right-padded mask runs WITHOUT the padding mask (pure causal): identical on every real token
+    assert torch.isfinite(got).all()
     assert (got - ref)[m.bool()].abs().max() < 3e-5
+    # and the packed fast path only accepts what it computes correctly
+    pooled = enc.pooled_last_token(ids, m)
+    if side == "right":
+        idx = (m.argmin(-1) - 1) % m.shape[-1]
+        assert (pooled - ref[torch.arange(6), idx]).abs().max() < 3e-5
+    else:
+        assert pooled is None
 
 
 def test_product_bert_vs_oracle_and_grads():

@@ -187,6 +187,139 @@ def test_gloo_gather_and_grad_reduce(world):
     assert all(ret.get(r) for r in range(world)), dict(ret)
 
 
+def _torch_infonce(q_local, p_local, temperature, use_inbatch_neg=True, q_all=None, p_all=None, q_row0=0, p_row0=0):
+    """Stand-in for ops.infonce_loss on CPU with the SAME contract: the loss over the gathered matrices, gradients to the
+    local rows only (the HIP kernel writes exactly those rows)."""
+    if q_all is None:
+        qa, pa = q_local, p_local
+    else:
+        qa, pa = q_all.clone(), p_all.clone()
+        qa = torch.cat([qa[:q_row0], q_local, qa[q_row0 + q_local.shape[0]:]], 0)
+        pa = torch.cat([pa[:p_row0], p_local, pa[p_row0 + p_local.shape[0]:]], 0)
+    s = qa @ pa.T / temperature
+    G = pa.shape[0] // qa.shape[0]
+    return torch.nn.functional.cross_entropy(s, torch.arange(qa.shape[0]) * G), s.detach()
+
+
+def _forward_worker(rank, world, port, ret):
+    """ModelForTraining.forward(negatives_cross_device=True) on real ranks (modeling.py:287-290, 331-404): row offsets, gather
+    order, returned gathered reps, loss and own-row gradients against the reference's 2-rank gloo run (crossdevice.npz).
+    The encoder and the scoring kernel are stubbed by torch ops (no GPU here): everything between them is the product."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import rankpo_amd
+        from rankpo_amd import encoder as PE, modeling, ops
+        g = np.load(os.path.join(ROOT, "tests", "golden", "crossdevice.npz"))
+        cfg = PE.llama_config(vocab_size=16, hidden_size=8, intermediate_size=8, num_hidden_layers=1,
+                              num_attention_heads=2, num_key_value_heads=1, pad_token_id=0)
+        ok = True
+        for fused in (True, False):
+            model = rankpo_amd.ModelForTraining(encoder=PE.LlamaEncoder(cfg), temperature=0.02,
+                                                negatives_cross_device=True, normalize_embeddings=True).train()
+            assert (model.process_rank, model.world_size) == (rank, world)
+            q = torch.tensor(g[f"w{world}_r{rank}_q"], requires_grad=True)
+            p = torch.tensor(g[f"w{world}_r{rank}_p"], requires_grad=True)
+            model.embed = lambda x: x["reps"]
+            if fused:       # one packed pass -> ONE q||p all-gather
+                model._embed_both = lambda qd, pd: torch.cat([qd["reps"], pd["reps"]], 0)
+            else:           # towers one after the other -> passage gather in flight during the query tower
+                model._embed_both = lambda qd, pd: None
+            real = ops.infonce_loss
+            ops.infonce_loss = _torch_infonce
+            try:
+                out = model(query={"reps": q, "input_ids": q}, passage={"reps": p, "input_ids": p})
+            finally:
+                ops.infonce_loss = real
+            out["loss"].backward()
+            ok = ok and abs(out.loss.item() - float(g[f"w{world}_r{rank}_loss"])) < 1e-9
+            ok = ok and np.allclose(out.scores.numpy(), g[f"w{world}_r{rank}_scores"], rtol=1e-9, atol=1e-9)
+            ok = ok and np.array_equal(out.q_reps.detach().numpy(), g[f"w{world}_r{rank}_q_reps"])
+            ok = ok and np.array_equal(out.p_reps.detach().numpy(), g[f"w{world}_r{rank}_p_reps"])
+            ok = ok and np.allclose(q.grad.numpy(), g[f"w{world}_r{rank}_dq"], rtol=1e-8, atol=1e-12)
+            ok = ok and np.allclose(p.grad.numpy(), g[f"w{world}_r{rank}_dp"], rtol=1e-8, atol=1e-12)
+        # a parameter that gets no gradient must not leave its bucket un-reduced (FlatGradAllReducer.finish)
+        from rankpo_amd.distributed import FlatGradAllReducer
+        torch.manual_seed(0)
+        used, unused = torch.nn.Linear(6, 4), torch.nn.Linear(4, 2)
+        params = list(used.parameters()) + list(unused.parameters())
+        red = FlatGradAllReducer(params, bucket_mb=1e-5)
+        assert len(red.buckets) >= 3
+        red.arm()
+        used(torch.full((3, 6), float(rank + 1))).sum().backward()       # `unused` never fires its hooks
+        scale = red.finish()
+        assert red.late_buckets >= 1
+        wg = used.weight.grad * scale
+        exp = sum(torch.full((4, 6), 3.0 * (r + 1)) for r in range(world)) / world
+        ok = ok and torch.allclose(wg, exp) and float(unused.weight.grad.abs().sum()) == 0.0
+        # the same reduced values on every rank
+        chk = red.flat.clone()
+        dist.all_reduce(chk, op=dist.ReduceOp.MAX)
+        ok = ok and torch.equal(chk, red.flat)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2])
+def test_gloo_model_forward_cross_device(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_forward_worker, args=(world, 29713, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` outside torchrun starts N fresh rank processes (scripts/train/run_contrastive.sh:27-30 does
+    the same with torchrun) and relays ONE JSON line; under torch.distributed.run it runs as a rank.  CPU rehearsal of the
+    launch + barrier + max-over-ranks only (no GPU here)."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-launch"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and json.loads(lines[0]) == {"rehearsal": "launch", "n_gpus": 2, "max_over_ranks": 2.0}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", "29717", bench, "--gpus", "2", "--rehearse-launch"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert [json.loads(ln)["n_gpus"] for ln in r.stdout.splitlines() if ln.startswith("{")] == [2]
+    # a world-size mismatch is refused, not silently run
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-launch"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in r.stderr
+
+
+def test_bench_attention_flops_follow_the_kernel_arguments():
+    """bench.py prices flash attention from the lengths the encoder hands to the kernels (filler sequence included), keyed by
+    the packed token count the C call receives; an unknown count is an error, never 0 flops (round 1's driver line)."""
+    import importlib
+    bench = importlib.import_module("bench")
+    from rankpo_amd import ops
+    real = ops.attn_tile_table
+    try:
+        bench._ATTN_PAIRS.clear()
+        bench.hook_attn_tables()
+        lens = [1280, 700, 4096, 3000, 140]                   # 9216 = 36 * 256 after a 0-token filler? no: add one below
+        lens = lens + [(-sum(lens)) % 256 or 256]
+        ops.attn_tile_table(lens, "cpu")
+        T = sum(lens)
+        assert T % 256 == 0
+        a = [None] * 19
+        a[15:19] = T, 32, 8, 64
+        nbytes, flops = bench._algo("rpo_flash_attn_bwd", a)
+        assert flops == 10 * 64 * 32 * sum(n * (n + 1) // 2 for n in lens) > 0
+        a[15] = T - 1
+        with pytest.raises(KeyError, match="no sequence lengths registered"):
+            bench._algo("rpo_flash_attn_bwd", a)
+    finally:
+        ops.attn_tile_table = real
+
+
 def test_compute_metrics_matches_reference(golden):
     from rankpo_amd.retrieval import compute_metrics
     g = golden("metrics")
