@@ -301,16 +301,26 @@ def cpu_baseline(model, cfg, temperature, sample=(40, 85, 4, 3), repeats=3):
     batch = {"query": mk(Q_s, Lq_s), "passage": mk(Q_s * G_s, Lp_s)}
     times = []
     for i in range(repeats + 1):
-        for t in w.values():
-            t.grad = None
         t0 = time.perf_counter()
-        loss, scores, q, p = E.contrastive_step(w, cd, batch, temperature)
-        loss.backward()
+        ref = oracle_step(w, cd, batch, temperature)
         if i:                                   # step 0 warms the allocator and the thread pool
             times.append(time.perf_counter() - t0)
-    grads = {k: w[k].grad.clone() for k in ("embed_tokens.weight", "layers.0.self_attn.q_proj.weight") if k in w}
-    ref = dict(loss=float(loss.detach()), scores=scores.detach().float(), q=q.detach(), p=p.detach(), grads=grads)
     return sorted(times)[len(times) // 2], times, Q_s * (Lq_s + G_s * Lp_s), cores, batch, ref
+
+
+PARITY_GRADS = ("embed_tokens.weight", "layers.0.self_attn.q_proj.weight")
+
+
+def oracle_step(w, cd, batch, temperature):
+    """One float32 training micro-step of the oracle (oracle/encoder_ref.py: contrastive_step + backward) on a dict of
+    float32 leaf weights: what `step_parity` compares against and what `cpu_baseline` times."""
+    from oracle import encoder_ref as E
+    for t in w.values():
+        t.grad = None
+    loss, scores, q, p = E.contrastive_step(w, cd, batch, temperature)
+    loss.backward()
+    grads = {k: w[k].grad.clone() for k in PARITY_GRADS if k in w}
+    return dict(loss=float(loss.detach()), scores=scores.detach().float(), q=q.detach(), p=p.detach(), grads=grads)
 
 
 def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
@@ -335,17 +345,12 @@ def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
             out["grad_rel_err:" + n] = float((grads[n].float().cpu() - gr).norm() / gr.norm().clamp_min(1e-30))
         return out
 
-    was = [p.grad for p in params.values()]
-    for p in params.values():
-        p.grad = None
     out = model(**dev_batch)
-    got = torch.autograd.grad(out["loss"], [params[n] for n in names])
+    got = torch.autograd.grad(out["loss"], [params[n] for n in names]) if names else ()   # .grad buffers stay untouched
     fast = stats(out["loss"].detach(), out["scores"].detach(), dict(zip(names, got)))
-    for p, g in zip(params.values(), was):
-        p.grad = g
     wd = {k: v.detach().to(device, dtype).requires_grad_(k in names) for k, v in model.model.state_dict().items()}
     loss_c, s_c = E.contrastive_step(wd, cfg.to_dict(), dev_batch, temperature, dtype=dtype)[:2]
-    got_c = torch.autograd.grad(loss_c, [wd[n] for n in names])
+    got_c = torch.autograd.grad(loss_c, [wd[n] for n in names]) if names else ()
     ctrl = stats(loss_c.detach(), s_c.detach(), dict(zip(names, got_c)))
     # floors: float32 round-off (both paths are then ~1e-7 on a cosine and the ratio of two round-off errors means nothing)
     tol = {"cos_rms_err": 1.5 * ctrl["cos_rms_err"] + 5e-6, "cos_max_err": 1.5 * ctrl["cos_max_err"] + 5e-6,
@@ -415,6 +420,8 @@ def main():
     ap.add_argument("--ckpt-layers", type=int, default=-2,
                     help="checkpoint the first k blocks (-2 = as few as fit in 72%% of HBM, -1 = all, 0 = none)")
     ap.add_argument("--padded", action="store_true", help="run the encoder on padded batches (reference behaviour)")
+    ap.add_argument("--no-fill", action="store_true", help="A/B: no filler sequence rounding the packed token count to 256")
+    ap.add_argument("--no-linear-tn", action="store_true", help="A/B: torch's own operand layout for the input-gradient GEMMs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -464,6 +471,10 @@ def main():
     with torch.device(device):
         enc = build_encoder(cfg)
     enc = enc.to(dtype)
+    if args.no_fill:
+        enc.pack_fill = False
+    if args.no_linear_tn:
+        rankpo_amd.ops.LINEAR_TN = False
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
                                         negatives_cross_device=multi, unpad=not args.padded).train()
     hook_attn_tables()

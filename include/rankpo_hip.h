@@ -6,8 +6,18 @@
  * stock-PyTorch op sequence at the cited reference lines.  Plain device pointers + sizes + a HIP stream;
  * no torch types.  Every call is asynchronous on `stream`, allocates nothing, never synchronises with
  * the host, never throws and never exits: it returns RPO_OK or a negative rpo_status.  All buffers are
- * owned by the caller.  The library keeps no global mutable state, so forward may be called from the
- * Python main thread and backward from PyTorch's autograd thread concurrently on different streams.
+ * owned by the caller.  The library keeps no global mutable state and reads no environment variable, so
+ * forward may be called from the Python main thread and backward from PyTorch's autograd thread
+ * concurrently on different streams, and two callers in one process cannot disagree about a kernel variant.
+ *
+ * Deviation from SURVEY.md §8b(5), deliberate: there is no `rpo_allgather_qp`.  The cross-device exchange of the
+ * path (modeling.py:287-290, 331-404) is ONE rank-major all-gather of a [B + B G, d] block with no arithmetic in it;
+ * the RCCL communicator it needs is the one torch.distributed already owns (bootstrap, stream ordering against the
+ * caching allocator, async work handles), and a second communicator created behind the C ABI would double RCCL's
+ * per-peer xGMI buffers and need its own bootstrap for nothing.  The gather therefore stays on the host side
+ * (rankpo_amd/distributed.py: FusedQPGather); what the library contributes to the exchange is that the InfoNCE
+ * kernels take the GATHERED matrices plus this rank's row window (q_row0 / q_rows / p_row0 / p_rows below) and
+ * write gradients for exactly those rows, which is what removes the backward collective.
  *
  * Embedding matrices are row-major [rows, d] with a contiguous inner dimension; dtype selects the
  * storage type of embeddings / hidden states / scores (f32 or bf16; accumulation is always f32).
@@ -211,13 +221,16 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
 
 /* Backward of rpo_flash_attn_fwd (three launches, no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
  * forward with lse_max_len == 0; delta: f32 [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale, the initial accumulators of the dP and S chains).  q_tiles as in the
- * forward; k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a 256-key block) sorted by (sequence, head, key).
+ * forward; k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a key block); key_block = the number of
+ * keys one entry stands for and thereby the dK/dV kernel that consumes the table: 256 (one wave per SIMD, entries dealt to
+ * the 8 XCDs in equal eighths, padded with first key >= 2^30) or 64 (the 8-wave kernel; entries sorted by (sequence, head,
+ * key)).  Any other value is RPO_ERR_UNSUPPORTED: the meaning of the table is an argument, never process-global state.
  * dq: [T, num_heads, 64], dk / dv: [T, num_kv_heads, 64] (token strides given), every valid row is written. */
 int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, int64_t q_stride,
                        int64_t k_stride, int64_t v_stride, int64_t out_stride, int64_t dout_stride,
                        const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles, const int* k_tiles,
-                       int64_t n_k_tiles, int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads,
-                       int64_t head_dim, float scale, const float* lse, float* delta, void* dq, void* dk, void* dv,
+                       int64_t n_k_tiles, int64_t key_block, int64_t total_tokens, int64_t num_heads,
+                       int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta, void* dq, void* dk, void* dv,
                        int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, rpo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------

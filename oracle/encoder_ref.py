@@ -103,8 +103,14 @@ def bert_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: to
     d, nh, eps = cfg["hidden_size"], cfg["num_attention_heads"], cfg["layer_norm_eps"]
     hd = d // nh
     N, L = input_ids.shape
-    x = (W("embeddings.word_embeddings.weight")[input_ids] + W("embeddings.token_type_embeddings.weight")[0]
-         + W("embeddings.position_embeddings.weight")[:L][None])
+    arch = (cfg.get("architectures") or ["BertModel"])[0]
+    if "Roberta" in arch:     # HF create_position_ids_from_input_ids: non-pad tokens count from padding_idx + 1
+        pad = cfg["pad_token_id"]
+        keep = (input_ids != pad).long()
+        pos = W("embeddings.position_embeddings.weight")[torch.cumsum(keep, 1) * keep + pad]
+    else:
+        pos = W("embeddings.position_embeddings.weight")[:L][None]
+    x = W("embeddings.word_embeddings.weight")[input_ids] + W("embeddings.token_type_embeddings.weight")[0] + pos
     x = _ln(x, W("embeddings.LayerNorm.weight"), W("embeddings.LayerNorm.bias"), eps)
     bias = torch.zeros(N, 1, 1, L, dtype=dtype).masked_fill(~attention_mask.bool()[:, None, None, :],
                                                             torch.finfo(dtype).min)

@@ -2109,13 +2109,17 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
 extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                                   int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t out_stride,
                                   int64_t dout_stride, const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles,
-                                  const int* k_tiles, int64_t n_k_tiles, int64_t total_tokens, int64_t num_heads,
+                                  const int* k_tiles, int64_t n_k_tiles, int64_t key_block, int64_t total_tokens,
+                                  int64_t num_heads,
                                   int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta,
                                   void* dq, void* dk, void* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
                                   rpo_stream_t stream) {
     if (!q || !k || !v || !out || !dout || !cu_seqlens || !q_tiles || !k_tiles || !lse || !delta || !dq || !dk || !dv)
         return RPO_ERR_INVALID_ARG;
     if (n_q_tiles <= 0 || n_k_tiles <= 0 || total_tokens <= 0) return RPO_ERR_INVALID_ARG;
+    // `key_block` states what the entries of `k_tiles` mean: blocks of 256 keys (one-wave-per-SIMD dK/dV kernel) or of 64
+    // keys (the 8-wave kernel).  The caller that built the table says so; nothing is read from the environment.
+    if (key_block != 256 && key_block != 64) return RPO_ERR_UNSUPPORTED;
     if (head_dim != kFaHD || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 || num_heads > 65535)
         return RPO_ERR_UNSUPPORTED;
     if (q_stride % 8 || k_stride % 8 || v_stride % 8 || out_stride % 8 || dout_stride % 8 || dq_stride % 4 ||
@@ -2137,10 +2141,7 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
     const unsigned dkdv_grid = (unsigned)(((n_k_tiles + 7) / 8) * 8);
-    static const bool use_v1 = [] {                           // RPO_FA_DKDV=v1: the 8-wave kernel (A/B)
-        const char* e = getenv("RPO_FA_DKDV");
-        return e && !strcmp(e, "v1");
-    }();
+    const bool use_v1 = key_block == 64;
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds);
         (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDkdv4Lds);

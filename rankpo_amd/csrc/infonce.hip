@@ -909,21 +909,6 @@ struct Plan {
 
 template <typename T> constexpr int row_elems() { return kTileRowBytes / (int)sizeof(T); }
 
-static bool force_small_tile() {   // RPO_SIM_TILE=128 keeps the 128x128 kernel (A/B comparisons, tests)
-    static const int v = [] { const char* e = getenv("RPO_SIM_TILE"); return e && atoi(e) == 128 ? 1 : 0; }();
-    return v != 0;
-}
-
-static int sim_stagger() {   // RPO_SIM_STAGGER=0/1 (experiments); default on
-    const char* e = getenv("RPO_SIM_STAGGER");
-    return e ? atoi(e) : 1;
-}
-
-static int sim_dbg() {   // RPO_SIM_DBG bit 0: skip the score stores (timing experiments only)
-    const char* e = getenv("RPO_SIM_DBG");
-    return e ? atoi(e) : 0;
-}
-
 static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) {
     Plan pl{};
     const int es = dtype == RPO_DT_BF16 ? 2 : 4;
@@ -942,7 +927,7 @@ static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) 
         }
     } else {
         // the 256 x 256 kernel runs one block per CU: take it only when its grid can fill most of the 256 CUs
-        const bool big = dtype == RPO_DT_BF16 && !force_small_tile() &&
+        const bool big = dtype == RPO_DT_BF16 &&
                          rpo_cdiv(P, kBigTile) * rpo_cdiv(Q, kBigTile) >= 192;
         const int tile = big ? kBigTile : kTileP;
         pl.path = big ? PATH_TILE256 : PATH_TILE;
@@ -1006,7 +991,7 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
             }
             RPO_LAUNCH(sim_tile256_kernel, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kBigThreads), kBigLdsBytes, st,
                        (const bf16_t*)q, (const bf16_t*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
-                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, sim_stagger(), sim_dbg());
+                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0);
         }
     } else if (pl.path == PATH_SKINNY) {
         const dim3 grid((unsigned)pl.nPb), block(kSkinnyThreads);

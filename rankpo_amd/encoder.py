@@ -88,6 +88,16 @@ def bge_small_config(**kw):
     return bert_config(**kw)
 
 
+def xlm_roberta_config(**kw) -> EncoderConfig:
+    """XLM-RoBERTa (BGE-M3's backbone, which the reference names next to BGE: README / modeling.py:231 CLS branch): the BERT
+    block with RoBERTa's position ids (`BertEmbeddings.forward`), pad id 1, one token type, eps 1e-5."""
+    d = dict(architectures=["XLMRobertaModel"], model_type="xlm-roberta", vocab_size=250002, hidden_size=1024,
+             intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, max_position_embeddings=8194,
+             type_vocab_size=1, layer_norm_eps=1e-5, pad_token_id=1)
+    d.update(kw)
+    return bert_config(**d)
+
+
 class EncoderOutput(dict):
     """`.last_hidden_state` + dict access, like transformers' ModelOutput."""
 
@@ -375,6 +385,7 @@ class LlamaEncoder(nn.Module):
         self.register_buffer("inv_freq", _rope_inv_freq(config), persistent=False)
         self.gradient_checkpointing = False
         self.checkpoint_layers = None      # None = all layers when gradient_checkpointing, else the first k
+        self.pack_fill = True              # packed path: round the token count up to a multiple of 256 with a filler sequence
         self.apply(self._init)
 
     def _init(self, m):
@@ -494,7 +505,7 @@ class LlamaEncoder(nn.Module):
         # and, having no gradient, it contributes exact zeros to every weight gradient.
         n_fill = 0
         if (ids_parts[0].is_cuda and self.embed_tokens.weight.dtype == torch.bfloat16 and sum(lens) >= 4096
-                and os.environ.get("RPO_FILL", "1") != "0"):
+                and self.pack_fill):
             n_fill = (-sum(lens)) % 256
         if n_fill:
             pad_id = self.config.pad_token_id if self.config.pad_token_id is not None else 0
@@ -539,12 +550,20 @@ class BertEmbeddings(nn.Module):
         self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, cfg.hidden_size)
         self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, cfg.hidden_size)
         self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        # RoBERTa family (XLM-R / BGE-M3): position ids count the NON-PAD tokens and start at padding_idx + 1; pad tokens
+        # sit on padding_idx (HF create_position_ids_from_input_ids).  BERT: plain arange.
+        self.roberta_positions = "Roberta" in cfg.architectures[0]
+        self.pad_id = cfg.pad_token_id
 
     def forward(self, input_ids, token_type_ids=None):
         L = input_ids.shape[1]
-        pos = torch.arange(L, device=input_ids.device)
+        if self.roberta_positions:
+            keep = input_ids.ne(self.pad_id).to(torch.int64)
+            pos_emb = self.position_embeddings(torch.cumsum(keep, dim=1) * keep + self.pad_id)
+        else:
+            pos_emb = self.position_embeddings(torch.arange(L, device=input_ids.device))[None]
         tt = self.token_type_embeddings.weight[0] if token_type_ids is None else self.token_type_embeddings(token_type_ids)
-        return self.LayerNorm(self.word_embeddings(input_ids) + tt + self.position_embeddings(pos)[None])
+        return self.LayerNorm(self.word_embeddings(input_ids) + tt + pos_emb)
 
 
 class _BertSelf(nn.Module):
@@ -654,9 +673,9 @@ def build_encoder(config: EncoderConfig) -> nn.Module:
     arch = config.architectures[0]
     if "Llama" in arch:
         return LlamaEncoder(config)
-    if "Bert" in arch or "XLMRoberta" in arch:
+    if "Bert" in arch or "Roberta" in arch:       # XLMRoberta* / Roberta*: the BERT block + RoBERTa position ids
         return BertEncoder(config)
-    raise ValueError(f"unsupported architecture {arch!r} (Llama* and Bert* encoders are implemented)")
+    raise ValueError(f"unsupported architecture {arch!r} (Llama*, Bert* and (XLM)Roberta* encoders are implemented)")
 
 
 def load_encoder(path: str, torch_dtype=None) -> nn.Module:
@@ -664,19 +683,21 @@ def load_encoder(path: str, torch_dtype=None) -> nn.Module:
     from safetensors.torch import load_file
     with open(os.path.join(path, "config.json")) as f:
         raw = json.load(f)
-    arch = (raw.get("architectures") or ["LlamaModel" if raw.get("model_type") == "llama" else "BertModel"])[0]
+    default_arch = {"llama": "LlamaModel", "xlm-roberta": "XLMRobertaModel", "roberta": "RobertaModel"}
+    arch = (raw.get("architectures") or [default_arch.get(raw.get("model_type"), "BertModel")])[0]
     raw["architectures"] = [arch]
     cfg = llama_config(**raw) if "Llama" in arch else bert_config(**raw)
     with torch.device("meta"):
         enc = build_encoder(cfg)
     sd = load_file(os.path.join(path, "model.safetensors"))
     sd = {(k[len("model."):] if k.startswith("model.") and "Llama" in arch else k): v for k, v in sd.items()}
-    sd = {(k[len("bert."):] if k.startswith("bert.") else k): v for k, v in sd.items()}
+    for prefix in ("bert.", "roberta."):            # checkpoints saved from a *ForMaskedLM / *ForSequenceClassification head
+        sd = {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in sd.items()}
     enc = enc.to_empty(device="cpu")
     missing, unexpected = enc.load_state_dict(sd, strict=False)
     missing = [m for m in missing if "inv_freq" not in m]
     unexpected = [u for u in unexpected if not (u.startswith("pooler.") or u.startswith("lm_head.") or
-                                               "position_ids" in u)]
+                                               "position_ids" in u or "token_type_ids" in u)]
     if missing or unexpected:
         raise RuntimeError(f"checkpoint {path} does not match the encoder: missing={missing} unexpected={unexpected}")
     if "Llama" in arch:

@@ -6,7 +6,6 @@ done by librankpo_hip.so.  There is no fallback: tensors must live on a HIP devi
 from __future__ import annotations
 
 import ctypes as C
-import os as _os
 from dataclasses import dataclass
 
 import torch
@@ -273,6 +272,9 @@ def _swiglu_fwd(lib, gu, prod, rows, ff):
     return prod
 
 
+LINEAR_TN = True      # input-gradient GEMMs against a transposed copy of the weight (`_LinearTN`); bench.py --no-linear-tn
+
+
 class _LinearTN(torch.autograd.Function):
     """y = x W^T (W [n, k], the nn.Linear layout) whose input gradient dX = dY W is computed against a transposed COPY of W:
     hipBLASLt's kernels for that operand layout (both operands contiguous along the reduction, the forward's layout) run
@@ -298,7 +300,7 @@ class _LinearTN(torch.autograd.Function):
 def linear(x, w, bias=None):
     """F.linear; on HIP tensors without bias and with gradients enabled the backward uses `_LinearTN`."""
     if (bias is None and x.is_cuda and torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
-            and _os.environ.get("RPO_LINEAR_TN", "1") != "0"):
+            and LINEAR_TN):
         return _LinearTN.apply(x, w)
     return torch.nn.functional.linear(x, w, bias)
 
@@ -327,7 +329,7 @@ class _SwiGLUDown(torch.autograd.Function):
         es = gu.element_size()
         # dprod first; ONE pass then reads g, u, dprod and writes dg, du AND the recomputed product over dprod (6 units of
         # [T, ff] traffic instead of 3 + 5 for a separate recompute), which the weight gradient consumes afterwards
-        if _os.environ.get("RPO_LINEAR_TN", "1") != "0":
+        if LINEAR_TN:
             dprod = torch.nn.functional.linear(dy, weight.t().contiguous())   # dy @ W through the faster operand layout (see _LinearTN)
         else:
             dprod = dy @ weight
@@ -496,13 +498,20 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
     return out, lse
 
 
-def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 0):
-    """int32 [n, 3] = (sequence id, kv head, first key of a key block), sorted by (sequence, head, key): the key blocks of one
-    (sequence, kv head) read the same Q / dO rows and are placed on one XCD by the kernel's block -> entry map.  Block =
-    256 keys (the one-wave-per-SIMD dK/dV kernel); 64 when RPO_FA_DKDV=v1 selects the 8-wave kernel (A/B)."""
-    import os
-    if block_n <= 0:
-        block_n = 64 if os.environ.get("RPO_FA_DKDV") == "v1" else 256
+ATTN_KEY_BLOCK = 256     # keys per entry of the dK/dV work list (256: one-wave-per-SIMD kernel; 64: the 8-wave kernel)
+
+
+def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = ATTN_KEY_BLOCK):
+    """int32 [n, 3] = (sequence id, kv head, first key of a key block): the key blocks of one (sequence, kv head) read the same
+    Q / dO rows and are placed on one XCD by the kernel's block -> entry map.  block_n = 256 keys (default, the
+    one-wave-per-SIMD dK/dV kernel) or 64 (the 8-wave kernel, A/B); whoever builds a table with block_n = 64 passes
+    key_block=64 to `flash_attn_varlen(_qkv)` as well -- it is an argument of the C call, not an environment switch."""
+    if block_n not in (64, 256):
+        raise ValueError("attn_key_tile_table: block_n must be 64 or 256")
+    return _attn_key_tile_table(lens, device, num_kv_heads, block_n)
+
+
+def _attn_key_tile_table(lens, device, num_kv_heads, block_n):
     import numpy as np
     if block_n != 256:
         parts = []
@@ -540,9 +549,10 @@ def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = 0):
     return torch.from_numpy(np.concatenate(out, 0)).to(device, non_blocking=True)
 
 
-def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale, grads=None):
+def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale, grads=None,
+                          key_block: int = ATTN_KEY_BLOCK):
     """grads: optional preallocated (dq, dk, dv) [T, heads, 64] views with arbitrary token strides (e.g. the three column
-    blocks of ONE fused d(q|k|v) buffer)."""
+    blocks of ONE fused d(q|k|v) buffer).  key_block: keys per entry of `k_tiles` (`attn_key_tile_table`'s block_n)."""
     lib = _lib.load()
     T, nh, hd = q.shape
     nkv = k.shape[1]
@@ -561,7 +571,7 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
         check(lib.rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0),
                                      cu_seqlens.data_ptr(), q_tiles.data_ptr(), q_tiles.shape[0], k_tiles.data_ptr(),
-                                     k_tiles.shape[0], T, nh, nkv, hd, scale, lse.data_ptr(), delta.data_ptr(),
+                                     k_tiles.shape[0], key_block, T, nh, nkv, hd, scale, lse.data_ptr(), delta.data_ptr(),
                                      dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0), dk.stride(0), dv.stride(0),
                                      _stream(q)), "rpo_flash_attn_bwd")
     return dq, dk, dv
@@ -572,29 +582,29 @@ class _FlashAttnVarlen(torch.autograd.Function):
     PyTorch's flash-attention backward op on the saved (out, padded lse) when k_tiles is None."""
 
     @staticmethod
-    def forward(ctx, q, k, v, cu, tiles, k_tiles, max_len, scale):
+    def forward(ctx, q, k, v, cu, tiles, k_tiles, max_len, scale, key_block):
         own_bwd = k_tiles is not None
         out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0 if own_bwd else max_len,
                                          num_seqs=cu.numel() - 1)
         ctx.save_for_backward(q, k, v, out, lse, cu, tiles, k_tiles if own_bwd else cu)
-        ctx.meta = (max_len, scale, own_bwd)
+        ctx.meta = (max_len, scale, own_bwd, key_block)
         return out
 
     @staticmethod
     def backward(ctx, go):
         q, k, v, out, lse, cu, tiles, k_tiles = ctx.saved_tensors
-        max_len, scale, own_bwd = ctx.meta
+        max_len, scale, own_bwd, key_block = ctx.meta
         if own_bwd:
-            dq, dk, dv = flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale)
+            dq, dk, dv = flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale, key_block=key_block)
         else:
             z = torch.zeros((), dtype=torch.int64, device=q.device)
             dq, dk, dv = torch.ops.aten._flash_attention_backward(go.contiguous(), q, k, v, out, lse, cu, cu, max_len,
                                                                   max_len, 0.0, True, z, z, scale=scale)
-        return dq, dk, dv, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None
 
 
-def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale, k_tiles=None):
-    return _FlashAttnVarlen.apply(q, k, v, cu, tiles, k_tiles, max_len, scale)
+def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale, k_tiles=None, key_block: int = ATTN_KEY_BLOCK):
+    return _FlashAttnVarlen.apply(q, k, v, cu, tiles, k_tiles, max_len, scale, key_block)
 
 
 class _FlashAttnVarlenQKV(torch.autograd.Function):
@@ -611,29 +621,29 @@ class _FlashAttnVarlenQKV(torch.autograd.Function):
                 x[:, nq + nk:].unflatten(1, (nkv, 64)))
 
     @staticmethod
-    def forward(ctx, qkv, nh, nkv, cu, tiles, k_tiles, scale):
+    def forward(ctx, qkv, nh, nkv, cu, tiles, k_tiles, scale, key_block):
         q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv)
         out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0, num_seqs=cu.numel() - 1)
         ctx.save_for_backward(qkv, out, lse, cu, tiles, k_tiles)
-        ctx.meta = (nh, nkv, scale)
+        ctx.meta = (nh, nkv, scale, key_block)
         return out
 
     @staticmethod
     def backward(ctx, go):
         qkv, out, lse, cu, tiles, k_tiles = ctx.saved_tensors
-        nh, nkv, scale = ctx.meta
+        nh, nkv, scale, key_block = ctx.meta
         q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv)
         dqkv = torch.empty_like(qkv)
         flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale,
-                              grads=_FlashAttnVarlenQKV._views(dqkv, nh, nkv))
-        return dqkv, None, None, None, None, None, None
+                              grads=_FlashAttnVarlenQKV._views(dqkv, nh, nkv), key_block=key_block)
+        return dqkv, None, None, None, None, None, None, None
 
 
-def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale):
+def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block: int = ATTN_KEY_BLOCK):
     """qkv: [T, (num_heads + 2 num_kv_heads) * 64] bf16, contiguous rows -> out [T, num_heads, 64]."""
     if qkv.dim() != 2 or qkv.shape[1] != (num_heads + 2 * num_kv_heads) * 64 or not qkv.is_contiguous():
         raise ValueError("flash_attn_varlen_qkv: qkv must be a contiguous [T, (nh + 2 nkv) * 64] tensor")
-    return _FlashAttnVarlenQKV.apply(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale)
+    return _FlashAttnVarlenQKV.apply(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -4,8 +4,8 @@ used by src/evaluate.py and src/get_hard_negatives.py through FAISS `IndexFlatIP
 `FlatIPIndex.search` is the flat-index search: the corpus is walked in chunks; scores = Q C_chunk^T come from the HIP
 similarity kernel of the hot path (f32 storage -> f32 MFMA, like FAISS' sgemm) and `rpo_topk_merge` folds every chunk's
 scores into the k winners per query (value descending, ties by the smaller corpus index) -- the [nq, ntotal] score matrix is
-never materialised, so the corpus size is bounded by the embeddings alone (288 GB of HBM: ~35 M rows of d = 2048 in f32).  `compute_metrics` follows the reference's definitions exactly, including its
-non-standard Recall denominator `max(min(cutoff, len(pred), len(label)), 1)` and the flattened "naive AUC".
+never materialised, so the corpus size is bounded by the embeddings alone (288 GB of HBM: ~35 M rows of d = 2048 in f32).  `compute_metrics` keeps the reference's definitions (its non-standard Recall denominator
+`max(min(cutoff, len(pred), len(label)), 1)`, the flattened "naive AUC") but computes them on one boolean hit matrix.
 """
 from __future__ import annotations
 
@@ -56,37 +56,63 @@ def faiss_search(index: FlatIPIndex, query_embedding, topk: int = 100, batch_siz
 
 
 def compute_metrics(preds, preds_scores, labels, cutoffs: Sequence[int] = (1, 5, 10, 20, 100)):
-    """MRR / Recall / AUC / nDCG at cutoffs (utils.py:87-153)."""
+    """MRR / Recall / AUC / nDCG at cutoffs with the reference's definitions (utils.py:87-153), computed on ONE boolean hit
+    matrix instead of per-query Python loops:
+
+      hit[i, j]  = preds[i][j] is one of labels[i]
+      MRR@c      = mean_i ( 1 / r_i  if r_i <= c else 0 ),  r_i = 1-based rank of the first hit of query i
+      Recall@c   = mean_i ( #distinct ids of preds[i][:c] that are labels / max(min(c, len(preds[i]), len(labels[i])), 1) )
+                   (the reference's non-standard denominator; len(labels[i]) counts duplicates, the numerator does not)
+      AUC@c      = roc_auc_score over the flattened first c columns of (hit, score)  ("naive AUC")
+      nDCG@c     = sklearn ndcg_score(hit, score, k=c)
+
+    Returns a dict in the reference's key order: all MRR@, then Recall@, AUC@, nDCG@.  preds may be ragged for MRR / Recall;
+    AUC / nDCG need a rectangular [N, k] prediction matrix, as in the reference."""
+    import warnings
     from sklearn.metrics import ndcg_score, roc_auc_score
-    assert len(preds) == len(labels), "shape not match for predictions and labels"
-    cutoffs = list(cutoffs)
-    if any(len(x) < max(cutoffs) for x in preds):
-        print(f"Warning: No enough predictions for some cutoffs, e.g. cutoff {max(cutoffs)}")
+    n = len(preds)
+    if n != len(labels):
+        raise AssertionError(f"compute_metrics: {n} prediction rows but {len(labels)} label rows")
+    cut = np.asarray(list(cutoffs), dtype=np.int64)
+    plen = np.fromiter((len(r) for r in preds), dtype=np.int64, count=n)
+    llen = np.fromiter((len(r) for r in labels), dtype=np.int64, count=n)
+    width = int(plen.max()) if n else 0
+    if n and int(plen.min()) < int(cut.max()):
+        warnings.warn(f"compute_metrics: some queries have fewer than {int(cut.max())} predictions", stacklevel=2)
+
+    # ids of any hashable / comparable kind -> dense codes; (row, code) -> one int64 key per entry
+    flat_p = np.concatenate([np.asarray(r).reshape(-1) for r in preds]) if width else np.zeros(0, dtype=np.int64)
+    flat_l = np.concatenate([np.asarray(r).reshape(-1) for r in labels]) if llen.sum() else flat_p[:0]
+    _, codes = np.unique(np.concatenate([flat_p, flat_l]), return_inverse=True)
+    ncode = int(codes.max()) + 1 if codes.size else 1
+    prow = np.repeat(np.arange(n), plen)
+    pkey = prow * ncode + codes[:flat_p.size]
+    lkey = np.repeat(np.arange(n), llen) * ncode + codes[flat_p.size:]
+    pcol = np.arange(flat_p.size) - np.repeat(np.cumsum(plen) - plen, plen)
+    hit = np.zeros((n, width), dtype=bool)
+    hit[prow, pcol] = np.isin(pkey, lkey)
+    # first occurrence of an id inside its own row (a repeated prediction counts once towards Recall)
+    order = np.argsort(pkey, kind="stable")
+    dup = np.zeros(flat_p.size, dtype=bool)
+    dup[order[1:]] = pkey[order[1:]] == pkey[order[:-1]]
+    fresh = np.zeros((n, width), dtype=bool)
+    fresh[prow, pcol] = ~dup
+
     metrics = {}
-    mrrs = np.zeros(len(cutoffs))
-    for pred, label in zip(preds, labels):
-        label = set(label)
-        for i, x in enumerate(pred, 1):
-            if x in label:                                   # first hit only
-                for j, cutoff in enumerate(cutoffs):
-                    if i <= cutoff:
-                        mrrs[j] += 1 / i
-                break
-    mrrs /= len(preds)
-    for i, cutoff in enumerate(cutoffs):
-        metrics[f"MRR@{cutoff}"] = mrrs[i]
-    recalls = np.zeros(len(cutoffs))
-    for pred, label in zip(preds, labels):
-        for i, cutoff in enumerate(cutoffs):
-            common = np.intersect1d(label, pred[:cutoff])
-            recalls[i] += len(common) / max(min(cutoff, len(pred), len(label)), 1)
-    recalls /= len(preds)
-    for i, cutoff in enumerate(cutoffs):
-        metrics[f"Recall@{cutoff}"] = recalls[i]
-    hard = np.asarray([np.isin(pred, label).astype(int).tolist() for pred, label in zip(preds, labels)])
-    preds_scores = np.asarray(preds_scores)
-    for cutoff in cutoffs:
-        metrics[f"AUC@{cutoff}"] = roc_auc_score(hard[:, :cutoff].flatten(), preds_scores[:, :cutoff].flatten())
-    for cutoff in cutoffs:
-        metrics[f"nDCG@{cutoff}"] = ndcg_score(hard, preds_scores, k=cutoff)
+    rank = np.where(hit.any(1), hit.argmax(1) + 1, np.iinfo(np.int64).max) if width else np.full(n, np.iinfo(np.int64).max)
+    rr = np.where(rank[:, None] <= cut[None, :], 1.0 / np.minimum(rank, 2 ** 40)[:, None], 0.0)          # [n, cutoffs]
+    for c, v in zip(cut, rr.mean(0) if n else np.zeros(len(cut))):
+        metrics[f"MRR@{int(c)}"] = v
+    found = np.concatenate([np.zeros((n, 1), dtype=np.int64), np.cumsum(hit & fresh, axis=1)], 1)        # found[:, j]: in the first j
+    upto = np.minimum(cut[None, :], plen[:, None])
+    denom = np.maximum(np.minimum(upto, llen[:, None]), 1)
+    rec = np.take_along_axis(found, upto, 1) / denom
+    for c, v in zip(cut, rec.mean(0) if n else np.zeros(len(cut))):
+        metrics[f"Recall@{int(c)}"] = v
+    hard = hit.astype(int)
+    sc = np.asarray(preds_scores)
+    for c in cut:
+        metrics[f"AUC@{int(c)}"] = roc_auc_score(hard[:, :c].ravel(), sc[:, :c].ravel())
+    for c in cut:
+        metrics[f"nDCG@{int(c)}"] = ndcg_score(hard, sc, k=int(c))
     return metrics

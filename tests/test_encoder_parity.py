@@ -77,6 +77,36 @@ def _mixed_mask(rs, N, L):
     return m
 
 
+def test_xlm_roberta_vs_transformers():
+    """XLM-R (BGE-M3's backbone): same block as BERT but position ids = padding_idx + cumsum(non-pad).  Round 1 routed it to
+    the BERT embeddings (arange positions): an XLM-R checkpoint loaded without error and gave wrong embeddings.  Oracle and
+    product against the installed transformers' XLMRobertaModel, incl. the HF-layout checkpoint round trip."""
+    import tempfile
+    from transformers import XLMRobertaConfig, XLMRobertaModel
+    torch.manual_seed(0)
+    kw = dict(vocab_size=120, hidden_size=48, intermediate_size=96, num_hidden_layers=2, num_attention_heads=4,
+              max_position_embeddings=66, layer_norm_eps=1e-5, type_vocab_size=1)
+    hf = XLMRobertaModel(XLMRobertaConfig(pad_token_id=1, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+                                          attn_implementation="eager", **kw), add_pooling_layer=False).eval()
+    rs = np.random.RandomState(3)
+    ids, m = _batch(rs, 5, 24, 118)
+    ids = (ids + 2) * m + 1 * (1 - m)                      # real tokens in [2, 120), pad id 1
+    with torch.no_grad():
+        ref = hf(input_ids=ids, attention_mask=m).last_hidden_state
+        cfgd = dict(kw, architectures=["XLMRobertaModel"], pad_token_id=1)
+        got = E.bert_forward(E.state_dict_to_f32(hf), cfgd, ids, m)
+        assert (got - ref)[m.bool()].abs().max() < 2e-5
+        with tempfile.TemporaryDirectory() as d:
+            hf.save_pretrained(d, safe_serialization=True)
+            enc = PE.load_encoder(d).eval()
+        assert enc.embeddings.roberta_positions and enc.config.architectures[0].startswith("XLMRoberta")
+        prod = enc(input_ids=ids, attention_mask=m).last_hidden_state
+        assert (prod - ref)[m.bool()].abs().max() < 3e-5
+        # the BERT rule on the same weights is measurably different: the test would catch the old routing
+        enc.embeddings.roberta_positions = False
+        assert (enc(input_ids=ids, attention_mask=m).last_hidden_state - ref)[m.bool()].abs().max() > 1e-2
+
+
 @pytest.mark.parametrize("ci", [0, 1])
 @pytest.mark.parametrize("side", ["right", "left", "mixed"])
 def test_product_llama_vs_oracle(ci, side):

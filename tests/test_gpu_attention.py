@@ -175,3 +175,34 @@ def test_flash_attn_bwd_random_shapes_deterministic():
             assert torch.isfinite(x.float()).all(), (name, ci, lens)
             err = (x.float() - y.float()).abs().max().item() / max(1.0, y.float().abs().max().item())
             assert err < 0.02, (name, err, ci, nh, nkv, lens)
+
+
+def test_key_block_is_an_abi_argument():
+    """rpo_flash_attn_bwd's `key_block` says what the k_tiles entries mean (include/rankpo_hip.h): 256 -> one-wave-per-SIMD
+    dK/dV kernel, 64 -> the 8-wave kernel; both agree with each other to bf16 round-off, and any other value is refused
+    instead of consuming a table with the wrong block size (round 1 read this from an environment variable in two places)."""
+    from rankpo_amd import ops
+    from rankpo_amd._lib import RankPOHipError
+    torch.manual_seed(11)
+    nh, nkv = 8, 2
+    lens = [700, 5, 256, 257, 1100]
+    T = sum(lens)
+    q = torch.randn(T, nh, 64, device=DEV).to(torch.bfloat16)
+    k = torch.randn(T, nkv, 64, device=DEV).to(torch.bfloat16)
+    v = torch.randn(T, nkv, 64, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    tiles = ops.attn_tile_table(lens, DEV)
+    out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, 0.125)
+    go = torch.randn_like(out)
+    res = {}
+    for kb in (256, 64):
+        kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=kb)
+        res[kb] = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, 0.125, key_block=kb)
+    assert torch.equal(res[256][0], res[64][0])                       # dQ: same kernel either way
+    for x, y in zip(res[256][1:], res[64][1:]):
+        assert (x.float() - y.float()).abs().max() <= 2.0 ** -6 * max(1.0, y.float().abs().max().item())
+    with pytest.raises(RankPOHipError, match="status -2"):
+        ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, ops.attn_key_tile_table(lens, DEV, nkv), 0.125,
+                                  key_block=128)
+    with pytest.raises(ValueError):
+        ops.attn_key_tile_table(lens, DEV, nkv, block_n=128)

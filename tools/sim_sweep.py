@@ -10,14 +10,10 @@ shapes = [(int(a), int(b), int(c)) for a, b, c in (s.split("x") for s in os.envi
 for Q, P, d in shapes:
     q = torch.nn.functional.normalize(torch.randn(Q, d, device=dev), dim=-1).to(torch.bfloat16)
     p = torch.nn.functional.normalize(torch.randn(P, d, device=dev), dim=-1).to(torch.bfloat16)
-    variants = [v for v in os.environ.get("VARIANTS", "").split(";") if v] or [""]
+    variants = [""]                # the library reads no environment switches any more: one variant, the shipped one
     n = int(os.environ.get("REPS", "5"))
     for rnd in range(int(os.environ.get("ROUNDS", "1"))):
-        for var in variants:       # interleaved A/B in ONE process: "RPO_SIM_STAGGER=0;RPO_SIM_STAGGER=1"
-            for kv in var.split(","):
-                if kv:
-                    k, v = kv.split("=")
-                    os.environ[k] = v
+        for var in variants:
             for _ in range(2):
                 ops.infonce_loss(q, p, 0.02)
             torch.cuda.synchronize()
