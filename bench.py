@@ -125,7 +125,7 @@ def _algo(name, a):
         pairs = _attn_pairs(T)                            # causal (query, key) pairs of this packed batch
         return 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh, 4 * hd * pairs * nh
     if name == "rpo_flash_attn_bwd":
-        T, nh, nkv, hd = a[15], a[16], a[17], a[18]
+        T, nh, nkv, hd = a[16], a[17], a[18], a[19]        # a[15] = key_block
         pairs = _attn_pairs(T)
         return 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, 10 * hd * pairs * nh
     if name == "rpo_topk_merge":

@@ -118,6 +118,7 @@ def test_filler_sequence_changes_nothing():
     exact_rows = torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     exact_grads = all(torch.equal(res[True][3][n], res[False][3][n]) for n in res[True][3])
     print(f"\nfiller on/off: pooled rows bit-identical={exact_rows}, weight gradients bit-identical={exact_grads}")
+    assert exact_rows and exact_grads       # measured: bit-identical on MI355X (round 2); the bounds below say what a miss means
     for a, b in zip(res[True][:2], res[False][:2]):
         assert (a.float() - b.float()).abs().max() <= 2.0 ** -7          # unit-norm rows: one bf16 ulp at 1.0
     assert abs(res[True][2] - res[False][2]) <= 2e-2 * max(1.0, abs(res[False][2]))

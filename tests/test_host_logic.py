@@ -309,11 +309,11 @@ def test_bench_attention_flops_follow_the_kernel_arguments():
         ops.attn_tile_table(lens, "cpu")
         T = sum(lens)
         assert T % 256 == 0
-        a = [None] * 19
-        a[15:19] = T, 32, 8, 64
+        a = [None] * 20
+        a[15:20] = 256, T, 32, 8, 64
         nbytes, flops = bench._algo("rpo_flash_attn_bwd", a)
         assert flops == 10 * 64 * 32 * sum(n * (n + 1) // 2 for n in lens) > 0
-        a[15] = T - 1
+        a[16] = T - 1
         with pytest.raises(KeyError, match="no sequence lengths registered"):
             bench._algo("rpo_flash_attn_bwd", a)
     finally:
