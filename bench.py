@@ -272,7 +272,35 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(model, cfg, temperature, sample=(40, 85, 4, 3), repeats=3):
+def usable_cores():
+    """(threads to use, how that was decided): the affinity mask, cut down to the cgroup CPU quota when there is one -- a GPU
+    box hands one GPU's job a share of a many-core host, its affinity mask still lists every core, and running one thread
+    per listed core under a 16-core quota only thrashes (a first version of this leg then ran for more than 7 minutes)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    how = f"affinity mask {n}"
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]                  # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())           # cgroup v1
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n = max(1, int(quota + 0.5))
+        how += f", cgroup cpu quota {quota:.1f} -> {n} threads"
+    return n, how
+
+
+def cpu_baseline(model, cfg, temperature, sample=(40, 85, 4, 3), repeats=3, note=lambda m: None, budget_s=150.0):
     """The oracle's training micro-step (encoder fwd+bwd + scoring, float32, eager) on the host cores, on a bounded
     sample of the workload: Q_s queries padded to Lq_s tokens + Q_s * G_s passages padded to Lp_s tokens (right-padded rows
     of random length, first row full: the reference's padded batches) through the SAME architecture and weights; median of
@@ -281,11 +309,9 @@ def cpu_baseline(model, cfg, temperature, sample=(40, 85, 4, 3), repeats=3):
     is ignored)."""
     from oracle import encoder_ref as E
     Lq_s, Lp_s, Q_s, G_s = sample
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
+    cores, how = usable_cores()
     torch.set_num_threads(cores)
+    note(f"cpu baseline: {cores} threads ({how}), {_cpu_model()}")
     w = {k: v.detach().to("cpu", torch.float32).requires_grad_(True) for k, v in model.model.state_dict().items()}
     cd = cfg.to_dict()
     g = torch.Generator().manual_seed(7)
@@ -299,13 +325,20 @@ def cpu_baseline(model, cfg, temperature, sample=(40, 85, 4, 3), repeats=3):
         ids = torch.randint(lo, hi, (N, L), generator=g)
         return {"input_ids": ids * m + pad * (1 - m), "attention_mask": m}
     batch = {"query": mk(Q_s, Lq_s), "passage": mk(Q_s * G_s, Lp_s)}
-    times = []
+    times, t_start = [], time.perf_counter()
     for i in range(repeats + 1):
         t0 = time.perf_counter()
         ref = oracle_step(w, cd, batch, temperature)
+        dt = time.perf_counter() - t0
+        note(f"cpu baseline: oracle step {i}{' (untimed warm-up)' if i == 0 else ''} {dt:.2f} s")
         if i:                                   # step 0 warms the allocator and the thread pool
-            times.append(time.perf_counter() - t0)
-    return sorted(times)[len(times) // 2], times, Q_s * (Lq_s + G_s * Lp_s), cores, batch, ref
+            times.append(dt)
+        elif dt > budget_s / 2:                 # a host this slow gets ONE measured step: the warm-up itself
+            times.append(dt)
+            break
+        if time.perf_counter() - t_start > budget_s and times:
+            break
+    return sorted(times)[len(times) // 2], times, Q_s * (Lq_s + G_s * Lp_s), (cores, how), batch, ref
 
 
 PARITY_GRADS = ("embed_tokens.weight", "layers.0.self_attn.q_proj.weight")
@@ -626,13 +659,13 @@ def main():
             note("sweep done")
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")
-            dt, times, toks, cores, sample_batch, ref = cpu_baseline(model, cfg, temperature)
+            dt, times, toks, (cores, cores_how), sample_batch, ref = cpu_baseline(model, cfg, temperature, note=note)
             note("step parity: fast path and stock-eager control vs the float32 oracle ...")
             out["step_loss_parity"] = step_parity(model, cfg, temperature, sample_batch, ref, device, dtype)
             toks_per_pair = Lp + Lq / (1 + K)
             nq_s, np_s = sample_batch["query"]["input_ids"].shape, sample_batch["passage"]["input_ids"].shape
             out["cpu_baseline"] = {"value": round(toks / dt / toks_per_pair, 5), "unit": "pairs/s", "cores": cores,
-                                   "kind": "port", "cpu_model": _cpu_model(),
+                                   "kind": "port", "cpu_model": _cpu_model(), "cores_from": cores_how,
                                    "step_seconds": [round(t, 3) for t in times], "median_seconds": round(dt, 3),
                                    "sample": f"oracle (eager torch f32, {cores} threads) fwd+bwd of {nq_s[0]} queries x {nq_s[1]} "
                                              f"tok + {np_s[0]} passages x {np_s[1]} tok (padded, as the reference runs them) "
