@@ -5,9 +5,9 @@ import csv
 import re
 import sys
 
-OURS = ("pool_normalize", "sim_tile", "sim_skinny", "sim_rowwise", "ce_finalize", "first_finalize", "infonce_bwd",
-        "infonce_first_bwd", "grouped_dots", "rankpo_", "adamw_kernel", "sumsq_kernel", "zero_fill", "rms_", "swiglu",
-        "rope_")
+OURS = ("pool_normalize", "sim_tile", "sim_skinny", "sim_rowwise", "ce_finalize", "first_finalize", "infonce_",
+        "grouped_dots", "rankpo_", "adamw_kernel", "sumsq_kernel", "zero_fill", "rmsnorm", "swiglu", "rope_", "fa_",
+        "topk_", "wgrad_")
 
 
 def short(name):
@@ -17,11 +17,27 @@ def short(name):
         m = re.search(r"MT\d+x\d+x\d+", name)
         return ("hipBLASLt " + name.split("_BBS")[0] + " " + (m.group(0) if m else ""))[:70]
     name = re.sub(r"at::native::", "", name)
+    if any(k in name for k in OURS):
+        name = name.split("(")[0]                     # our kernels: the name (+ template arguments) says it all
     return name[:110]
 
 
+def rows_from_db(path):
+    """rocprofv3's default output is a rocpd SQLite file: the same per-kernel statistics, from its `kernels` view."""
+    import sqlite3
+    con = sqlite3.connect(path)
+    cur = con.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                      "group by name order by sum(duration) desc")
+    rows = [dict(Name=n, Calls=str(c), TotalDurationNs=str(int(t)), AverageNs=str(a), MinNs=str(int(lo)), MaxNs=str(int(hi)))
+            for n, c, t, a, lo, hi in cur]
+    tot = sum(int(r["TotalDurationNs"]) for r in rows) or 1
+    for r in rows:
+        r["Percentage"] = str(100.0 * int(r["TotalDurationNs"]) / tot)
+    return rows
+
+
 def main(path, title):
-    rows = list(csv.DictReader(open(path)))
+    rows = rows_from_db(path) if path.endswith(".db") else list(csv.DictReader(open(path)))
     tot = sum(int(r["TotalDurationNs"]) for r in rows)
     print(f"# {title}\n")
     print(f"source: `{path.split('gpurun_out/')[-1]}` (rocprofv3 --kernel-trace --stats), total GPU kernel time "
