@@ -5,8 +5,9 @@
 //   sim_tile_kernel    Q > 64: 128(p) x 128(q) x 128-byte MFMA tile, LDS double-buffered, filled by
 //                      16-byte global_load_lds with an XOR-swizzled source (conflict-free ds_read_b128),
 //                      XCD-aware block order.  bf16: v_mfma_f32_16x16x32_bf16; f32: v_mfma_f32_16x16x4_f32.
-//   sim_skinny_kernel  Q <= 64 (every shape the reference scripts produce: 8x48 ... 64x384): 16 passage
-//                      rows per block, fragments loaded straight into registers, K split over the 4 waves.
+//   sim_skinny_kernel  Q <= 64 (every shape the reference scripts produce: 8x48 ... 64x384): 16 queries x 16..64 passage
+//                      rows per pass, fragments loaded straight into registers, K split over the 8 waves; small problems
+//                      run as ONE block that also finishes lse and the loss (one launch).
 //   sim_rowwise_kernel any d / alignment (scalar loads), one block per score row.
 //   ce_finalize_kernel combines the partials -> lse[Q], loss (fixed summation order; a ticket counter with
 //                      agent-scope release/acquire picks the block that adds up the per-block sums).
@@ -534,87 +535,139 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
-// Skinny kernel: Q <= 16 * NQ <= 64.  grid = ceil(P / 16).  Wave w accumulates K segments w, w+4, ...
+// Skinny kernel: Q <= 64 (every shape the reference scripts produce: 8 x 48 ... 64 x 384).
+//   A pass = one group of 16 queries x NG groups of 16 passage rows (NG = 4 for Q <= 16, where q is small and is
+//   amortised over four passage groups; NG = 1 above: a block that re-reads 64 queries per 16 passages spends 4/5 of its
+//   bytes on q).  Block = 8 waves; block b takes passes b, b + gridDim.x, ...
+//   Fragments go straight from global memory into registers (every byte is used once per pass).  K is split over the
+//   8 waves, wave w taking the 64-byte segments w, w + 8, ...; a wave issues the loads of EIGHT of its segments
+//   (8 (NG + 1) 16-byte loads per lane, up to ~200 VGPRs: 8 waves per block leave them the whole register file; a 16-wave
+//   version spilled) before the first MFMA, so a cfg-2 block (8 x 48 x 2048: 224 KB) has its whole operand set in flight
+//   at once and pays ONE memory round trip (the round-1 kernel walked 16 dependent load -> MFMA steps per wave).  The 8
+//   partial tiles are summed through LDS in wave order (deterministic), one wave per tile, which then rounds / scales /
+//   stores its 16 x 16 scores and reduces its rows.
+//   gridDim.x == 1 (small problems, <= 384 KB: every single-GPU shape of the reference): the block walks all passes, then
+//   merges the per-group softmax partials, writes lse and the mean loss itself -- ONE launch, no workspace traffic.
+//   Otherwise partial[group][row] goes to the workspace and ce_finalize_kernel follows.
+//   Measured anatomy of the one-block launch (rocprofv3, MI355X): 4.2 us for a near-empty problem (dispatch, kernel
+//   arguments, one memory round trip, LDS sum, two barriers, end-of-kernel write-back) + ~29 us per MB: fragment-shaped
+//   loads (16 rows x 64 B per wave instruction) bring one CU ~35 GB/s.
 // ------------------------------------------------------------------------------------------------
-constexpr int kSkinnyThreads = 256;
+constexpr int kSkinnyThreads = 512, kSkinnyWaves = 8, kSkinnyUnroll = 8, kSkinnyMaxFusedGroups = 16;
 
-template <typename T, int NQ>
+template <typename T, int NG>
 __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
     const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
-    int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial) {
+    int scale, int do_stats, int64_t group, T* __restrict__ scores, float2* __restrict__ partial,
+    float* __restrict__ lse_out, float* __restrict__ loss_out) {
     typedef typename Mma<T>::Frag Frag;
     constexpr int CE = 16 / (int)sizeof(T);   // elements per chunk
     constexpr int SE = 4 * CE;                // elements per 64-byte K segment
-    __shared__ float4_t s_acc[3][NQ][64];
+    constexpr int U = kSkinnyUnroll;
+    __shared__ float4_t s_acc[kSkinnyWaves][NG][64];
+    __shared__ float2 s_part[kSkinnyMaxFusedGroups][64];
+    __shared__ float s_tgt[64];
+    __shared__ float s_red[kSkinnyWaves];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, frow = lane & 15;
-    const int64_t p0 = (int64_t)blockIdx.x * 16;
-    const int64_t pr = p0 + frow;
-    const bool pv = pr < P;
-    const T* a_row = p + (pv ? pr : 0) * d + g * CE;
-    const T* b_row[NQ];
-    bool bv[NQ];
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) {
-        const int64_t qr = 16 * n + frow;
-        bv[n] = qr < Q;
-        b_row[n] = q + (bv[n] ? qr : 0) * d + g * CE;
-    }
-    float4_t acc[NQ];
-#pragma unroll
-    for (int n = 0; n < NQ; ++n) acc[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const int ngroups = (int)((P + 15) / 16);              // passage groups
+    const int npchunk = (ngroups + NG - 1) / NG;
+    const int npass = npchunk * (int)((Q + 15) / 16);
+    const bool fused = gridDim.x == 1 && do_stats;
     const int64_t nseg = (d + SE - 1) / SE;
-    for (int64_t s = wave; s < nseg; s += 4) {
-        const int64_t k = s * SE;
-        const bool kv = k + g * CE < d;       // d % CE == 0 is guaranteed by the host
-        Frag a = Mma<T>::zero();
-        if (pv && kv) a = *reinterpret_cast<const Frag*>(a_row + k);
+    for (int pass = (int)blockIdx.x; pass < npass; pass += (int)gridDim.x) {
+        const int qg = pass / npchunk, pg0 = (pass % npchunk) * NG;
+        const int64_t qr = 16 * qg + frow;
+        const bool bv = qr < Q;
+        const T* b_row = q + (bv ? qr : 0) * d + g * CE;
+        const T* a_row[NG];
+        bool av[NG];
 #pragma unroll
-        for (int n = 0; n < NQ; ++n) {
-            Frag b = Mma<T>::zero();
-            if (bv[n] && kv) b = *reinterpret_cast<const Frag*>(b_row[n] + k);
-            Mma<T>::mma(a, b, acc[n]);
+        for (int n = 0; n < NG; ++n) {
+            const int64_t pr = (int64_t)(pg0 + n) * 16 + frow;
+            av[n] = pr < P;
+            a_row[n] = p + (av[n] ? pr : 0) * d + g * CE;
         }
-    }
-    if (wave > 0) {
+        float4_t acc[NG];
 #pragma unroll
-        for (int n = 0; n < NQ; ++n) s_acc[wave - 1][n][lane] = acc[n];
-    }
-    __syncthreads();
-    if (wave != 0) return;
-    const int64_t pbase = p0 + g * 4;
-    const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
-    const float inv_t = 1.0f / temperature;
+        for (int n = 0; n < NG; ++n) acc[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int64_t s0 = wave; s0 < nseg; s0 += kSkinnyWaves * U) {
+            Frag a[U][NG], b[U];
 #pragma unroll
-    for (int n = 0; n < NQ; ++n) {
+            for (int u = 0; u < U; ++u) {          // all loads of the batch first: one memory round trip per batch
+                const int64_t k = (s0 + (int64_t)u * kSkinnyWaves) * SE;
+                const bool kv = k + g * CE < d;       // d % CE == 0 is guaranteed by the host
 #pragma unroll
-        for (int w = 0; w < 3; ++w) {   // fixed order: wave 0 + 1 + 2 + 3
-            const float4_t o = s_acc[w][n][lane];
-            acc[n] += o;
-        }
-        const int64_t qi = 16 * n + frow;
-        float v[4];
-        float mx = RPO_NEG_INF;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = finish_score<T>(acc[n][j], temperature, inv_t, scale);
-            if (pbase + j < P) mx = fmaxf(mx, v[j]);
-        }
-        if (qi < Q) store_scores4<T>(scores + qi * P, pbase, P, v, vec_ok);
-        if (do_stats) {
-            float sum = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (pbase + j < P) sum += exp_sub(v[j], mx * RPO_LOG2E);
-#pragma unroll
-            for (int o = 16; o <= 32; o <<= 1) {
-                const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
-                softmax_merge(mx, sum, om, ol);
+                for (int n = 0; n < NG; ++n) {
+                    a[u][n] = Mma<T>::zero();
+                    if (av[n] && kv) a[u][n] = *reinterpret_cast<const Frag*>(a_row[n] + k);
+                }
+                b[u] = Mma<T>::zero();
+                if (bv && kv) b[u] = *reinterpret_cast<const Frag*>(b_row + k);
             }
-            if (g == 0 && qi < Q) partial[(int64_t)blockIdx.x * Q + qi] = make_float2(mx, sum);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int n = 0; n < NG; ++n) Mma<T>::mma(a[u][n], b[u], acc[n]);
         }
+#pragma unroll
+        for (int n = 0; n < NG; ++n) s_acc[wave][n][lane] = acc[n];
+        __syncthreads();
+        if (wave < NG) {                              // wave t finishes the tile of passage group pg0 + t
+            float4_t t = s_acc[0][wave][lane];
+#pragma unroll
+            for (int w = 1; w < kSkinnyWaves; ++w) t += s_acc[w][wave][lane];      // fixed order: wave 0 + 1 + ... + 7
+            const int pg = pg0 + wave;
+            if (pg < ngroups) {
+                const int64_t pbase = (int64_t)pg * 16 + g * 4;
+                const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
+                const float inv_t = 1.0f / temperature;
+                float v[4];
+                float mx = RPO_NEG_INF;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = finish_score<T>(t[j], temperature, inv_t, scale);
+                    if (pbase + j < P) mx = fmaxf(mx, v[j]);
+                }
+                if (bv) store_scores4<T>(scores + qr * P, pbase, P, v, vec_ok);
+                if (do_stats) {
+                    float sum = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (pbase + j < P) sum += exp_sub(v[j], mx * RPO_LOG2E);
+#pragma unroll
+                    for (int o = 16; o <= 32; o <<= 1) {
+                        const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
+                        softmax_merge(mx, sum, om, ol);
+                    }
+                    if (bv) {
+                        if (fused) {
+                            if (g == 0) s_part[pg][qr] = make_float2(mx, sum);
+                            const int64_t tgt = qr * group;                  // the positive's column (modeling.py:301-302)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (pbase + j == tgt) s_tgt[qr] = v[j];
+                        } else if (g == 0) {
+                            partial[(int64_t)pg * Q + qr] = make_float2(mx, sum);
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                              // s_acc is rewritten by the next pass
     }
+    if (!fused) return;
+    float rowloss = 0.f;
+    if (tid < Q) {
+        float m = RPO_NEG_INF, l = 0.f;
+        for (int b2 = 0; b2 < ngroups; ++b2) softmax_merge(m, l, s_part[b2][tid].x, s_part[b2][tid].y);
+        const float lse = m + logf(l);
+        lse_out[tid] = lse;
+        rowloss = lse - s_tgt[tid];
+    }
+    const float tot = block_sum<kSkinnyWaves>(rowloss, s_red);
+    if (tid == 0) loss_out[0] = tot / (float)Q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -734,13 +787,20 @@ __global__ __launch_bounds__(kFinThreads) void first_finalize_kernel(const float
 //   blocks [0, q_rows*nchunk): dq row;  blocks [q_rows*nchunk, +p_rows*nchunk): dp row.
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ __launch_bounds__(64) void infonce_bwd_valu_kernel(
+__global__ __launch_bounds__(256) void infonce_bwd_valu_kernel(
     const T* __restrict__ q, const T* __restrict__ p, const T* __restrict__ scores, const float* __restrict__ lse,
     const float* __restrict__ grad_loss, int64_t Q, int64_t P, int64_t d, float temperature, int64_t group,
     int64_t q_row0, int64_t q_rows, int64_t p_row0, int64_t p_rows, T* __restrict__ dq, T* __restrict__ dp,
     int nchunk) {
+    // block = one output row x one chunk of 64 x V columns; its 4 waves split the reduction range (the P passages of a dq
+    // row, the Q queries of a dp row) into contiguous quarters and each wave issues the row loads of 8 terms before their
+    // FMAs, so a row costs a few memory round trips instead of one per term (round 1: one wave per row walking 48
+    // dependent load -> FMA steps, 19 us at 8 x 48 x 2048).  The four partial sums are added in wave order through LDS.
     constexpr int V = Elem<T>::kVec;
-    const int lane = threadIdx.x;
+    constexpr int U = 8;
+    __shared__ float s_sum[3][64][V];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const float coef = grad_loss[0] / ((float)Q * temperature);
     int64_t b = blockIdx.x;
     const int64_t ndq = dq ? q_rows * nchunk : 0;
@@ -752,55 +812,48 @@ __global__ __launch_bounds__(64) void infonce_bwd_valu_kernel(
 #pragma unroll
     for (int k = 0; k < V; ++k) accv[k] = 0.f;
     const int64_t c0 = ((int64_t)chunk * 64 + lane) * V;
-    if (is_dq) {
-        const int64_t gi = q_row0 + row;
-        const float lse_i = lse[gi];
-        const int64_t tgt = gi * group;
-        for (int64_t j0 = 0; j0 < P; j0 += 64) {
-            const int64_t j = j0 + lane;
-            float w = 0.f;
-            if (j < P) w = coef * (__expf(Elem<T>::ld(scores + gi * P + j) - lse_i) - (j == tgt ? 1.f : 0.f));
-            const int jn = (int)min((int64_t)64, P - j0);
-            for (int jj = 0; jj < jn; ++jj) {
-                const float wj = __shfl(w, jj, 64);     // uniform trip count: every lane takes part
-                if (c0 < d) {
-                    Vec16<T> x;
-                    x.load(p + (j0 + jj) * d + c0);
+    const bool cv = c0 < d;
+    // dq row gi:  sum_j w[gi, j] p_j   ;   dp row gj:  sum_i w[i, gj] q_i     (w = coef (softmax(S) - onehot))
+    const int64_t R = is_dq ? P : Q;                       // reduction length
+    const int64_t per = (R + 3) / 4;
+    const int64_t r_begin = wave * per, r_end = min(R, r_begin + per);
+    const int64_t gi = q_row0 + row, gj = p_row0 + row;
+    const T* src = is_dq ? p : q;
+    for (int64_t r0 = r_begin; r0 < r_end; r0 += 64) {
+        const int64_t r = r0 + lane;
+        float w = 0.f;
+        if (r < r_end) {
+            if (is_dq) w = coef * (__expf(Elem<T>::ld(scores + gi * P + r) - lse[gi]) - (r == gi * group ? 1.f : 0.f));
+            else       w = coef * (__expf(Elem<T>::ld(scores + r * P + gj) - lse[r]) - (gj == r * group ? 1.f : 0.f));
+        }
+        const int rn = (int)min((int64_t)64, r_end - r0);  // wave-uniform
+        for (int t0 = 0; t0 < rn; t0 += U) {
+            Vec16<T> x[U];
+            float wt[U];
 #pragma unroll
-                    for (int k = 0; k < V; ++k) accv[k] = fmaf(wj, x.v[k], accv[k]);
-                }
+            for (int u = 0; u < U; ++u) {                  // loads of the batch first
+                const int t = min(t0 + u, rn - 1);         // clamped: a repeated row gets weight 0 below
+                wt[u] = (t0 + u < rn) ? __shfl(w, t, 64) : 0.f;
+                if (cv) x[u].load(src + (r0 + t) * d + c0);
             }
-        }
-        if (c0 < d) {
-            Vec16<T> o;
+            if (cv) {
 #pragma unroll
-            for (int k = 0; k < V; ++k) o.v[k] = accv[k];
-            o.store(dq + row * d + c0);
-        }
-    } else {
-        const int64_t gj = p_row0 + row;
-        for (int64_t i0 = 0; i0 < Q; i0 += 64) {
-            const int64_t i = i0 + lane;
-            float w = 0.f;
-            if (i < Q) w = coef * (__expf(Elem<T>::ld(scores + i * P + gj) - lse[i]) - (gj == i * group ? 1.f : 0.f));
-            const int in = (int)min((int64_t)64, Q - i0);
-            for (int ii = 0; ii < in; ++ii) {
-                const float wi = __shfl(w, ii, 64);
-                if (c0 < d) {
-                    Vec16<T> x;
-                    x.load(q + (i0 + ii) * d + c0);
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-                    for (int k = 0; k < V; ++k) accv[k] = fmaf(wi, x.v[k], accv[k]);
-                }
+                    for (int k = 0; k < V; ++k) accv[k] = fmaf(wt[u], x[u].v[k], accv[k]);
             }
-        }
-        if (c0 < d) {
-            Vec16<T> o;
-#pragma unroll
-            for (int k = 0; k < V; ++k) o.v[k] = accv[k];
-            o.store(dp + row * d + c0);
         }
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) s_sum[wave - 1][lane][k] = accv[k];
+    }
+    __syncthreads();
+    if (wave != 0 || !cv) return;
+    Vec16<T> o;
+#pragma unroll
+    for (int k = 0; k < V; ++k) o.v[k] = ((accv[k] + s_sum[0][lane][k]) + s_sum[1][lane][k]) + s_sum[2][lane][k];
+    o.store((is_dq ? dq : dp) + row * d + c0);
 }
 
 // Scalar backward for shapes the vector form cannot take (d % V != 0 or unaligned): thread per column.
@@ -971,6 +1024,7 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         return rpo_launch_status();
     }
     float2* partial = do_stats ? (float2*)(wsb + pl.off_partial) : nullptr;
+    bool fused_finalize = false;      // the forward kernel wrote lse and loss itself (single-block skinny launch)
     if (pl.path == PATH_TILE) {
         static bool attr_set = false;   // idempotent; a race only repeats the same call
         if (!attr_set) {
@@ -994,24 +1048,27 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
                        (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0);
         }
     } else if (pl.path == PATH_SKINNY) {
-        const dim3 grid((unsigned)pl.nPb), block(kSkinnyThreads);
-        const int nq = (int)rpo_cdiv(Q, 16);
-#define RPO_SKINNY(NQ)                                                                                       \
-    RPO_LAUNCH((sim_skinny_kernel<T, NQ>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d,     \
-                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial)
-        switch (nq) {
-            case 1: RPO_SKINNY(1); break;
-            case 2: RPO_SKINNY(2); break;
-            case 3: RPO_SKINNY(3); break;
-            default: RPO_SKINNY(4); break;
-        }
-#undef RPO_SKINNY
+        const int ng = Q <= 16 ? 4 : 1;
+        const int64_t npass = rpo_cdiv(pl.nPb, ng) * rpo_cdiv(Q, 16);
+        // small problems (every single-GPU shape of the reference: 8 x 48 x 2048 bf16 is 224 KB) run as ONE block that
+        // walks all passes and finishes lse / loss itself: a second launch costs more than the one CU loses in bandwidth
+        const int64_t bytes = (Q + P) * d * (int64_t)sizeof(T);
+        const bool one_block = pl.nPb <= kSkinnyMaxFusedGroups && bytes <= 384 * 1024;
+        const unsigned nblk = one_block ? 1u : (unsigned)npass;
+        fused_finalize = do_stats && nblk == 1;
+        const dim3 grid(nblk), block(kSkinnyThreads);
+        if (ng == 4)
+            RPO_LAUNCH((sim_skinny_kernel<T, 4>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d, temperature, scale,
+                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out);
+        else
+            RPO_LAUNCH((sim_skinny_kernel<T, 1>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d, temperature, scale,
+                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out);
     } else {
         RPO_LAUNCH(sim_rowwise_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q, (const T*)p, Q,
                            P, d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial);
     }
     int rc = rpo_launch_status();
-    if (rc != RPO_OK || !do_stats) return rc;
+    if (rc != RPO_OK || !do_stats || fused_finalize) return rc;
     unsigned* ticket = (unsigned*)wsb;
     if (pl.nFin > 1) (void)hipMemsetAsync(ticket, 0, 16, st);
     RPO_LAUNCH(ce_finalize_kernel<T>, dim3((unsigned)pl.nFin), dim3(kFinThreads), 0, st, partial,
@@ -1038,7 +1095,7 @@ int bwd_impl(const void* q, const void* p, const void* scores, const float* lse,
         const int nchunk = (int)rpo_cdiv(d, 64 * V);
         const int64_t blocks = ((dq ? q_rows : 0) + (dp ? p_rows : 0)) * nchunk;
         if (blocks <= 0) return RPO_OK;
-        RPO_LAUNCH(infonce_bwd_valu_kernel<T>, dim3((unsigned)blocks), dim3(64), 0, st, (const T*)q,
+        RPO_LAUNCH(infonce_bwd_valu_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, (const T*)q,
                            (const T*)p, (const T*)scores, lse, grad_loss, Q, P, d, temperature, group, q_row0,
                            q_rows, p_row0, p_rows, (T*)dq, (T*)dp, nchunk);
     } else {
