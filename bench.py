@@ -121,13 +121,16 @@ def _algo(name, a):
         rows, d, dt = a[7], a[8], a[9]
         return rows * d * _es(dt) * (4 if a[4] is not None else 3) + rows * 4, 8 * rows * d
     if name == "rpo_flash_attn_fwd":
-        T, nh, nkv, hd = a[9], a[10], a[11], a[12]
+        T, nh, nkv, hd = a[10], a[11], a[12], a[13]          # a[9] = tile_cols
         pairs = _attn_pairs(T)                            # causal (query, key) pairs of this packed batch
         return 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh, 4 * hd * pairs * nh
     if name == "rpo_flash_attn_bwd":
-        T, nh, nkv, hd = a[16], a[17], a[18], a[19]        # a[15] = key_block
+        T, nh, nkv, hd = a[17], a[18], a[19], a[20]        # a[13] = q_tile_cols, a[16] = key_block
         pairs = _attn_pairs(T)
         return 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, 10 * hd * pairs * nh
+    if name == "rpo_transpose":
+        rows, cols, dt = a[2], a[3], a[6]
+        return 2 * rows * cols * _es(dt), 0
     if name == "rpo_topk_merge":
         rows, cols, k, dt = a[2], a[3], a[5], a[6]
         return rows * cols * _es(dt) + 2 * rows * k * 12, rows * cols
@@ -455,6 +458,7 @@ def main():
     ap.add_argument("--padded", action="store_true", help="run the encoder on padded batches (reference behaviour)")
     ap.add_argument("--no-fill", action="store_true", help="A/B: no filler sequence rounding the packed token count to 256")
     ap.add_argument("--no-linear-tn", action="store_true", help="A/B: torch's own operand layout for the input-gradient GEMMs")
+    ap.add_argument("--no-wgrad-mixed", action="store_true", help="A/B: weight-gradient GEMMs as autograd issues them")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -508,6 +512,8 @@ def main():
         enc.pack_fill = False
     if args.no_linear_tn:
         rankpo_amd.ops.LINEAR_TN = False
+    if args.no_wgrad_mixed:
+        rankpo_amd.ops.WGRAD_MIXED = False
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
                                         negatives_cross_device=multi, unpad=not args.padded).train()
     hook_attn_tables()

@@ -194,6 +194,13 @@ int rpo_rope(const void* x_in, void* x_out, int64_t row_stride, const float* cos
              int64_t rows, int64_t heads, int64_t head_dim, int64_t period, int dtype, int backward,
              rpo_stream_t stream);
 
+/* 2-D transpose out[cols, rows] = in[rows, cols]^T, row-major with row strides ld_in / ld_out (elements); HBM-bound.  Used
+ * by the encoder's backward to hand hipBLASLt ONE operand of the weight-gradient GEMM dW = dY^T X (reduction over the
+ * tokens) contiguous along the reduction, and W^T to the input-gradient GEMM (stands where PyTorch's autograd of
+ * nn.Linear issues `grad_output.t() @ input` / `grad_output @ weight`). */
+int rpo_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int dtype,
+                  rpo_stream_t stream);
+
 /* Residual add + RMSNorm, fused (HF LlamaDecoderLayer: `h = residual + delta; y = rmsnorm(h) * w`).
  *   fwd: x_new = x + delta (delta NULL: x_new = x, x_out unused); rstd_r = rsqrt(mean(x_new_r^2) + eps);
  *        y = x_new * rstd * w.  x, delta, x_out, y: [rows, d]; rstd_out: f32 [rows].
@@ -210,25 +217,32 @@ int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, c
 /* Causal variable-length flash attention, forward, head_dim 64, bf16, grouped-query heads (encoder side; the packed
  * encoder path of rankpo_amd/encoder.py).  q: [T, num_heads, 64] with token stride q_stride elements (heads contiguous),
  * k / v: [T, num_kv_heads, 64] likewise (all three may be views of one fused projection output).  cu_seqlens: int32
- * [N + 1].  tiles: int32 [ntiles][2] = (sequence id, first query row inside the sequence), one entry per block of 128
- * queries, heaviest first.  out: [T, num_heads * 64] (token stride out_stride), lse = log sum_j exp(scale * <q_i, k_j>)
+ * [N + 1].  tiles = the query-tile work list, one entry per block of 128 queries, in the format tile_cols names:
+ *   2: int32 [ntiles][2] = (sequence id, first query row inside the sequence), heaviest first; one launch block per
+ *      (entry, head);
+ *   3: int32 [ntiles][3] = (sequence id, first query row, head), ntiles % 8 == 0: launch block b takes entry
+ *      (b % 8) * ntiles / 8 + b / 8, so the blocks that share an XCD walk one eighth of the list in order; the caller puts
+ *      all entries of one (sequence, kv head) next to each other in one eighth (their K / V then stay in that XCD's L2);
+ *      entries whose first query row is >= 2^30 are padding.
+ * out: [T, num_heads * 64] (token stride out_stride), lse = log sum_j exp(scale * <q_i, k_j>)
  * over the keys j <= i of the same sequence, f32, laid out [num_heads][T] when lse_max_len == 0 or padded
  * [N][num_heads][lse_max_len] (the layout PyTorch's flash-attention backward reads) when lse_max_len > 0. */
 int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
-                       int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles, int64_t total_tokens,
+                       int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles, int64_t tile_cols,
+                       int64_t total_tokens,
                        int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
                        int64_t out_stride, float* lse, int64_t lse_max_len, rpo_stream_t stream);
 
 /* Backward of rpo_flash_attn_fwd (three launches, no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
  * forward with lse_max_len == 0; delta: f32 [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale, the initial accumulators of the dP and S chains).  q_tiles as in the
- * forward; k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a key block); key_block = the number of
+ * forward (q_tile_cols = its format); k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a key block); key_block = the number of
  * keys one entry stands for and thereby the dK/dV kernel that consumes the table: 256 (one wave per SIMD, entries dealt to
  * the 8 XCDs in equal eighths, padded with first key >= 2^30) or 64 (the 8-wave kernel; entries sorted by (sequence, head,
  * key)).  Any other value is RPO_ERR_UNSUPPORTED: the meaning of the table is an argument, never process-global state.
  * dq: [T, num_heads, 64], dk / dv: [T, num_kv_heads, 64] (token strides given), every valid row is written. */
 int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, int64_t q_stride,
                        int64_t k_stride, int64_t v_stride, int64_t out_stride, int64_t dout_stride,
-                       const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles, const int* k_tiles,
+                       const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles, int64_t q_tile_cols, const int* k_tiles,
                        int64_t n_k_tiles, int64_t key_block, int64_t total_tokens, int64_t num_heads,
                        int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta, void* dq, void* dk, void* dv,
                        int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, rpo_stream_t stream);

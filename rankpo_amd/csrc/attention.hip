@@ -55,18 +55,37 @@ __device__ __forceinline__ short8_t join_tr(const u32x2& lo, const u32x2& hi) {
     return __builtin_bit_cast(short8_t, w);
 }
 
-// tiles: int32 [ntiles][2] = (sequence id, first query row inside the sequence), heaviest tiles first.
+// Query-tile work list, two formats (`tcols`, an argument of the C entry points):
+//   2: int32 [n][2] = (sequence id, first query row), heaviest tiles first; grid = (n, heads), the head is blockIdx.y.
+//   3: int32 [n][3] = (sequence id, first query row, head), n % 8 == 0, grid = (n): block b takes entry (b & 7) * n / 8 + (b >> 3),
+//      i.e. the blocks that share an XCD (round-robin dispatch: b and b + 8) walk ONE eighth of the list in order.  The host
+//      puts all query tiles x all q heads of one (sequence, kv head) into one eighth, next to each other: the ~100 blocks an
+//      XCD runs at a time then stream the SAME K / V rows (<= 1 MB) through its 4 MB L2, instead of the K / V of every
+//      sequence at once (format 2: FETCH traffic 6.3 x the algorithmic bytes, 50 % L2 hit rate, profiles/r01_fa_pmc.md).
+//      Padding entries have first query row >= 2^30.  Placement is a speed matter only.
+struct FaTile { int seq, q0, h; };
+__device__ __forceinline__ FaTile fa_tile(const int* __restrict__ tiles, int tcols) {
+    if (tcols == 3) {
+        const int per = (int)(gridDim.x >> 3);
+        const int e = 3 * ((int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3));
+        return FaTile{tiles[e], tiles[e + 1], tiles[e + 2]};
+    }
+    return FaTile{tiles[2 * blockIdx.x], tiles[2 * blockIdx.x + 1], (int)blockIdx.y};
+}
+
 __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
-    int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int nh, int nkv, float scale_log2e,
+    int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
     float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
     int64_t lse_head_stride, int lse_packed) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kKvTile];       // ring of (K tile | V tile), 128-byte rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, fr = lane & 15;
-    const int seq = tiles[2 * blockIdx.x], q0 = tiles[2 * blockIdx.x + 1];
-    const int h = blockIdx.y, hk = h / (nh / nkv);
+    const FaTile ft = fa_tile(tiles, tcols);
+    if (ft.q0 >= (1 << 30)) return;                      // padding entry of the XCD-dealt list
+    const int seq = ft.seq, q0 = ft.q0;
+    const int h = ft.h, hk = h / (nh / nkv);
     const int64_t t0 = cu[seq];
     const int len = cu[seq + 1] - (int)t0;
     const int qw = q0 + 32 * wave;                       // this wave's first query row (inside the sequence)
@@ -315,14 +334,16 @@ constexpr int kDqTile = kKvTile;
 __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
-    const int* __restrict__ tiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ lse,
-    const float* __restrict__ delta, int64_t T, bf16_t* __restrict__ dq, int64_t sdq) {
+    const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e, float scale,
+    const float* __restrict__ lse, const float* __restrict__ delta, int64_t T, bf16_t* __restrict__ dq, int64_t sdq) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kDqTile];      // ring of (K tile | V tile), chunk ^= row & 7
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, fr = lane & 15;
-    const int seq = tiles[2 * blockIdx.x], q0 = tiles[2 * blockIdx.x + 1];
-    const int h = blockIdx.y, hk = h / (nh / nkv);
+    const FaTile ft = fa_tile(tiles, tcols);
+    if (ft.q0 >= (1 << 30)) return;
+    const int seq = ft.seq, q0 = ft.q0;
+    const int h = ft.h, hk = h / (nh / nkv);
     const int64_t t0 = cu[seq];
     const int len = cu[seq + 1] - (int)t0;
     const int qw = q0 + 32 * wave;
@@ -2086,11 +2107,12 @@ extern "C" int rpo_debug_fa_stamps(unsigned long long* out64, int reset) {
 
 extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
                                   int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles,
-                                  int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim,
+                                  int64_t tile_cols, int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim,
                                   float scale, void* out, int64_t out_stride, float* lse, int64_t lse_max_len,
                                   rpo_stream_t stream) {
     if (!q || !k || !v || !cu_seqlens || !tiles || !out || !lse || ntiles <= 0 || total_tokens <= 0)
         return RPO_ERR_INVALID_ARG;
+    if (!(tile_cols == 2 || (tile_cols == 3 && ntiles % 8 == 0))) return RPO_ERR_UNSUPPORTED;
     if (head_dim != kFaHD || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 || num_heads > 65535)
         return RPO_ERR_UNSUPPORTED;
     if (q_stride % 8 || k_stride % 8 || v_stride % 8 || out_stride % 4 || !rpo_aligned16(q) || !rpo_aligned16(k) ||
@@ -2098,8 +2120,9 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
         return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const float log2e = 1.4426950408889634f;
-    RPO_LAUNCH(fa_fwd_kernel, dim3((unsigned)ntiles, (unsigned)num_heads), dim3(kFaThreads), 0, st, (const bf16_t*)q,
-               (const bf16_t*)k, (const bf16_t*)v, q_stride, k_stride, v_stride, cu_seqlens, tiles, (int)num_heads,
+    RPO_LAUNCH(fa_fwd_kernel, dim3((unsigned)ntiles, tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0, st,
+               (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride, k_stride, v_stride, cu_seqlens, tiles,
+               (int)tile_cols, (int)num_heads,
                (int)num_kv_heads, scale * log2e, scale, (bf16_t*)out, out_stride, lse,
                lse_max_len > 0 ? num_heads * lse_max_len : 0, lse_max_len > 0 ? lse_max_len : total_tokens,
                lse_max_len > 0 ? 0 : 1);
@@ -2109,7 +2132,7 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
 extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout,
                                   int64_t q_stride, int64_t k_stride, int64_t v_stride, int64_t out_stride,
                                   int64_t dout_stride, const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles,
-                                  const int* k_tiles, int64_t n_k_tiles, int64_t key_block, int64_t total_tokens,
+                                  int64_t q_tile_cols, const int* k_tiles, int64_t n_k_tiles, int64_t key_block, int64_t total_tokens,
                                   int64_t num_heads,
                                   int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta,
                                   void* dq, void* dk, void* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
@@ -2120,6 +2143,7 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     // `key_block` states what the entries of `k_tiles` mean: blocks of 256 keys (one-wave-per-SIMD dK/dV kernel) or of 64
     // keys (the 8-wave kernel).  The caller that built the table says so; nothing is read from the environment.
     if (key_block != 256 && key_block != 64) return RPO_ERR_UNSUPPORTED;
+    if (!(q_tile_cols == 2 || (q_tile_cols == 3 && n_q_tiles % 8 == 0))) return RPO_ERR_UNSUPPORTED;
     if (head_dim != kFaHD || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 || num_heads > 65535)
         return RPO_ERR_UNSUPPORTED;
     if (q_stride % 8 || k_stride % 8 || v_stride % 8 || out_stride % 8 || dout_stride % 8 || dq_stride % 4 ||
@@ -2134,9 +2158,9 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
                out_stride, dout_stride, (int)num_heads, total_tokens, lse, 1.0f / scale, nd, nl);
     int rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
-    RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, (unsigned)num_heads), dim3(kFaThreads), 0, st,
-               (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
-               dout_stride, cu_seqlens, q_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd,
+    RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0,
+               st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
+               dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd,
                total_tokens, (bf16_t*)dq, dq_stride);
     rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;

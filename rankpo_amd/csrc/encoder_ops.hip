@@ -100,6 +100,78 @@ inline unsigned ew_grid(int64_t nvec) { return (unsigned)rpo_cdiv(nvec, kEwThrea
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------------------------
+// 2-D transpose  out[C, R] = in[R, C]^T  (both row-major, row strides ld_in / ld_out elements).
+// Why it exists: hipBLASLt's weight-gradient GEMM dW = dY^T X with BOTH operands strided along the token reduction runs at
+// 0.9-1.2 PFLOP/s; with ONE operand contiguous along it, 1.36-1.39 (tools/probe_wgrad.py), and the input-gradient GEMM wants
+// W^T.  PyTorch's `.t().contiguous()` moves 0.35 TB/s on these shapes (3.4 ms for a [151552, 2048] bf16 operand); this kernel
+// is HBM-bound.  64 x 64 tile through LDS: 16-byte global loads along the input rows, 2-byte (bf16) / 4-byte (f32) LDS reads
+// down the tile columns, 16-byte global stores along the output rows: whole 128-byte lines on both sides.
+// ------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t R, int64_t C,
+                                                        int64_t ld_in, int64_t ld_out, int vec_in, int vec_out) {
+    constexpr int V = 16 / (int)sizeof(T);            // elements per 16-byte vector
+    constexpr int TS = 64;                            // tile side
+    constexpr int LDT = TS + 8 / (int)sizeof(T);      // 136-byte (bf16) / 264-byte (f32) LDS rows: 8-byte aligned, banks spread
+    constexpr int VPR = TS / V;                       // vectors per tile row
+    __shared__ __attribute__((aligned(16))) T tile[TS][LDT];
+    const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < TS * VPR / 256; ++i) {
+        const int idx = t + 256 * i;
+        const int row = idx / VPR, cv = (idx % VPR) * V;
+        const int64_t r = r0 + row, c = c0 + cv;
+        __attribute__((aligned(16))) T v[V];
+        if (r < R && vec_in && c + V <= C) {
+            *reinterpret_cast<uint4_t*>(v) = __builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(in + r * ld_in + c));
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = (r < R && c + e < C) ? in[r * ld_in + c + e] : T(0);
+        }
+#pragma unroll
+        for (int e = 0; e < V; ++e) tile[row][cv + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TS * VPR / 256; ++i) {
+        const int idx = t + 256 * i;
+        const int oc = idx / VPR, rv = (idx % VPR) * V;          // output row = input column c0 + oc; input rows r0 + rv ..
+        const int64_t c = c0 + oc, r = r0 + rv;
+        if (c >= C) continue;
+        __attribute__((aligned(16))) T v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = tile[rv + e][oc];
+        if (vec_out && r + V <= R) {
+            __builtin_nontemporal_store(*reinterpret_cast<const uint4_t*>(v), reinterpret_cast<uint4_t*>(out + c * ld_out + r));
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+                if (r + e < R) out[c * ld_out + r + e] = v[e];
+        }
+    }
+}
+
+extern "C" int rpo_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int dtype,
+                             rpo_stream_t stream) {
+    if (!in || !out || rows <= 0 || cols <= 0 || ld_in < cols || ld_out < rows) return RPO_ERR_INVALID_ARG;
+    if (dtype != RPO_DT_F32 && dtype != RPO_DT_BF16) return RPO_ERR_INVALID_ARG;
+    const int64_t gx = rpo_cdiv(cols, 64), gy = rpo_cdiv(rows, 64);
+    if (gy > 65535) return RPO_ERR_UNSUPPORTED;                 // 4 M rows
+    const int es = dtype == RPO_DT_BF16 ? 2 : 4, V = 16 / es;
+    const int vec_in = rpo_aligned16(in) && (ld_in % V == 0), vec_out = rpo_aligned16(out) && (ld_out % V == 0);
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+    if (dtype == RPO_DT_BF16)
+        RPO_LAUNCH(transpose_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out,
+                   vec_in, vec_out);
+    else
+        RPO_LAUNCH(transpose_kernel<float>, grid, dim3(256), 0, st, (const float*)in, (float*)out, rows, cols, ld_in, ld_out,
+                   vec_in, vec_out);
+    return rpo_launch_status();
+}
+
 extern "C" int rpo_swiglu_fwd(const void* g, const void* u, void* out, int64_t rows, int64_t cols, int64_t ld_gu,
                               int64_t ld_out, int dtype, rpo_stream_t stream) {
     if (!g || !u || !out || rows <= 0 || cols <= 0) return RPO_ERR_INVALID_ARG;

@@ -521,7 +521,7 @@ class LlamaEncoder(nn.Module):
         cu[1:] = torch.tensor(lens, dtype=torch.int64).cumsum(0).to(torch.int32).to(x.device, non_blocking=True)
         tiles = k_tiles = None
         if x.is_cuda and self.config.head_dim == 64 and x.dtype == torch.bfloat16:     # hand-written flash attention
-            tiles = _ops.attn_tile_table(lens, x.device)
+            tiles = _ops.attn_tile_table(lens, x.device, self.config.num_attention_heads, self.config.num_key_value_heads)
             if torch.is_grad_enabled():
                 k_tiles = _ops.attn_key_tile_table(lens, x.device, self.config.num_key_value_heads)
         ctx = VarlenCtx(cu, lens, max(lens), tiles, k_tiles)

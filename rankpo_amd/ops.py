@@ -273,13 +273,48 @@ def _swiglu_fwd(lib, gu, prod, rows, ff):
 
 
 LINEAR_TN = True      # input-gradient GEMMs against a transposed copy of the weight (`_LinearTN`); bench.py --no-linear-tn
+WGRAD_MIXED = True    # weight-gradient GEMMs with the smaller operand transposed first (`wgrad`); bench.py --no-wgrad-mixed
+
+
+def transpose2d(x):
+    """x [R, C] (row stride free, unit column stride) -> contiguous [C, R], by the HBM-bound HIP kernel (`.t().contiguous()`
+    moves 0.35 TB/s on the encoder's operand shapes)."""
+    _need_gpu(x)
+    lib = _lib.load()
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("transpose2d: a 2-D tensor with contiguous rows")
+    R, C_ = x.shape
+    out = torch.empty((C_, R), dtype=x.dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib.rpo_transpose(x.data_ptr(), out.data_ptr(), R, C_, x.stride(0), R, _dt(x), _stream(x)), "rpo_transpose")
+    return out
+
+
+def wgrad(dy2, x2):
+    """dW [n, k] = dy2[T, n]^T x2[T, k] (reduction over the tokens).  hipBLASLt's kernels for two operands that are both
+    strided along the reduction reach 0.9-1.2 PFLOP/s on the block's shapes, with ONE operand contiguous along it 1.36-1.39
+    (tools/probe_wgrad.py): when one operand is at most half of the other (gate|up: x, down: dy), a transposed copy of the
+    smaller one (0.25 ms, HBM-bound) buys 0.7-1.1 ms of GEMM time; at 2 : 3 (q|k|v) the copy costs what it saves and at
+    1 : 1 (o) autograd's layout is the fastest."""
+    n, k = dy2.shape[1], x2.shape[1]
+    if WGRAD_MIXED and dy2.is_cuda and dy2.dtype == torch.bfloat16 and dy2.stride(1) == 1 and x2.stride(1) == 1:
+        if n >= 2 * k:
+            return dy2.t() @ transpose2d(x2).t()          # x is the smaller operand
+        if k >= 2 * n:
+            return transpose2d(dy2) @ x2                   # dy is the smaller operand
+    return dy2.t() @ x2
+
+
+def _wt(w):
+    """W^T as a contiguous matrix (operand of the input-gradient GEMM in the forward's layout)."""
+    return transpose2d(w) if w.is_cuda and w.dtype in (torch.bfloat16, torch.float32) and w.stride(1) == 1 else w.t().contiguous()
 
 
 class _LinearTN(torch.autograd.Function):
     """y = x W^T (W [n, k], the nn.Linear layout) whose input gradient dX = dY W is computed against a transposed COPY of W:
     hipBLASLt's kernels for that operand layout (both operands contiguous along the reduction, the forward's layout) run
     12-18 % faster than the ones torch's own backward gets (1.23-1.58 vs 1.11-1.36 PFLOP/s on the block's four shapes,
-    tools/probe_dgrad.py), and transposing the weights of a block costs 0.3 ms against 1.4 ms saved."""
+    tools/probe_dgrad.py); the weight gradient goes through `wgrad`."""
 
     @staticmethod
     def forward(ctx, x, w):
@@ -291,9 +326,9 @@ class _LinearTN(torch.autograd.Function):
         x, w = ctx.saved_tensors
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            dx = torch.nn.functional.linear(dy, w.t().contiguous())
+            dx = torch.nn.functional.linear(dy, _wt(w))
         if ctx.needs_input_grad[1]:
-            dw = dy.reshape(-1, dy.shape[-1]).t() @ x.reshape(-1, x.shape[-1])
+            dw = wgrad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]))
         return dx, dw
 
 
@@ -330,7 +365,7 @@ class _SwiGLUDown(torch.autograd.Function):
         # dprod first; ONE pass then reads g, u, dprod and writes dg, du AND the recomputed product over dprod (6 units of
         # [T, ff] traffic instead of 3 + 5 for a separate recompute), which the weight gradient consumes afterwards
         if LINEAR_TN:
-            dprod = torch.nn.functional.linear(dy, weight.t().contiguous())   # dy @ W through the faster operand layout (see _LinearTN)
+            dprod = torch.nn.functional.linear(dy, _wt(weight))   # dy @ W through the faster operand layout (see _LinearTN)
         else:
             dprod = dy @ weight
         dgu = torch.empty_like(gu)                            # [dg | du]: the gradient of the fused projection output
@@ -342,7 +377,7 @@ class _SwiGLUDown(torch.autograd.Function):
         dW = None
         if want_dw:
             prod = dprod                                      # overwritten in place by the kernel
-            dW = dy.reshape(-1, dy.shape[-1]).t() @ prod.reshape(-1, ff)
+            dW = wgrad(dy.reshape(-1, dy.shape[-1]), prod.reshape(-1, ff))
         return dgu, dW
 
 
@@ -469,12 +504,45 @@ def rope_(x, cos, sin, heads, head_dim, grad_inplace: bool = False):
 # ------------------------------------------------------------------------------------------------
 # (6) causal variable-length flash attention, head_dim 64 (encoder side)
 # ------------------------------------------------------------------------------------------------
-def attn_tile_table(lens, device, block_m: int = 128):
-    """int32 [ntiles, 2] = (sequence id, first query row), heaviest (latest) tiles first: causal tiles late in a long
-    sequence have the most key tiles, scheduling them first evens out the tail."""
-    tiles = [(s, q0) for s, n in enumerate(lens) for q0 in range(0, n, block_m)]
-    tiles.sort(key=lambda t: -t[1])
-    return torch.tensor(tiles, dtype=torch.int32).to(device, non_blocking=True)
+def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, block_m: int = 128):
+    """The query-tile work list of the forward and dQ kernels (block = 128 queries of one (sequence, head)).
+
+    num_heads == 0: int32 [ntiles, 2] = (sequence id, first query row), heaviest (latest) tiles first; the kernels run one
+    block per (entry, head).
+    num_heads > 0 (what the encoder uses): int32 [n, 3] = (sequence id, first query row, head) dealt to the 8 XCDs -- the
+    kernels give the blocks b, b + 8, ... (one XCD under round-robin dispatch) the (b % 8)-th eighth of the list, in order.
+    The (sequence, kv head) groups go round-robin, longest sequence first, to the eighths (with 8 kv heads: XCD x gets kv head
+    x of every sequence, so the eighths are equal by construction); inside an eighth a group's tiles follow each other, latest
+    (heaviest) first, its q heads interleaved: the blocks an XCD runs at one time stream the SAME K / V rows through its L2.
+    Eighths are padded to equal length with entries the kernels skip (first query row 2^30)."""
+    import numpy as np
+    if num_heads <= 0:
+        tiles = [(s, q0) for s, n in enumerate(lens) for q0 in range(0, n, block_m)]
+        tiles.sort(key=lambda t: -t[1])
+        return torch.tensor(tiles, dtype=torch.int32).to(device, non_blocking=True)
+    H = num_kv_heads if num_kv_heads > 0 else num_heads
+    rep = num_heads // H
+    lens_np = np.asarray(lens, dtype=np.int64)
+    order = np.argsort(-lens_np, kind="stable")                       # sequences, longest first
+    nt_seq = (lens_np[order] + block_m - 1) // block_m                   # query tiles per sequence (rank order)
+    gid = np.arange(len(order) * H)                                      # group = (rank, kv head), dealt round-robin
+    chunks = []
+    for x in range(8):
+        g = gid[x::8]
+        rank, hk = g // H, g % H
+        nt = nt_seq[rank]
+        tot = int(nt.sum())
+        gi = np.repeat(np.arange(len(g)), nt)                            # group index of every tile
+        pos = np.arange(tot) - np.repeat(np.cumsum(nt) - nt, nt)
+        q0 = (nt[gi] - 1 - pos) * block_m                                # latest tile of the group first
+        seq = order[rank][gi]
+        e = np.stack([np.repeat(seq, rep), np.repeat(q0, rep),
+                      np.repeat(hk[gi] * rep, rep) + np.tile(np.arange(rep), tot)], 1).astype(np.int32)
+        chunks.append(e)
+    per = max(len(c) for c in chunks)
+    pad = np.array([[0, 1 << 30, 0]], dtype=np.int32)
+    out = [np.concatenate([c, np.repeat(pad, per - len(c), 0)], 0) for c in chunks]
+    return torch.from_numpy(np.concatenate(out, 0)).to(device, non_blocking=True)
 
 
 def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0):
@@ -492,7 +560,7 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
         lse = torch.empty((nh, T), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         check(lib.rpo_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0),
-                                     cu_seqlens.data_ptr(), tiles.data_ptr(), tiles.shape[0], T, nh, nkv, hd, scale,
+                                     cu_seqlens.data_ptr(), tiles.data_ptr(), tiles.shape[0], tiles.shape[1], T, nh, nkv, hd, scale,
                                      out.data_ptr(), nh * hd, lse.data_ptr(), padded_lse_len, _stream(q)),
               "rpo_flash_attn_fwd")
     return out, lse
@@ -570,7 +638,7 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
     with torch.cuda.device(q.device):
         check(lib.rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0),
-                                     cu_seqlens.data_ptr(), q_tiles.data_ptr(), q_tiles.shape[0], k_tiles.data_ptr(),
+                                     cu_seqlens.data_ptr(), q_tiles.data_ptr(), q_tiles.shape[0], q_tiles.shape[1], k_tiles.data_ptr(),
                                      k_tiles.shape[0], key_block, T, nh, nkv, hd, scale, lse.data_ptr(), delta.data_ptr(),
                                      dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0), dk.stride(0), dv.stride(0),
                                      _stream(q)), "rpo_flash_attn_bwd")
@@ -676,7 +744,7 @@ def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
     return best_val, best_idx
 
 
-__all__ = ["pool_normalize", "topk_merge", "linear", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
+__all__ = ["pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
            "flash_attn_varlen", "flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
            "attn_key_tile_table"]

@@ -206,3 +206,30 @@ def test_key_block_is_an_abi_argument():
                                   key_block=128)
     with pytest.raises(ValueError):
         ops.attn_key_tile_table(lens, DEV, nkv, block_n=128)
+
+
+def test_xcd_dealt_tile_list_is_only_a_schedule():
+    """The [n, 3] XCD-dealt query-tile list (what the encoder passes) and the [n, 2] list + grid.y = heads run the same
+    blocks in a different order: outputs, lse and all three gradients are bit-identical; a malformed list is refused."""
+    from rankpo_amd import ops
+    from rankpo_amd._lib import RankPOHipError
+    rs = np.random.RandomState(7)
+    for nh, nkv, lens in ((8, 2, [1, 63, 64, 65, 200, 129, 333, 700]), (32, 8, [int(x) for x in rs.randint(1, 1500, size=11)]),
+                          (4, 1, [513])):
+        T = sum(lens)
+        torch.manual_seed(T)
+        q = torch.randn(T, nh, 64, device=DEV).to(torch.bfloat16)
+        k = torch.randn(T, nkv, 64, device=DEV).to(torch.bfloat16)
+        v = torch.randn(T, nkv, 64, device=DEV).to(torch.bfloat16)
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+        kt = ops.attn_key_tile_table(lens, DEV, nkv)
+        t2, t3 = ops.attn_tile_table(lens, DEV), ops.attn_tile_table(lens, DEV, nh, nkv)
+        o2, l2 = ops.flash_attn_varlen_fwd(q, k, v, cu, t2, 0.125)
+        o3, l3 = ops.flash_attn_varlen_fwd(q, k, v, cu, t3, 0.125)
+        assert torch.equal(o2, o3) and torch.equal(l2, l3)
+        go = torch.randn_like(o2)
+        g2 = ops.flash_attn_varlen_bwd(q, k, v, o2, go, l2, cu, t2, kt, 0.125)
+        g3 = ops.flash_attn_varlen_bwd(q, k, v, o2, go, l2, cu, t3, kt, 0.125)
+        assert all(torch.equal(a, b) for a, b in zip(g2, g3))
+    with pytest.raises(RankPOHipError, match="status -2"):
+        ops.flash_attn_varlen_fwd(q, k, v, cu, t3[:-1], 0.125)          # a 3-column list must have a multiple of 8 entries

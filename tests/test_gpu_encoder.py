@@ -391,3 +391,27 @@ def test_checkpoint_round_trip_after_flat_optimizer_step(tmp_path):
         h1 = enc(input_ids=pi.to(DEV), attention_mask=pm.to(DEV)).last_hidden_state
         h2 = enc2(input_ids=pi.to(DEV), attention_mask=pm.to(DEV)).last_hidden_state
     assert torch.equal(h1, h2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_transpose_and_mixed_layout_wgrad(dtype):
+    """rpo_transpose (exact: a permutation of the elements) on aligned, ragged and strided inputs, and ops.wgrad's
+    mixed-layout weight gradient against `dy.t() @ x` (autograd's form of nn.Linear's weight gradient)."""
+    from rankpo_amd import ops
+    torch.manual_seed(3)
+    for R, C in ((256, 128), (300, 72), (64, 64), (1, 8), (5, 3), (1000, 2048), (4099, 24)):
+        x = torch.randn(R, C, device=DEV).to(dtype)
+        assert torch.equal(ops.transpose2d(x), x.t().contiguous())
+    big = torch.randn(130, 300, device=DEV).to(dtype)
+    view = big[:, 8:200]                                   # row stride 300, unaligned width
+    assert torch.equal(ops.transpose2d(view), view.t().contiguous())
+    with pytest.raises(ValueError):
+        ops.transpose2d(big.t())
+    if dtype == torch.bfloat16:
+        T = 1536
+        for n, k in ((1024, 256), (256, 1024), (512, 512), (768, 512)):
+            dy = torch.randn(T, n, device=DEV).to(dtype)
+            x = torch.randn(T, k, device=DEV).to(dtype)
+            got, ref = ops.wgrad(dy, x), dy.float().t() @ x.float()
+            assert got.shape == (n, k) and got.is_contiguous()
+            assert (got.float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max() + 1e-3

@@ -98,33 +98,38 @@ def test_bench_path_parity_hd64_bf16_packed_filler():
 
 def test_filler_sequence_changes_nothing():
     """pack_fill on / off (256-token rounding of the packed batch): same pooled rows, same loss, same weight gradients.
-    The filler is a sequence of its own, its pooled row is dropped and it has no gradient, so it adds exact zeros; what may
-    differ is the vendor GEMM's summation order for a different row count, hence bit-equality is reported and the assertion is
-    bf16 round-off."""
+    The filler is a sequence of its own, its pooled row is dropped and it has no gradient, so it adds exact zeros to every
+    sum.  Pooled rows and loss are bit-identical.  Weight gradients are bit-identical when the weight-gradient GEMMs run in
+    autograd's operand layout (measured, asserted); in the shipped mixed layout (ops.wgrad) the vendor GEMM splits the token
+    reduction differently for a different token count, so there the gradients agree to f32 summation-order round-off before the bf16
+    rounding (measured 2.5e-5 relative L2; asserted <= 1e-3, against the 0.9-1.9 % the bf16 gradients are off the f32 oracle)."""
     import rankpo_amd
-    from rankpo_amd import encoder as PE
+    from rankpo_amd import encoder as PE, ops
     cfg, enc, model = _model(PE, rankpo_amd, seed=1)
     batch, _ = _batch()
     gb = {k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in batch.items()}
-    res = {}
-    for fill in (True, False):
+
+    def run(fill):
         enc.pack_fill = fill
         enc.zero_grad()
         out = model(**gb)
         out.loss.backward()
-        res[fill] = (out.q_reps.detach().clone(), out.p_reps.detach().clone(), out.loss.item(),
-                     {n: p.grad.detach().clone() for n, p in enc.named_parameters()})
-    enc.pack_fill = True
-    exact_rows = torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
-    exact_grads = all(torch.equal(res[True][3][n], res[False][3][n]) for n in res[True][3])
-    print(f"\nfiller on/off: pooled rows bit-identical={exact_rows}, weight gradients bit-identical={exact_grads}")
-    assert exact_rows and exact_grads       # measured: bit-identical on MI355X (round 2); the bounds below say what a miss means
-    for a, b in zip(res[True][:2], res[False][:2]):
-        assert (a.float() - b.float()).abs().max() <= 2.0 ** -7          # unit-norm rows: one bf16 ulp at 1.0
-    assert abs(res[True][2] - res[False][2]) <= 2e-2 * max(1.0, abs(res[False][2]))
-    for n, g in res[False][3].items():
-        d = (res[True][3][n].float() - g.float()).norm() / g.float().norm().clamp_min(1e-30)
-        assert d <= 2e-2, (n, float(d))
+        return (out.q_reps.detach().clone(), out.p_reps.detach().clone(), out.loss.item(),
+                {n: p.grad.detach().clone() for n, p in enc.named_parameters()})
+    try:
+        for mixed in (False, True):
+            ops.WGRAD_MIXED = mixed
+            on, off = run(True), run(False)
+            exact_rows = torch.equal(on[0], off[0]) and torch.equal(on[1], off[1])
+            exact_grads = all(torch.equal(on[3][n], off[3][n]) for n in on[3])
+            worst = max(float((on[3][n].float() - g.float()).norm() / g.float().norm().clamp_min(1e-30)) for n, g in off[3].items())
+            print(f"\nfiller on/off (mixed-layout wgrad {mixed}): pooled rows bit-identical={exact_rows}, weight gradients "
+                  f"bit-identical={exact_grads}, worst relative gradient difference {worst:.2e}")
+            assert exact_rows and on[2] == off[2]
+            assert exact_grads if not mixed else worst <= 1e-3
+    finally:
+        ops.WGRAD_MIXED = True
+        enc.pack_fill = True
 
 
 def _mask_kinds(rs, N, L):

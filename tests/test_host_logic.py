@@ -309,11 +309,11 @@ def test_bench_attention_flops_follow_the_kernel_arguments():
         ops.attn_tile_table(lens, "cpu")
         T = sum(lens)
         assert T % 256 == 0
-        a = [None] * 20
-        a[15:20] = 256, T, 32, 8, 64
+        a = [None] * 21
+        a[16:21] = 256, T, 32, 8, 64
         nbytes, flops = bench._algo("rpo_flash_attn_bwd", a)
         assert flops == 10 * 64 * 32 * sum(n * (n + 1) // 2 for n in lens) > 0
-        a[16] = T - 1
+        a[17] = T - 1
         with pytest.raises(KeyError, match="no sequence lengths registered"):
             bench._algo("rpo_flash_attn_bwd", a)
     finally:
@@ -404,3 +404,41 @@ def test_key_block_table_properties():
             assert (chunk[len(work):, 2] == (1 << 30)).all()
             for s, h, k in chunk[:len(work)].tolist():
                 assert owner.setdefault((s, h), x) == x
+
+
+def test_query_tile_table_properties():
+    """ops.attn_tile_table in its XCD-dealt form (the forward / dQ kernels' work list): every (sequence, 128-query tile, head)
+    exactly once, a (sequence, kv head) group inside ONE eighth and contiguous there (its blocks stream the same K / V through
+    one L2), latest tiles of a group first, eighths padded to equal length with entries the kernels skip."""
+    from rankpo_amd import ops
+    rs = np.random.RandomState(1)
+    for nh, nkv, lens in ((32, 8, rs.randint(1, 4097, size=29).tolist()), (8, 2, [5, 300, 257, 256, 1]), (4, 1, [1000]),
+                          (4, 4, [129, 128])):
+        t = ops.attn_tile_table(lens, "cpu", nh, nkv).numpy()
+        assert t.shape[1] == 3 and t.shape[0] % 8 == 0
+        per = t.shape[0] // 8
+        real = t[t[:, 1] < (1 << 30)]
+        want = {(s, q0, h) for s, n in enumerate(lens) for q0 in range(0, n, 128) for h in range(nh)}
+        assert len(real) == len(want) and set(map(tuple, real.tolist())) == want
+        rep = nh // nkv
+        owner = {}
+        for x in range(8):
+            chunk = t[x * per:(x + 1) * per]
+            nreal = int((chunk[:, 1] < (1 << 30)).sum())
+            assert (chunk[nreal:, 1] == (1 << 30)).all()                      # padding last
+            groups = [(s, h // rep) for s, q0, h in chunk[:nreal].tolist()]
+            for gkey in groups:
+                assert owner.setdefault(gkey, x) == x                           # one eighth per group
+            # contiguous: a group never re-appears after another one started
+            seen, last = set(), None
+            for gkey in groups:
+                if gkey != last:
+                    assert gkey not in seen
+                    seen.add(gkey)
+                    last = gkey
+            # inside a group: first query rows non-increasing
+            for gkey in seen:
+                q0s = [q0 for s, q0, h in chunk[:nreal].tolist() if (s, h // rep) == gkey]
+                assert q0s == sorted(q0s, reverse=True)
+    legacy = ops.attn_tile_table([300, 5], "cpu").numpy()
+    assert legacy.shape == (4, 2) and legacy[0, 1] == 256

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Interleaved A/B in ONE process (rounds x variants, medians): the query-tile work list of the forward / dQ kernels in its
+two formats -- [n, 2] + grid.y = heads (round 1) vs the XCD-dealt [n, 3] list -- on the cfg-2 passage batch."""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from rankpo_amd import ops
+DEV = "cuda"; torch.manual_seed(0)
+nh, nkv, hd, N, L = 32, 8, 64, 48, 4096
+lens = torch.randint(L // 2, L + 1, (N,)); lens[0] = L
+lens = lens.tolist(); T = sum(lens)
+q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+kt = ops.attn_key_tile_table(lens, DEV, nkv)
+tabs = {"list2": ops.attn_tile_table(lens, DEV), "xcd3": ops.attn_tile_table(lens, DEV, nh, nkv)}
+fl = sum(4 * nh * hd * n * (n + 1) / 2 for n in lens)
+out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tabs["list2"], 0.125)
+go = torch.randn_like(out)
+
+
+def t(fn, n=5):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+res = {(a, b): [] for a in tabs for b in ("fwd", "bwd")}
+for name, tb in tabs.items():
+    for _ in range(3):
+        ops.flash_attn_varlen_fwd(q, k, v, cu, tb, 0.125); ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tb, kt, 0.125)
+for rnd in range(int(os.environ.get("ROUNDS", "7"))):
+    for name, tb in tabs.items():
+        res[(name, "fwd")].append(t(lambda: ops.flash_attn_varlen_fwd(q, k, v, cu, tb, 0.125)))
+        res[(name, "bwd")].append(t(lambda: ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tb, kt, 0.125)))
+for (name, what), ts in res.items():
+    ts.sort(); med = ts[len(ts) // 2]
+    f = fl if what == "fwd" else 2.5 * fl
+    print(f"{what} {name}: median {med:.3f} ms (min {ts[0]:.3f}) = {f / med / 1e9:.0f} TFLOP/s", flush=True)
+a = ops.flash_attn_varlen_fwd(q, k, v, cu, tabs["list2"], 0.125); b = ops.flash_attn_varlen_fwd(q, k, v, cu, tabs["xcd3"], 0.125)
+print("fwd outputs bit-identical:", torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]))
+a = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tabs["list2"], kt, 0.125)
+b = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tabs["xcd3"], kt, 0.125)
+print("bwd outputs bit-identical:", all(torch.equal(x, y) for x, y in zip(a, b)))
