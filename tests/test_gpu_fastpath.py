@@ -5,7 +5,8 @@ the packed token count up to a multiple of 256 (needs >= 4096 packed tokens).
 
 The tolerance is not a guessed constant: the same tokens and weights also go through a CONTROL -- the oracle's eager
 arithmetic (HF eager semantics) in bf16 on the GPU, i.e. the reference's stock reduced-precision path -- and the fast path
-must be no further from the float32 oracle than 1.5x the control (`bench.step_parity`, the same rule the bench line's
+must be no further from the float32 oracle than 1.5x the control (2x on the max cosine error, an extreme-value statistic;
+`bench.step_parity`, the same rule the bench line's
 `step_loss_parity` asserts).  Also here: left-padded / holed masks through the product's `embed` (a2's reference edge case).
 """
 import importlib
