@@ -555,6 +555,64 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
 // ------------------------------------------------------------------------------------------------
 constexpr int kSkinnyThreads = 512, kSkinnyWaves = 8, kSkinnyUnroll = 8, kSkinnyMaxFusedGroups = 16;
 
+// One finished 16 (passages of group pg) x 16 (queries) tile, held as the MFMA accumulator layout (lane = query column
+// lane & 15, registers = passages 4 (lane >> 4) + j): round / scale / store the scores, reduce the rows' softmax partial over
+// the tile's 16 columns, and either park (max, sum) + the positive's score in LDS (fused single-block finalize) or write the
+// partial to the workspace.
+template <typename T>
+__device__ __forceinline__ void skinny_tile_epilogue(const float4_t& t, int pg, int ngroups, int64_t qr, bool bv, int g,
+                                                     int64_t Q, int64_t P, float temperature, int scale, int do_stats,
+                                                     bool fused, int64_t group, T* __restrict__ scores,
+                                                     float2* __restrict__ partial, float2 (*s_part)[64], float* s_tgt) {
+    if (pg >= ngroups) return;
+    const int64_t pbase = (int64_t)pg * 16 + g * 4;
+    const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
+    const float inv_t = 1.0f / temperature;
+    float v[4];
+    float mx = RPO_NEG_INF;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v[j] = finish_score<T>(t[j], temperature, inv_t, scale);
+        if (pbase + j < P) mx = fmaxf(mx, v[j]);
+    }
+    if (bv) store_scores4<T>(scores + qr * P, pbase, P, v, vec_ok);
+    if (!do_stats) return;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (pbase + j < P) sum += exp_sub(v[j], mx * RPO_LOG2E);
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
+        softmax_merge(mx, sum, om, ol);
+    }
+    if (!bv) return;
+    if (fused) {
+        if (g == 0) s_part[pg][qr] = make_float2(mx, sum);
+        const int64_t tgt = qr * group;                  // the positive's column (modeling.py:301-302)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (pbase + j == tgt) s_tgt[qr] = v[j];
+    } else if (g == 0) {
+        partial[(int64_t)pg * Q + qr] = make_float2(mx, sum);
+    }
+}
+
+// lse / loss of a single-block launch from the per-group partials parked in LDS (thread i < Q owns row i)
+__device__ __forceinline__ void skinny_fused_finalize(int tid, int64_t Q, int ngroups, float2 (*s_part)[64], const float* s_tgt,
+                                                      float* s_red, float* __restrict__ lse_out, float* __restrict__ loss_out) {
+    float rowloss = 0.f;
+    if (tid < Q) {
+        float m = RPO_NEG_INF, l = 0.f;
+        for (int b2 = 0; b2 < ngroups; ++b2) softmax_merge(m, l, s_part[b2][tid].x, s_part[b2][tid].y);
+        const float lse = m + logf(l);
+        lse_out[tid] = lse;
+        rowloss = lse - s_tgt[tid];
+    }
+    const float tot = block_sum<8>(rowloss, s_red);
+    if (tid == 0) loss_out[0] = tot / (float)Q;
+}
+
 template <typename T, int NG>
 __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
     const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
@@ -618,56 +676,119 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
             float4_t t = s_acc[0][wave][lane];
 #pragma unroll
             for (int w = 1; w < kSkinnyWaves; ++w) t += s_acc[w][wave][lane];      // fixed order: wave 0 + 1 + ... + 7
-            const int pg = pg0 + wave;
-            if (pg < ngroups) {
-                const int64_t pbase = (int64_t)pg * 16 + g * 4;
-                const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
-                const float inv_t = 1.0f / temperature;
-                float v[4];
-                float mx = RPO_NEG_INF;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    v[j] = finish_score<T>(t[j], temperature, inv_t, scale);
-                    if (pbase + j < P) mx = fmaxf(mx, v[j]);
-                }
-                if (bv) store_scores4<T>(scores + qr * P, pbase, P, v, vec_ok);
-                if (do_stats) {
-                    float sum = 0.f;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (pbase + j < P) sum += exp_sub(v[j], mx * RPO_LOG2E);
-#pragma unroll
-                    for (int o = 16; o <= 32; o <<= 1) {
-                        const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
-                        softmax_merge(mx, sum, om, ol);
-                    }
-                    if (bv) {
-                        if (fused) {
-                            if (g == 0) s_part[pg][qr] = make_float2(mx, sum);
-                            const int64_t tgt = qr * group;                  // the positive's column (modeling.py:301-302)
-#pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (pbase + j == tgt) s_tgt[qr] = v[j];
-                        } else if (g == 0) {
-                            partial[(int64_t)pg * Q + qr] = make_float2(mx, sum);
-                        }
-                    }
-                }
-            }
+            skinny_tile_epilogue<T>(t, pg0 + wave, ngroups, qr, bv, g, Q, P, temperature, scale, do_stats, fused, group, scores,
+                                    partial, s_part, s_tgt);
         }
         __syncthreads();                              // s_acc is rewritten by the next pass
     }
     if (!fused) return;
-    float rowloss = 0.f;
-    if (tid < Q) {
-        float m = RPO_NEG_INF, l = 0.f;
-        for (int b2 = 0; b2 < ngroups; ++b2) softmax_merge(m, l, s_part[b2][tid].x, s_part[b2][tid].y);
-        const float lse = m + logf(l);
-        lse_out[tid] = lse;
-        rowloss = lse - s_tgt[tid];
+    skinny_fused_finalize(tid, Q, ngroups, s_part, s_tgt, s_red, lse_out, loss_out);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Small kernel: the reference's single-GPU shapes (Q <= 16, P <= 128, e.g. 8 x 48 x 2048) as ONE block with COALESCED loads.
+//   Why: the skinny kernel's fragment-shaped loads (16 rows x 64 B per wave instruction) bring one CU ~35 GB/s, so its
+//   one-block launch spends 6.4 of its ~8 us loading 224 KB.  Here every wave instruction loads 1 KiB of ONE row
+//   (whole 128-byte lines), all (P + Q) rows x 2 K-halves are in flight at once (<= 32 x 16 B per lane), and the MFMA
+//   fragments come out of an LDS image: rows of KCB + 32 bytes (the 32-byte skew puts the 16 rows of a ds_read_b128
+//   fragment on distinct bank groups), queries in rows 0..15, passage group pg in rows 16 + 16 pg ...  The row length is
+//   processed in two chunks of KCB bytes because (P + 16) x 4 KiB exceeds LDS.  Rows / K-tails that do not exist are
+//   zero (K-tail) or never leave their own output row / column (missing rows), which is masked at the stores.
+//   K is split over the 8 waves per 64-byte segment as in the skinny kernel; the 8 partial tiles per passage group are
+//   summed through LDS in wave order, then wave t finishes group t and the block finalizes lse / loss.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSmallThreads = 512, kSmallMaxGroups = 8, kSmallQPieces = 4, kSmallPPieces = 14;   // pieces per wave and chunk
+
+template <typename T>
+__global__ __launch_bounds__(kSmallThreads) void sim_small_kernel(
+    const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature, int scale,
+    int do_stats, int64_t group, T* __restrict__ scores, float* __restrict__ lse_out, float* __restrict__ loss_out,
+    int kcb, int stage_bytes) {
+    typedef typename Mma<T>::Frag Frag;
+    extern __shared__ __attribute__((aligned(16))) unsigned char s_raw[];
+    __shared__ float2 s_part[kSmallMaxGroups][64];
+    __shared__ float s_tgt[64];
+    __shared__ float s_red[8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, frow = lane & 15;
+    const int ngroups = (int)((P + 15) / 16);
+    const int row_bytes = (int)(d * (int64_t)sizeof(T));
+    const int ldsrow = kcb + 32;
+    // A chunk of a row is 1 << pshift pieces of 1 KiB.  Wave w owns piece j = w & pmask of rows (w >> pshift) + i * rstep:
+    // per load only an offset increment is left (the first version recomputed row / piece / base per load: ~55
+    // instructions each, 1750 before the first wait).  Offsets are 32-bit against the uniform q / p base pointers.
+    const int pshift = 31 - __builtin_clz((unsigned)(kcb >> 10));
+    const int pmask = (1 << pshift) - 1;
+    const int rstep = 8 >> pshift, row0 = wave >> pshift;
+    const unsigned jbyte = (unsigned)((wave & pmask) * 1024 + lane * 16);
+    const unsigned rb = (unsigned)row_bytes, gstep = (unsigned)rstep * rb, lstep = (unsigned)(rstep * ldsrow);
+    const unsigned char* qb = reinterpret_cast<const unsigned char*>(q);
+    const unsigned char* pb = reinterpret_cast<const unsigned char*>(p);
+    constexpr int NPQ = kSmallQPieces, NPP = kSmallPPieces;
+    uint4_t bq[2][NPQ], bp[2][NPP];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i) bq[c][i] = uint4_t{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NPP; ++i) bp[c][i] = uint4_t{0u, 0u, 0u, 0u};
+        const unsigned koff = (unsigned)(c * kcb) + jbyte;
+        if (koff < rb) {                                   // the K tail of a short row stays zero
+            unsigned off = (unsigned)row0 * rb + koff;
+#pragma unroll
+            for (int i = 0; i < NPQ; ++i, off += gstep)
+                if (row0 + i * rstep < (int)Q) bq[c][i] = *reinterpret_cast<const uint4_t*>(qb + off);
+            off = (unsigned)row0 * rb + koff;
+#pragma unroll
+            for (int i = 0; i < NPP; ++i, off += gstep)
+                if (row0 + i * rstep < (int)P) bp[c][i] = *reinterpret_cast<const uint4_t*>(pb + off);
+        }
     }
-    const float tot = block_sum<kSkinnyWaves>(rowloss, s_red);
-    if (tid == 0) loss_out[0] = tot / (float)Q;
+    float4_t acc[kSmallMaxGroups];
+#pragma unroll
+    for (int n = 0; n < kSmallMaxGroups; ++n) acc[n] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const int nseg = kcb >> 6;                            // 64-byte K segments per chunk
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        if (c * kcb >= row_bytes) break;                   // short rows fit one chunk
+        unsigned lo = (unsigned)(row0 * ldsrow) + jbyte;
+#pragma unroll
+        for (int i = 0; i < NPQ; ++i, lo += lstep)
+            if (row0 + i * rstep < (int)Q) *reinterpret_cast<uint4_t*>(s_raw + lo) = bq[c][i];
+        lo = (unsigned)((16 + row0) * ldsrow) + jbyte;
+#pragma unroll
+        for (int i = 0; i < NPP; ++i, lo += lstep)
+            if (row0 + i * rstep < (int)P) *reinterpret_cast<uint4_t*>(s_raw + lo) = bp[c][i];
+        __syncthreads();
+        for (int sgm = wave; sgm < nseg; sgm += 8) {
+            const int koff = sgm * 64 + g * 16;
+            const Frag b = *reinterpret_cast<const Frag*>(s_raw + frow * ldsrow + koff);
+#pragma unroll
+            for (int n = 0; n < kSmallMaxGroups; ++n)
+                if (n < ngroups) {
+                    const Frag a = *reinterpret_cast<const Frag*>(s_raw + (16 + 16 * n + frow) * ldsrow + koff);
+                    Mma<T>::mma(a, b, acc[n]);
+                }
+        }
+        __syncthreads();                                  // the image is overwritten by the next chunk / by the partial sums
+    }
+    float4_t (*s_acc)[kSmallMaxGroups][64] = reinterpret_cast<float4_t (*)[kSmallMaxGroups][64]>(s_raw);   // [8][8][64]
+#pragma unroll
+    for (int n = 0; n < kSmallMaxGroups; ++n)
+        if (n < ngroups) s_acc[wave][n][lane] = acc[n];
+    __syncthreads();
+    const bool fused = do_stats != 0;
+    if (wave < ngroups) {
+        float4_t t = s_acc[0][wave][lane];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) t += s_acc[w][wave][lane];          // fixed order: wave 0 + 1 + ... + 7
+        skinny_tile_epilogue<T>(t, wave, ngroups, frow, frow < Q, g, Q, P, temperature, scale, do_stats, fused, group, scores,
+                                nullptr, s_part, s_tgt);
+    }
+    if (!fused) return;
+    __syncthreads();
+    skinny_fused_finalize(tid, Q, ngroups, s_part, s_tgt, s_red, lse_out, loss_out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1049,6 +1170,27 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         }
     } else if (pl.path == PATH_SKINNY) {
         const int ng = Q <= 16 ? 4 : 1;
+        // the reference's single-GPU shapes: one block, coalesced loads through an LDS image (sim_small_kernel)
+        {
+            const int64_t row_bytes = d * (int64_t)sizeof(T);
+            int64_t kcb = 1024;                                   // bytes of a row per chunk: a power-of-two number of KiB
+            while (2 * kcb < row_bytes) kcb *= 2;
+            const int64_t stage = (16 + 16 * (int64_t)pl.nPb) * (kcb + 32);
+            const int64_t accb = 8 * (int64_t)kSmallMaxGroups * 64 * 16;
+            const int64_t lds = stage > accb ? stage : accb;
+            if (Q <= 16 && pl.nPb <= kSmallMaxGroups && kcb <= 8192 && Q * (kcb / 1024) <= 8 * kSmallQPieces &&
+                P * (kcb / 1024) <= 8 * kSmallPPieces && lds <= 150 * 1024 && row_bytes % 16 == 0) {
+                static bool attr_set_small = false;
+                if (!attr_set_small) {
+                    (void)hipFuncSetAttribute((const void*)sim_small_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              150 * 1024);
+                    attr_set_small = true;
+                }
+                RPO_LAUNCH(sim_small_kernel<T>, dim3(1), dim3(kSmallThreads), (size_t)lds, st, (const T*)q, (const T*)p, Q, P, d,
+                           temperature, scale, do_stats ? 1 : 0, P / Q, (T*)scores_out, lse_out, loss_out, (int)kcb, (int)lds);
+                return rpo_launch_status();
+            }
+        }
         const int64_t npass = rpo_cdiv(pl.nPb, ng) * rpo_cdiv(Q, 16);
         // small problems (every single-GPU shape of the reference: 8 x 48 x 2048 bf16 is 224 KB) run as ONE block that
         // walks all passes and finishes lse / loss itself: a second launch costs more than the one CU loses in bandwidth
