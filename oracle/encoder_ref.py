@@ -112,8 +112,8 @@ def bert_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: to
         pos = W("embeddings.position_embeddings.weight")[:L][None]
     x = W("embeddings.word_embeddings.weight")[input_ids] + W("embeddings.token_type_embeddings.weight")[0] + pos
     x = _ln(x, W("embeddings.LayerNorm.weight"), W("embeddings.LayerNorm.bias"), eps)
-    bias = torch.zeros(N, 1, 1, L, dtype=dtype).masked_fill(~attention_mask.bool()[:, None, None, :],
-                                                            torch.finfo(dtype).min)
+    bias = torch.zeros(N, 1, 1, L, dtype=dtype, device=x.device).masked_fill(~attention_mask.bool()[:, None, None, :],
+                                                                             torch.finfo(dtype).min)
     for i in range(cfg["num_hidden_layers"]):
         p = f"encoder.layer.{i}."
         lin = lambda name, t: t @ W(p + name + ".weight").T + W(p + name + ".bias")
