@@ -125,7 +125,7 @@ def _algo(name, a):
         pairs = _attn_pairs(T)                            # causal (query, key) pairs of this packed batch
         return 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh, 4 * hd * pairs * nh
     if name == "rpo_flash_attn_bwd":
-        T, nh, nkv, hd = a[17], a[18], a[19], a[20]        # a[13] = q_tile_cols, a[16] = key_block
+        T, nh, nkv, hd = a[18], a[19], a[20], a[21]        # a[13] = q_tile_cols, a[16] = key_block, a[17] = sweep_down
         pairs = _attn_pairs(T)
         return 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, 10 * hd * pairs * nh
     if name == "rpo_transpose":
@@ -627,17 +627,17 @@ def main():
         if kernels:
             top = kernels[0]
             # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed
-            # rocprofv3 passes (profiles/r01_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE over algorithmic bytes,
+            # rocprofv3 passes (profiles/r02_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE over algorithmic bytes,
             # measured per kernel at the same shapes) give the ratio that is applied to this run's bytes.
             traffic, tsrc = None, None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
                 key = {"rpo_swiglu_fwd": "swiglu_fwd_kernel", "rpo_swiglu_bwd": "swiglu_bwd_kernel",
                        "rpo_adamw_step": "adamw_kernel", "rpo_rope": "rope_kernel",
                        "rpo_sumsq_partial": "sumsq_kernel"}.get(top["entry"])
                 if key in pmc:
                     traffic = int(top["algo_bytes"] * pmc[key]["traffic_over_algorithmic"])
-                    tsrc = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
+                    tsrc = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
                             "FETCH x2 gfx950 correction), ratio %.3f applied to this run's algorithmic bytes"
                             % pmc[key]["traffic_over_algorithmic"])
             except Exception:
@@ -645,11 +645,11 @@ def main():
             if top["bound"] == "mfma":
                 mtraffic, msrc = None, None
                 try:
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
                     if top["entry"] in pmc:
                         ratio = pmc[top["entry"]]["traffic_over_algorithmic"]
                         mtraffic = int(top["algo_bytes"] * ratio)
-                        msrc = ("profiles/r01_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH "
+                        msrc = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH "
                                 "x2 gfx950 correction) of this entry point's kernels on the cfg-2 passage batch, ratio %.2f "
                                 "applied to this run's algorithmic bytes" % ratio)
                 except Exception:

@@ -243,7 +243,7 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
 int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, int64_t q_stride,
                        int64_t k_stride, int64_t v_stride, int64_t out_stride, int64_t dout_stride,
                        const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles, int64_t q_tile_cols, const int* k_tiles,
-                       int64_t n_k_tiles, int64_t key_block, int64_t total_tokens, int64_t num_heads,
+                       int64_t n_k_tiles, int64_t key_block, int64_t sweep_down, int64_t total_tokens, int64_t num_heads,
                        int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta, void* dq, void* dk, void* dv,
                        int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, rpo_stream_t stream);
 

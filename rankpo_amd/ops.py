@@ -567,19 +567,22 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
 
 
 ATTN_KEY_BLOCK = 256     # keys per entry of the dK/dV work list (256: one-wave-per-SIMD kernel; 64: the 8-wave kernel)
+ATTN_SWEEP_DOWN = False  # dK/dV schedule: key blocks of a (sequence, kv head) side by side, sweeping the query slices downwards
 
 
-def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = ATTN_KEY_BLOCK):
+def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = ATTN_KEY_BLOCK, group_order=None):
     """int32 [n, 3] = (sequence id, kv head, first key of a key block): the key blocks of one (sequence, kv head) read the same
     Q / dO rows and are placed on one XCD by the kernel's block -> entry map.  block_n = 256 keys (default, the
     one-wave-per-SIMD dK/dV kernel) or 64 (the 8-wave kernel, A/B); whoever builds a table with block_n = 64 passes
     key_block=64 to `flash_attn_varlen(_qkv)` as well -- it is an argument of the C call, not an environment switch."""
     if block_n not in (64, 256):
         raise ValueError("attn_key_tile_table: block_n must be 64 or 256")
-    return _attn_key_tile_table(lens, device, num_kv_heads, block_n)
+    if group_order is None:
+        group_order = ATTN_SWEEP_DOWN
+    return _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order)
 
 
-def _attn_key_tile_table(lens, device, num_kv_heads, block_n):
+def _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order=False):
     import numpy as np
     if block_n != 256:
         parts = []
@@ -609,7 +612,10 @@ def _attn_key_tile_table(lens, device, num_kv_heads, block_n):
     chunks = []
     for x in range(8):
         sel = np.nonzero(xcd == x)[0]
-        sel = sel[np.argsort(-work[sel], kind="stable")]
+        if not group_order:                     # heaviest blocks of the eighth first (round 1's schedule)
+            sel = sel[np.argsort(-work[sel], kind="stable")]
+        # group_order: index order = (kv head, sequence longest first, first key ascending): the key blocks of a
+        # (sequence, kv head) stay next to each other, heaviest first (pairs with sweep_down=True of the kernel)
         chunks.append(np.stack([seqs[sel], heads[sel], k0s[sel]], 1).astype(np.int32))
     per = max(len(c) for c in chunks)
     pad = np.array([[0, 0, 1 << 30]], dtype=np.int32)
@@ -618,10 +624,12 @@ def _attn_key_tile_table(lens, device, num_kv_heads, block_n):
 
 
 def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale, grads=None,
-                          key_block: int = ATTN_KEY_BLOCK):
+                          key_block: int = ATTN_KEY_BLOCK, sweep_down=None):
     """grads: optional preallocated (dq, dk, dv) [T, heads, 64] views with arbitrary token strides (e.g. the three column
     blocks of ONE fused d(q|k|v) buffer).  key_block: keys per entry of `k_tiles` (`attn_key_tile_table`'s block_n)."""
     lib = _lib.load()
+    if sweep_down is None:
+        sweep_down = ATTN_SWEEP_DOWN
     T, nh, hd = q.shape
     nkv = k.shape[1]
     dout = dout.contiguous()
@@ -639,7 +647,7 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
         check(lib.rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0),
                                      cu_seqlens.data_ptr(), q_tiles.data_ptr(), q_tiles.shape[0], q_tiles.shape[1], k_tiles.data_ptr(),
-                                     k_tiles.shape[0], key_block, T, nh, nkv, hd, scale, lse.data_ptr(), delta.data_ptr(),
+                                     k_tiles.shape[0], key_block, int(bool(sweep_down)), T, nh, nkv, hd, scale, lse.data_ptr(), delta.data_ptr(),
                                      dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0), dk.stride(0), dv.stride(0),
                                      _stream(q)), "rpo_flash_attn_bwd")
     return dq, dk, dv

@@ -309,11 +309,11 @@ def test_bench_attention_flops_follow_the_kernel_arguments():
         ops.attn_tile_table(lens, "cpu")
         T = sum(lens)
         assert T % 256 == 0
-        a = [None] * 21
-        a[16:21] = 256, T, 32, 8, 64
+        a = [None] * 22
+        a[16:22] = 256, 0, T, 32, 8, 64
         nbytes, flops = bench._algo("rpo_flash_attn_bwd", a)
         assert flops == 10 * 64 * 32 * sum(n * (n + 1) // 2 for n in lens) > 0
-        a[17] = T - 1
+        a[18] = T - 1
         with pytest.raises(KeyError, match="no sequence lengths registered"):
             bench._algo("rpo_flash_attn_bwd", a)
     finally:
@@ -379,7 +379,7 @@ def test_generated_dkdv_slice_body_is_in_sync():
     src = open(os.path.join(root, "rankpo_amd", "csrc", "attention.hip")).read()
     norm = lambda t: [re.sub(r"\s*\\$", "", ln.rstrip()) for ln in t.splitlines() if ln.strip()]
     a = src.index("// generated by tools/gen/gen_dkdv4_body.py")
-    b = src.index("__global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(")
+    b = src.index("template <bool DOWN>\n__global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(")
     assert norm(src[a:b]) == norm(gen)
 
 

@@ -19,7 +19,7 @@ q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
 k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
 v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
 cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
-tiles = ops.attn_tile_table(lens, DEV)
+tiles = ops.attn_tile_table(lens, DEV, nh, nkv)        # XCD-dealt list, what the encoder passes (round 2)
 kt = ops.attn_key_tile_table(lens, DEV, nkv)
 out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, 0.125)
 go = torch.randn_like(out)

@@ -37,6 +37,27 @@ for rnd in range(int(os.environ.get("ROUNDS", "7"))):
     for name, tb in tabs.items():
         res[(name, "fwd")].append(t(lambda: ops.flash_attn_varlen_fwd(q, k, v, cu, tb, 0.125)))
         res[(name, "bwd")].append(t(lambda: ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tb, kt, 0.125)))
+# dK/dV schedule: heaviest-first list + ascending sweep (round 1) vs group-ordered list + downward slice-major sweep
+kts = {"heavy/up": (ops.attn_key_tile_table(lens, DEV, nkv, group_order=False), False),
+       "group/down": (ops.attn_key_tile_table(lens, DEV, nkv, group_order=True), True),
+       "heavy/down": (ops.attn_key_tile_table(lens, DEV, nkv, group_order=False), True),
+       "group/up": (ops.attn_key_tile_table(lens, DEV, nkv, group_order=True), False)}
+tb3 = tabs["xcd3"]
+r2 = {n: [] for n in kts}
+for n, (ktab, down) in kts.items():
+    for _ in range(2):
+        ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tb3, ktab, 0.125, sweep_down=down)
+for rnd in range(int(os.environ.get("ROUNDS", "7"))):
+    for n, (ktab, down) in kts.items():
+        r2[n].append(t(lambda: ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tb3, ktab, 0.125, sweep_down=down)))
+for n, ts in r2.items():
+    ts.sort()
+    print(f"bwd (xcd3 q list) dK/dV schedule {n}: median {ts[len(ts)//2]:.3f} ms (min {ts[0]:.3f}) = {2.5 * fl / ts[len(ts)//2] / 1e9:.0f} TFLOP/s", flush=True)
+ra = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tb3, kts["heavy/up"][0], 0.125, sweep_down=False)
+rb = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tb3, kts["group/down"][0], 0.125, sweep_down=True)
+print("dK/dV schedules: dq identical", torch.equal(ra[0], rb[0]), "; max |d dk|, |d dv| =",
+      float((ra[1].float() - rb[1].float()).abs().max()), float((ra[2].float() - rb[2].float()).abs().max()),
+      "; |dk|max", float(ra[1].float().abs().max()))
 for (name, what), ts in res.items():
     ts.sort(); med = ts[len(ts) // 2]
     f = fl if what == "fwd" else 2.5 * fl
