@@ -160,6 +160,14 @@ SHAPES = [
     (512, 512, 64),     # 256x256 phased tile kernel (bf16), single K step
     (512, 1536, 256),   # 256x256 kernel, 4 K steps
     (600, 1800, 192),   # 256x256 kernel, ragged edges in both dimensions, odd K-step count
+    # one-block kernel with coalesced loads (sim_small_kernel: Q <= 16, P <= 112 / pieces): limits and K tails
+    (1, 1, 8),          # smallest: one 16-byte piece (bf16), 32 bytes (f32)
+    (16, 112, 1024),    # most rows it takes at 2 KiB (bf16) rows; f32 rows are 4 KiB: 2 pieces per chunk
+    (16, 16, 264),      # 528-byte rows (bf16): one partial piece, zero K tail
+    (9, 27, 1032),      # 2064-byte rows (bf16): the second chunk holds 16 bytes
+    (2, 100, 512),      # 7 passage groups, last one ragged
+    (8, 64, 2048),      # P * pieces over the limit -> falls back to the skinny kernel (one block, fused finalize)
+    (16, 96, 2048),     # > 384 KB: skinny kernel on two blocks + ce_finalize
 ]
 
 
