@@ -66,6 +66,14 @@ __device__ __forceinline__ float finish_score(float acc, float temperature, floa
     return x;
 }
 
+// two f32 -> one dword of two bf16 (round to nearest even, NaN kept) in ONE v_cvt_pk_bf16_f32; written as
+// `f32_to_bf16(a) | f32_to_bf16(b) << 16` hipcc converts each value on its own and merges them with a third instruction.
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // exp(v - m) as one FMA + one v_exp_f32
 #define RPO_LOG2E 1.4426950408889634f
 __device__ __forceinline__ float exp_sub(float v, float m_log2e) { return __builtin_amdgcn_exp2f(fmaf(v, RPO_LOG2E, -m_log2e)); }
@@ -457,6 +465,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     // instead of 8-byte stores that touch a quarter of a 128-byte line each (measured: the direct stores cost 14 %
     // of the kernel at Q = P = 16384).
     const bool staged = (P % 8 == 0) && rpo_aligned16_dev(scores) && !(dbg & 2);
+    const bool interior = staged && p0 + kBigTile <= P && q0 + kBigTile <= Q;
     char* wstage = smem + wave * kBigStageWaveBytes;
     float2* s_stat = reinterpret_cast<float2*>(smem + 8 * kBigStageWaveBytes);   // [wq][64] from the wp == 1 waves
 #pragma unroll
@@ -464,30 +473,71 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         const int64_t qi = qbase + 16 * n;
         const bool qv = qi < Q;
         float mx = RPO_NEG_INF, sum = 0.f;
+        if (interior) {
+            // interior tile (no row or column outside the matrix): no bounds tests, both roundings as packed conversions
+            // (two scores per v_cvt_pk_bf16_f32, whose result IS the store payload): ~10 VALU instructions per score
+            // instead of ~18 -- the epilogue is VALU-bound (128 scores per lane) and was 14 % of the kernel at d = 2048
 #pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            float v[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[j] = finish_score<bf16_t>(acc[m][n][j], temperature, inv_t, scale);
-                acc[m][n][j] = v[j];
-                if (pbase + 16 * m + j < P) mx = fmaxf(mx, v[j]);
-            }
-            if (staged) {
+            for (int m = 0; m < 8; ++m) {
                 uint2 w;
-                w.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                w.x = pack2_bf16(acc[m][n][0], acc[m][n][1]);               // the reference's bf16 matmul output
+                w.y = pack2_bf16(acc[m][n][2], acc[m][n][3]);
+                float x[4] = {__uint_as_float(w.x << 16), __uint_as_float(w.x & 0xffff0000u), __uint_as_float(w.y << 16),
+                              __uint_as_float(w.y & 0xffff0000u)};
+                if (scale) {                                                // x / T as finish_score computes it, then bf16
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float q0v = x[j] * inv_t;
+                        const float r = fmaf(-q0v, temperature, x[j]);
+                        x[j] = fmaf(r, inv_t, q0v);
+                    }
+                    w.x = pack2_bf16(x[0], x[1]);
+                    w.y = pack2_bf16(x[2], x[3]);
+                    x[0] = __uint_as_float(w.x << 16);
+                    x[1] = __uint_as_float(w.x & 0xffff0000u);
+                    x[2] = __uint_as_float(w.y << 16);
+                    x[3] = __uint_as_float(w.y & 0xffff0000u);
+                }
                 *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
-            } else if (qv && !(dbg & 1)) {
-                store_scores4<bf16_t>(scores + qi * P, pbase + 16 * m, P, v, vec_ok);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[m][n][j] = x[j];
+                mx = fmaxf(mx, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+            }
+            if (do_stats) {
+                const float ml = mx * RPO_LOG2E;
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sum += exp_sub(acc[m][n][j], ml);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = finish_score<bf16_t>(acc[m][n][j], temperature, inv_t, scale);
+                    acc[m][n][j] = v[j];
+                    if (pbase + 16 * m + j < P) mx = fmaxf(mx, v[j]);
+                }
+                if (staged) {
+                    uint2 w;
+                    w.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                    w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
+                } else if (qv && !(dbg & 1)) {
+                    store_scores4<bf16_t>(scores + qi * P, pbase + 16 * m, P, v, vec_ok);
+                }
+            }
+            if (do_stats) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (pbase + 16 * m + j < P) sum += exp_sub(acc[m][n][j], mx * RPO_LOG2E);
             }
         }
         if (do_stats) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (pbase + 16 * m + j < P) sum += exp_sub(acc[m][n][j], mx * RPO_LOG2E);
 #pragma unroll
             for (int o = 16; o <= 32; o <<= 1) {
                 const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
