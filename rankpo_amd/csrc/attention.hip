@@ -20,6 +20,32 @@ constexpr int kFaThreads = 256, kFaBM = 128, kFaBN = 64, kFaHD = 64;
 
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
+#ifndef RPO_FA_STAGE_POS
+#define RPO_FA_STAGE_POS 0      // where the forward kernel issues the LDS-DMA of tile kt + 2 (experiments: 1, 2)
+#endif
+
+#ifdef RPO_FA_STAMP   // diagnostic build only (tools/exp): in-kernel cycle stamps of a kernel's loop segments, summed per wave role
+                      // (-DRPO_FA_STAMP: the 8-wave dK/dV kernel; + -DRPO_FA_STAMP_FWD: the forward kernel instead)
+__device__ unsigned long long g_fa_stamp[8 * 8];
+#define RPO_STAMP(VAR)                                                                     \
+    do {                                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(VAR)::"memory");        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    } while (0)
+#define RPO_STAMP_ADD(I, A, B) st_acc[I] += (B) - (A)
+#else
+#define RPO_STAMP(VAR)
+#define RPO_STAMP_ADD(I, A, B)
+#endif
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+#define RPO_FSTAMP(VAR) RPO_STAMP(VAR)
+#define RPO_FSTAMP_ADD(I, A, B) RPO_STAMP_ADD(I, A, B)
+#else
+#define RPO_FSTAMP(VAR)
+#define RPO_FSTAMP_ADD(I, A, B)
+#endif
+
 
 // two f32 -> one dword of two bf16 (round to nearest even) in ONE instruction; written as `f32_to_bf16(a) | f32_to_bf16(b) << 16`
 // hipcc converts each value on its own and merges them with a third instruction.
@@ -150,12 +176,24 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     for (int ks = 0; ks < 2; ++ks) row_off[ks] = fr * 128 + (((4 * ks + g) ^ (fr & 7)) << 4);
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+    unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta, tb_, tc, td, te, tf, tg;
+#endif
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
+        RPO_FSTAMP(ta);
         if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile kt landed; tile kt + 1 may fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        RPO_FSTAMP(tb_);
         __builtin_amdgcn_s_barrier();
+        RPO_FSTAMP(tc);
+#if RPO_FA_STAGE_POS == 0
         if (kt + 2 < nkt) stage(kt + 2, cur == 0 ? 2 : cur - 1);               // the buffer read in iteration kt - 1
+#endif
+        RPO_FSTAMP(td);
+        RPO_FSTAMP_ADD(0, ta, tb_);
+        RPO_FSTAMP_ADD(1, tb_, tc);
+        RPO_FSTAMP_ADD(2, tc, td);
         // this wave's queries may all lie before this key tile (upper waves of the last tiles): nothing to do
         const bool active = (kt * kFaBN <= qw + 31) && (qw < len);
         if (active) {
@@ -185,6 +223,11 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                     for (int n = 0; n < 2; ++n) s[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[n][ks], s[m][n], 0, 0, 0);
                 }
             }
+            RPO_FSTAMP(te);
+            RPO_FSTAMP_ADD(3, td, te);
+#if RPO_FA_STAGE_POS == 1
+            if (kt + 2 < nkt) stage(kt + 2, cur == 0 ? 2 : cur - 1);           // behind the S MFMAs: their results are still in the pipe
+#endif
             // ---- causal / length mask (only tiles that touch the diagonal or the sequence end)
             const int kbase = kt * kFaBN + 4 * g;
             const bool need_mask = (kt * kFaBN + kFaBN - 1 > qw) || (kt * kFaBN + kFaBN > len);
@@ -205,14 +248,17 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
             float mnew[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float mx[4];
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    mx[m] = fmaxf(fmaxf(s[m][n][0], s[m][n][1]), fmaxf(s[m][n][2], s[m][n][3]));
-                float mm = fmaxf(fmaxf(mx[0], mx[1]), fmaxf(mx[2], mx[3]));
-                mm = fmaxf(mm, __shfl_xor(mm, 16, 64));
-                mm = fmaxf(mm, __shfl_xor(mm, 32, 64));
-                mnew[n] = fmaxf(mrun[n], mm);
+                float mm = max3_raw(s[0][n][0], s[0][n][1], s[0][n][2]);          // 16 scores of this lane: 8 v_max3_f32
+                mm = max3_raw(mm, s[0][n][3], s[1][n][0]);
+                mm = max3_raw(mm, s[1][n][1], s[1][n][2]);
+                mm = max3_raw(mm, s[1][n][3], s[2][n][0]);
+                mm = max3_raw(mm, s[2][n][1], s[2][n][2]);
+                mm = max3_raw(mm, s[2][n][3], s[3][n][0]);
+                mm = max3_raw(mm, s[3][n][1], s[3][n][2]);
+                mm = max2_raw(mm, s[3][n][3]);
+                mm = max2_raw(mm, __shfl_xor(mm, 16, 64));
+                mm = max3_raw(mm, __shfl_xor(mm, 32, 64), mrun[n]);
+                mnew[n] = mm;
             }
             // the running maximum rarely moves after the first tiles: skip the rescale of O (32 multiplies) when no lane's did
             if (__builtin_amdgcn_ballot_w64(mnew[0] != mrun[0] || mnew[1] != mrun[1]) != 0) {
@@ -245,6 +291,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                 pfrag[0][n] = pack_frag(s[0][n], s[1][n]);
                 pfrag[1][n] = pack_frag(s[2][n], s[3][n]);
             }
+            RPO_FSTAMP(tf);
+            RPO_FSTAMP_ADD(4, te, tf);
             // ---- O^T += V^T P^T   (A = V^T via the transposed LDS reads, same key order as the P fragments).
             // hipcc does not model inline-asm LDS reads: naming every destination in the wait keeps the MFMAs below it.
             asm volatile("s_waitcnt lgkmcnt(0)"
@@ -264,9 +312,27 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     oacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt1[c], pfrag[1][n], oacc[c][n], 0, 0, 0);
+            RPO_FSTAMP(tg);
+            RPO_FSTAMP_ADD(5, tf, tg);
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+            st_acc[6] += 1;
+#endif
         }
+#if RPO_FA_STAGE_POS == 1
+        else if (kt + 2 < nkt) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+#endif
+#if RPO_FA_STAGE_POS == 2
+        if (kt + 2 < nkt) stage(kt + 2, cur == 0 ? 2 : cur - 1);               // at the end of the iteration: the waves have drifted apart
+#endif
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+        st_acc[7] += 1;
+#endif
         cur = cur == 2 ? 0 : cur + 1;
     }
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_fa_stamp[wave * 8 + i], st_acc[i]);
+#endif
     // ---- epilogue: O[q][16c + 4g + r] = O^T / l ;  lse = scale m + ln l
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -533,19 +599,6 @@ constexpr int kDmaLds = 3 * kDmaTile;                             // 101376 B (o
                  : "v"(ADDR)                                                                                         \
                  : "memory")
 
-#ifdef RPO_FA_STAMP   // diagnostic build only (tools/exp): in-kernel cycle stamps of the dK/dV loop, summed per wave role
-__device__ unsigned long long g_fa_stamp[8 * 8];
-#define RPO_STAMP(VAR)                                                                     \
-    do {                                                                                   \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(VAR)::"memory");        \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-    } while (0)
-#define RPO_STAMP_ADD(I, A, B) st_acc[I] += (B) - (A)
-#else
-#define RPO_STAMP(VAR)
-#define RPO_STAMP_ADD(I, A, B)
-#endif
 
 __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,

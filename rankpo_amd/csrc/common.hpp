@@ -98,6 +98,21 @@ __device__ __forceinline__ bool rpo_aligned16_dev(const void* p) {
     return (reinterpret_cast<uintptr_t>(p) & 15) == 0;
 }
 
+// max of MFMA results without hipcc's canonicalising `v_max_f32 x, x, x` in front of every fmaxf operand (an MFMA output is
+// not known to be a quiet number to the compiler: 32 extra VALU instructions per key tile in the attention forward, 490 in
+// the 256 x 256 similarity kernel's epilogue).  NaN behaviour = the instruction's (IEEE maxNum: a quiet NaN operand is
+// ignored), the same as fmaxf.
+__device__ __forceinline__ float max3_raw(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max2_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // ---- wave / block reductions (64-wide waves) -----------------------------------------------------
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll

@@ -501,7 +501,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                 *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[m][n][j] = x[j];
-                mx = fmaxf(mx, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+                mx = max3_raw(max3_raw(mx, x[0], x[1]), x[2], x[3]);
             }
             if (do_stats) {
                 const float ml = mx * RPO_LOG2E;
