@@ -233,7 +233,7 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
                        int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
                        int64_t out_stride, float* lse, int64_t lse_max_len, rpo_stream_t stream);
 
-/* Backward of rpo_flash_attn_fwd (three launches, no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
+/* Backward of rpo_flash_attn_fwd (two launches: dQ, which also computes the row constants, then dK/dV; no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
  * forward with lse_max_len == 0; delta: f32 [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale, the initial accumulators of the dP and S chains).  q_tiles as in the
  * forward (q_tile_cols = its format); k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a key block); key_block = the number of
  * keys one entry stands for and thereby the dK/dV kernel that consumes the table: 256 (one wave per SIMD, entries dealt to

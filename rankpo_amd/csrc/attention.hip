@@ -354,9 +354,9 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Backward.  Three launches, no atomics, deterministic:
-//   fa_delta_kernel      delta[h][t] = sum_d dO[t,h,d] O[t,h,d]
-//   fa_bwd_dq_kernel     block = 128 queries of one (sequence, head), loop over key tiles <= diagonal:
+// Backward.  Two launches, no atomics, deterministic:
+//   fa_bwd_dq_kernel     block = 128 queries of one (sequence, head): delta[h][t] = sum_d dO[t,h,d] O[t,h,d] in the prologue,
+//                        then the loop over key tiles <= diagonal:
 //                        S^T = K Q^T, dP^T = V dO^T, dS^T = P (dP - delta) scale, dQ^T += K^T dS^T
 //                        (query on the lane: lse / delta are per-lane scalars; dS^T accumulators are the B fragments)
 //   fa_bwd_dkdv_kernel   block = 64 keys of one (sequence, kv head), loop over the q heads of the group and the query
@@ -365,34 +365,10 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 //                        images that serve the row reads (chunk ^= row & 7 is conflict-free for both kinds of read).
 // P is recomputed from the saved lse: P = exp(scale s - lse).
 // ------------------------------------------------------------------------------------------------------------------
-// Writes the two per-(head, query) row constants of the backward, NEGATED so that they can be the initial accumulators of the
-// S and dP MFMA chains:  nd[h][t] = -delta = -sum_d dO O   and   nl[h][t] = -lse / scale, so that S' = Q K^T - lse / scale
-// gives p = exp2(scale log2(e) S') with no subtraction, and dP' = dO V^T - delta is dS / (p scale) as it leaves the chain.
-__global__ __launch_bounds__(256) void fa_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout,
-                                                       int64_t so, int64_t sdo, int nh, int64_t T,
-                                                       const float* __restrict__ lse, float inv_scale,
-                                                       float* __restrict__ nd, float* __restrict__ nl) {
-    // one wave per (token, 8 heads): lane = (head in group of 8, 16-byte chunk)
-    const int64_t t = blockIdx.x;
-    for (int hc = threadIdx.x; hc < nh * 8; hc += 256) {
-        const int h = hc >> 3, ch = hc & 7;
-        Vec16<bf16_t> a, b;
-        a.load(o + t * so + h * kFaHD + ch * 8);
-        b.load(dout + t * sdo + h * kFaHD + ch * 8);
-        float acc = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc = fmaf(a.v[e], b.v[e], acc);
-        acc += __shfl_xor(acc, 1, 64);
-        acc += __shfl_xor(acc, 2, 64);
-        acc += __shfl_xor(acc, 4, 64);
-        if (ch == 0) {
-            nd[(int64_t)h * T + t] = -acc;
-            nl[(int64_t)h * T + t] = -lse[(int64_t)h * T + t] * inv_scale;
-        }
-    }
-}
-
-
+// The two per-(head, query) row constants of the backward, NEGATED so that they can be the initial accumulators of the S and dP
+// MFMA chains: nd[h][t] = -delta = -sum_d dO O and nl[h][t] = -lse / scale, so that S' = Q K^T - lse / scale gives
+// p = exp2(scale log2(e) S') with no subtraction, and dP' = dO V^T - delta is dS / (p scale) as it leaves the chain.  The dQ kernel
+// computes them in its prologue and writes them for the dK/dV kernel (round 1: a separate fa_delta_kernel, 0.32 ms per call).
 
 // K / V tiles: the same LDS-DMA ring as the forward kernel.
 constexpr int kDqTile = kKvTile;
@@ -401,7 +377,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
     const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e, float scale,
-    const float* __restrict__ lse, const float* __restrict__ delta, int64_t T, bf16_t* __restrict__ dq, int64_t sdq) {
+    const float* __restrict__ lse, const bf16_t* __restrict__ o, int64_t so, float* __restrict__ nl_out,
+    float* __restrict__ nd_out, int64_t T, bf16_t* __restrict__ dq, int64_t sdq) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kDqTile];      // ring of (K tile | V tile), chunk ^= row & 7
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -426,8 +403,27 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
             bdo[n][ks] = ok ? *reinterpret_cast<const short8_t*>(dout + (t0 + qi) * sdo + h * kFaHD + 32 * ks + 8 * g)
                             : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
-        lq[n] = ok ? lse[(int64_t)h * T + t0 + qi] : 0.f;      // -lse / scale (fa_delta_kernel)
-        dl[n] = ok ? delta[(int64_t)h * T + t0 + qi] : 0.f;    // -delta
+        // The two row constants of the backward, NEGATED (they are the initial accumulators of the S and dP chains):
+        // -lse / scale and -delta = -sum_d dO O.  Computed HERE (round 1 ran a separate fa_delta_kernel over O and dO: 0.32 ms
+        // per call): the block holds its dO fragments anyway, the O fragments are 4 more 16-byte loads per lane; lane (g, fr)
+        // sums its 16 hd columns of query fr, two shfl_xor finish the row.  Lane group 0 also writes both for the dK/dV kernel.
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const short8_t ov = ok ? *reinterpret_cast<const short8_t*>(o + (t0 + qi) * so + h * kFaHD + 32 * ks + 8 * g)
+                                   : short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                part = fmaf(bf16_to_f32((bf16_t)bdo[n][ks][e]), bf16_to_f32((bf16_t)ov[e]), part);
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        lq[n] = ok ? -lse[(int64_t)h * T + t0 + qi] / scale : 0.f;
+        dl[n] = ok ? -part : 0.f;
+        if (ok && g == 0) {
+            nl_out[(int64_t)h * T + t0 + qi] = lq[n];
+            nd_out[(int64_t)h * T + t0 + qi] = dl[n];
+        }
     }
     const int last_q = min(q0 + kFaBM - 1, len - 1);
     const int nkt = last_q / kFaBN + 1;
@@ -2236,15 +2232,12 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     const float log2e = 1.4426950408889634f;
     float* nd = delta;                                       // scratch [2][num_heads][T]: -delta | -lse / scale
     float* nl = delta + num_heads * total_tokens;
-    RPO_LAUNCH(fa_delta_kernel, dim3((unsigned)total_tokens), dim3(256), 0, st, (const bf16_t*)out, (const bf16_t*)dout,
-               out_stride, dout_stride, (int)num_heads, total_tokens, lse, 1.0f / scale, nd, nl);
-    int rc = rpo_launch_status();
-    if (rc != RPO_OK) return rc;
+    // (round 1 launched fa_delta_kernel here; the dQ kernel now computes and writes both row constants itself)
     RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0,
                st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
-               dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd,
-               total_tokens, (bf16_t*)dq, dq_stride);
-    rc = rpo_launch_status();
+               dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse,
+               (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride);
+    int rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
     const unsigned dkdv_grid = (unsigned)(((n_k_tiles + 7) / 8) * 8);
     const bool use_v1 = key_block == 64;
