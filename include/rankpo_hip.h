@@ -214,9 +214,9 @@ int rpo_add_rmsnorm_fwd(const void* x, const void* delta, const void* weight, fl
 int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, const float* rstd, const void* dres,
                         void* dx_out, float* dw_partial, int64_t rows, int64_t d, int dtype, rpo_stream_t stream);
 
-/* Causal variable-length flash attention, forward, head_dim 64, bf16, grouped-query heads (encoder side; the packed
- * encoder path of rankpo_amd/encoder.py).  q: [T, num_heads, 64] with token stride q_stride elements (heads contiguous),
- * k / v: [T, num_kv_heads, 64] likewise (all three may be views of one fused projection output).  cu_seqlens: int32
+/* Causal variable-length flash attention, forward, head_dim 64 or 128, bf16, grouped-query heads (encoder side; the packed
+ * encoder path of rankpo_amd/encoder.py).  q: [T, num_heads, hd] with token stride q_stride elements (heads contiguous),
+ * k / v: [T, num_kv_heads, hd] likewise (all three may be views of one fused projection output).  cu_seqlens: int32
  * [N + 1].  tiles = the query-tile work list, one entry per block of 128 queries, in the format tile_cols names:
  *   2: int32 [ntiles][2] = (sequence id, first query row inside the sequence), heaviest first; one launch block per
  *      (entry, head);
@@ -224,7 +224,7 @@ int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, c
  *      (b % 8) * ntiles / 8 + b / 8, so the blocks that share an XCD walk one eighth of the list in order; the caller puts
  *      all entries of one (sequence, kv head) next to each other in one eighth (their K / V then stay in that XCD's L2);
  *      entries whose first query row is >= 2^30 are padding.
- * out: [T, num_heads * 64] (token stride out_stride), lse = log sum_j exp(scale * <q_i, k_j>)
+ * out: [T, num_heads * hd] (token stride out_stride), lse = log sum_j exp(scale * <q_i, k_j>)
  * over the keys j <= i of the same sequence, f32, laid out [num_heads][T] when lse_max_len == 0 or padded
  * [N][num_heads][lse_max_len] (the layout PyTorch's flash-attention backward reads) when lse_max_len > 0. */
 int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
@@ -233,7 +233,8 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
                        int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
                        int64_t out_stride, float* lse, int64_t lse_max_len, rpo_stream_t stream);
 
-/* Backward of rpo_flash_attn_fwd (two launches: dQ, which also computes the row constants, then dK/dV; no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
+/* Backward of rpo_flash_attn_fwd, head_dim 64 only (head_dim 128: RPO_ERR_UNSUPPORTED; the host side pairs the 128
+ * forward with PyTorch's flash-attention backward on the saved output / lse) (two launches: dQ, which also computes the row constants, then dK/dV; no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
  * forward with lse_max_len == 0; delta: f32 [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale, the initial accumulators of the dP and S chains).  q_tiles as in the
  * forward (q_tile_cols = its format); k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a key block); key_block = the number of
  * keys one entry stands for and thereby the dK/dV kernel that consumes the table: 256 (one wave per SIMD, entries dealt to

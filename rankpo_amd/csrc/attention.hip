@@ -354,6 +354,219 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// head_dim 128 (the Llama-3-8B architecture, BASELINE configs[4]): the same forward with the tile re-proportioned so that the
+// LDS ring, the DMA count and the MFMAs per barrier stay what they are at head_dim 64 -- key tiles of 32 (32 keys x 256 B =
+// the same 8 KiB image as 64 keys x 128 B), 4 k-steps for S^T = K Q^T (16 MFMAs), 8 hd tiles for O^T = V^T P^T (16 MFMAs), half
+// the softmax arithmetic per MFMA.  LDS rows are 256 bytes = the whole bank width, so the swizzle is chunk ^= 2 (row & 7):
+// conflict-free for the ds_read_b128 row reads of K (16 rows x one chunk) AND for the ds_read_b64_tr_b16 reads of V^T
+// (8 rows x 32 bytes per half-wave), checked by enumeration.  A 1-KiB DMA piece is 4 rows.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kFa128HD = 128, kFa128BN = 32, kFa128Row = 256;
+
+__global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
+    int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
+    float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
+    int64_t lse_head_stride, int lse_packed) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * kKvTile];       // ring of (K tile | V tile), 256-byte rows, 32 keys
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, fr = lane & 15;
+    const FaTile ft = fa_tile(tiles, tcols);
+    if (ft.q0 >= (1 << 30)) return;
+    const int seq = ft.seq, q0 = ft.q0;
+    const int h = ft.h, hk = h / (nh / nkv);
+    const int64_t t0 = cu[seq];
+    const int len = cu[seq + 1] - (int)t0;
+    const int qw = q0 + 32 * wave;
+
+    short8_t bq[2][4];                                   // Q^T fragments: lane = query fr of tile n, k = hd 32 ks + 8 g .. + 7
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int qi = qw + 16 * n + fr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (qi < len) bq[n][ks] = *reinterpret_cast<const short8_t*>(q + (t0 + qi) * sq + h * kFa128HD + 32 * ks + 8 * g);
+            else bq[n][ks] = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+    const int last_q = min(q0 + kFaBM - 1, len - 1);
+    const int nkt = last_q / kFa128BN + 1;
+    // staging: DMA instruction u = 2 * wave + i fills tile rows 4u .. 4u + 3 of K and of V; lane l carries row 4u + (l >> 4),
+    // physical chunk l & 15 = logical chunk (l & 15) ^ 2 (row & 7)
+    const int srow = lane >> 4;
+    const char* ksrc = reinterpret_cast<const char*>(k + t0 * sk + hk * kFa128HD);
+    const char* vsrc = reinterpret_cast<const char*>(v + t0 * sv + hk * kFa128HD);
+    const unsigned skb = (unsigned)sk * 2u, svb = (unsigned)sv * 2u;
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * kKvTile;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = 2 * wave + i;
+            const int trow = 4 * u + srow;                                         // tile row 0 .. 31
+            const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
+            const unsigned row = (unsigned)min(kt * kFa128BN + trow, len - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + (row * skb + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + (row * svb + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + kFa128BN * kFa128Row + u * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(bq[n][ks]));
+
+    float4_t oacc[8][2];                                 // O^T: [hd tile c][query tile n], rows = hd 16c + 4g + r
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) oacc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+
+    // K row reads: row 16 m + fr, chunk (4 ks + g) ^ 2 (fr & 7).  V transposed reads: lane (g, qq, pp) addresses row 16 h + 4 g + qq,
+    // hd columns 16 c + 4 pp .. + 3 = chunk (2 c + (pp >> 1)) ^ 2 (4 (g & 1) + qq), byte 8 (pp & 1) inside it; h = immediate 4096.
+    const int qq = fr >> 2, pp = fr & 3;
+    const int vsw = 2 * (4 * (g & 1) + qq);
+    unsigned tr_off[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        tr_off[c] = kFa128BN * kFa128Row + (4 * g + qq) * kFa128Row + (((2 * c + (pp >> 1)) ^ vsw) << 4) + 8 * (pp & 1);
+    unsigned row_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) row_off[ks] = fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+        const bool active = (kt * kFa128BN <= qw + 31) && (qw < len);
+        if (active) {
+            const char* Ks = smem + cur * kKvTile;
+            const unsigned tb = smem_base + cur * kKvTile;
+            // V^T fragments of the 32 keys: x[c] = keys 4g .. 4g + 3 of rows 0-15, y[c] = of rows 16-31, for hd tile c
+            u32x2 x0, x1, x2, x3, x4, x5, x6, x7, y0, y1, y2, y3, y4, y5, y6, y7;
+#define RPO_TR2V(OUT0, OUT1, ADDR)                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=&v"(OUT0), "=&v"(OUT1) : "v"(ADDR) : "memory")
+            RPO_TR2V(x0, y0, tb + tr_off[0]);
+            RPO_TR2V(x1, y1, tb + tr_off[1]);
+            RPO_TR2V(x2, y2, tb + tr_off[2]);
+            RPO_TR2V(x3, y3, tb + tr_off[3]);
+            RPO_TR2V(x4, y4, tb + tr_off[4]);
+            RPO_TR2V(x5, y5, tb + tr_off[5]);
+            RPO_TR2V(x6, y6, tb + tr_off[6]);
+            RPO_TR2V(x7, y7, tb + tr_off[7]);
+#undef RPO_TR2V
+            // ---- S^T = K Q^T: 2 key sub-tiles x 2 query tiles, 4 k-steps
+            float4_t s[2][2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) s[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const short8_t a = *reinterpret_cast<const short8_t*>(Ks + row_off[ks] + m * 16 * kFa128Row);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) s[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[n][ks], s[m][n], 0, 0, 0);
+                }
+            }
+            const int kbase = kt * kFa128BN + 4 * g;
+            const bool need_mask = (kt * kFa128BN + kFa128BN - 1 > qw) || (kt * kFa128BN + kFa128BN > len);
+            if (need_mask) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int qi = qw + 16 * n + fr;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = kbase + 16 * m + r;
+                            if (key > qi || key >= len) s[m][n][r] = -1e30f;
+                        }
+                }
+            }
+            float mnew[2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                float mm = max3_raw(s[0][n][0], s[0][n][1], s[0][n][2]);
+                mm = max3_raw(mm, s[0][n][3], s[1][n][0]);
+                mm = max3_raw(mm, s[1][n][1], s[1][n][2]);
+                mm = max2_raw(mm, s[1][n][3]);
+                mm = max2_raw(mm, __shfl_xor(mm, 16, 64));
+                mm = max3_raw(mm, __shfl_xor(mm, 32, 64), mrun[n]);
+                mnew[n] = mm;
+            }
+            if (__builtin_amdgcn_ballot_w64(mnew[0] != mrun[0] || mnew[1] != mrun[1]) != 0) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const float alpha = __builtin_amdgcn_exp2f((mrun[n] - mnew[n]) * scale_log2e);
+                    lrun[n] *= alpha;
+                    mrun[n] = mnew[n];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) oacc[c][n] *= alpha;
+                }
+            }
+            short8_t pfrag[2];                           // [query tile n]: k-slots = keys {4g + j, 16 + 4g + (j - 4)} of the tile
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const float mls = mnew[n] * scale_log2e;
+                float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -mls));
+                        s[m][n][r] = pv;
+                        sum[r] += pv;
+                    }
+                float st = (sum[0] + sum[1]) + (sum[2] + sum[3]);
+                st += __shfl_xor(st, 16, 64);
+                st += __shfl_xor(st, 32, 64);
+                lrun[n] += st;
+                pfrag[n] = pack_frag(s[0][n], s[1][n]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(y0),
+                           "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7)
+                         :
+                         : "memory");
+            const short8_t vt[8] = {join_tr(x0, y0), join_tr(x1, y1), join_tr(x2, y2), join_tr(x3, y3),
+                                    join_tr(x4, y4), join_tr(x5, y5), join_tr(x6, y6), join_tr(x7, y7)};
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    oacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[c], pfrag[n], oacc[c][n], 0, 0, 0);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int qi = qw + 16 * n + fr;
+        if (qi >= len) continue;
+        const float inv = 1.0f / lrun[n];
+        bf16_t* orow = o + (t0 + qi) * so + h * kFa128HD;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint2 w;
+            w.x = pack_bf16(oacc[c][n][0] * inv, oacc[c][n][1] * inv);
+            w.y = pack_bf16(oacc[c][n][2] * inv, oacc[c][n][3] * inv);
+            *reinterpret_cast<uint2*>(orow + 16 * c + 4 * g) = w;
+        }
+        if (g == 0)
+            lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
+                mrun[n] * scale + logf(lrun[n]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Backward.  Two launches, no atomics, deterministic:
 //   fa_bwd_dq_kernel     block = 128 queries of one (sequence, head): delta[h][t] = sum_d dO[t,h,d] O[t,h,d] in the prologue,
 //                        then the loop over key tiles <= diagonal:
@@ -2192,19 +2405,25 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
     if (!q || !k || !v || !cu_seqlens || !tiles || !out || !lse || ntiles <= 0 || total_tokens <= 0)
         return RPO_ERR_INVALID_ARG;
     if (!(tile_cols == 2 || (tile_cols == 3 && ntiles % 8 == 0))) return RPO_ERR_UNSUPPORTED;
-    if (head_dim != kFaHD || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 || num_heads > 65535)
+    if ((head_dim != kFaHD && head_dim != kFa128HD) || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 ||
+        num_heads > 65535)
         return RPO_ERR_UNSUPPORTED;
     if (q_stride % 8 || k_stride % 8 || v_stride % 8 || out_stride % 4 || !rpo_aligned16(q) || !rpo_aligned16(k) ||
         !rpo_aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7))
         return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const float log2e = 1.4426950408889634f;
-    RPO_LAUNCH(fa_fwd_kernel, dim3((unsigned)ntiles, tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0, st,
-               (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride, k_stride, v_stride, cu_seqlens, tiles,
-               (int)tile_cols, (int)num_heads,
-               (int)num_kv_heads, scale * log2e, scale, (bf16_t*)out, out_stride, lse,
-               lse_max_len > 0 ? num_heads * lse_max_len : 0, lse_max_len > 0 ? lse_max_len : total_tokens,
-               lse_max_len > 0 ? 0 : 1);
+    const dim3 grid((unsigned)ntiles, tile_cols == 3 ? 1u : (unsigned)num_heads);
+    if (head_dim == kFa128HD)
+        RPO_LAUNCH(fa_fwd128_kernel, grid, dim3(kFaThreads), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
+                   k_stride, v_stride, cu_seqlens, tiles, (int)tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,
+                   (bf16_t*)out, out_stride, lse, lse_max_len > 0 ? num_heads * lse_max_len : 0,
+                   lse_max_len > 0 ? lse_max_len : total_tokens, lse_max_len > 0 ? 0 : 1);
+    else
+        RPO_LAUNCH(fa_fwd_kernel, grid, dim3(kFaThreads), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
+                   k_stride, v_stride, cu_seqlens, tiles, (int)tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,
+                   (bf16_t*)out, out_stride, lse, lse_max_len > 0 ? num_heads * lse_max_len : 0,
+                   lse_max_len > 0 ? lse_max_len : total_tokens, lse_max_len > 0 ? 0 : 1);
     return rpo_launch_status();
 }
 

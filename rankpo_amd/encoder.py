@@ -179,10 +179,11 @@ class VarlenCtx:
 
 def _varlen_causal_attention(q, k, v, ctx: VarlenCtx):
     """q [T, nh, hd], k/v [T, nkv, hd] packed; causal attention inside each sequence."""
-    if q.is_cuda and q.dtype == torch.bfloat16 and q.shape[-1] == 64 and ctx.tiles is not None:
-        # hand-written HIP kernel (head_dim 64): 2.2x the AOTriton varlen forward on the cfg-2 passage shape
+    if q.is_cuda and q.dtype == torch.bfloat16 and q.shape[-1] in (64, 128) and ctx.tiles is not None:
+        # hand-written HIP kernels: forward for head_dim 64 and 128; backward for 64 (k_tiles given), else PyTorch's
+        # flash-attention backward on the saved (out, padded lse)
         return _ops.flash_attn_varlen(q, k, v, ctx.cu, ctx.tiles, ctx.max_len, 1.0 / math.sqrt(q.shape[-1]),
-                                      k_tiles=ctx.k_tiles)
+                                      k_tiles=ctx.k_tiles if q.shape[-1] == 64 else None)
     if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16):
         return torch.ops.aten._flash_attention_forward(q, k, v, ctx.cu, ctx.cu, ctx.max_len, ctx.max_len, 0.0, True,
                                                        False)[0]
@@ -520,9 +521,9 @@ class LlamaEncoder(nn.Module):
         cu = torch.zeros(N + 1, dtype=torch.int32, device=x.device)
         cu[1:] = torch.tensor(lens, dtype=torch.int64).cumsum(0).to(torch.int32).to(x.device, non_blocking=True)
         tiles = k_tiles = None
-        if x.is_cuda and self.config.head_dim == 64 and x.dtype == torch.bfloat16:     # hand-written flash attention
+        if x.is_cuda and self.config.head_dim in (64, 128) and x.dtype == torch.bfloat16:     # hand-written flash attention
             tiles = _ops.attn_tile_table(lens, x.device, self.config.num_attention_heads, self.config.num_key_value_heads)
-            if torch.is_grad_enabled():
+            if torch.is_grad_enabled() and self.config.head_dim == 64:
                 k_tiles = _ops.attn_key_tile_table(lens, x.device, self.config.num_key_value_heads)
         ctx = VarlenCtx(cu, lens, max(lens), tiles, k_tiles)
         last_idx = (cu[1:] - 1).to(torch.int64)

@@ -546,13 +546,14 @@ def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, blo
 
 
 def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0):
-    """q [T, nh, 64], k / v [T, nkv, 64] (last two dims contiguous, token stride free); returns (out [T, nh, 64] bf16,
-    lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0)."""
+    """q [T, nh, hd], k / v [T, nkv, hd], hd = 64 or 128 (last two dims contiguous, token stride free); returns
+    (out [T, nh, hd] bf16, lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0)."""
     lib = _lib.load()
     T, nh, hd = q.shape
     nkv = k.shape[1]
-    if q.dtype != torch.bfloat16 or hd != 64 or q.stride(2) != 1 or q.stride(1) != hd or k.stride(1) != hd or v.stride(1) != hd:
-        raise ValueError("flash_attn_varlen_fwd: bf16, head_dim 64, heads contiguous inside a token row")
+    if (q.dtype != torch.bfloat16 or hd not in (64, 128) or q.stride(2) != 1 or q.stride(1) != hd or k.stride(1) != hd
+            or v.stride(1) != hd):
+        raise ValueError("flash_attn_varlen_fwd: bf16, head_dim 64 or 128, heads contiguous inside a token row")
     out = torch.empty((T, nh, hd), dtype=q.dtype, device=q.device)
     if padded_lse_len > 0:
         lse = torch.zeros((num_seqs, nh, padded_lse_len), dtype=torch.float32, device=q.device)

@@ -233,3 +233,76 @@ def test_xcd_dealt_tile_list_is_only_a_schedule():
         assert all(torch.equal(a, b) for a, b in zip(g2, g3))
     with pytest.raises(RankPOHipError, match="status -2"):
         ops.flash_attn_varlen_fwd(q, k, v, cu, t3[:-1], 0.125)          # a 3-column list must have a multiple of 8 entries
+
+
+@pytest.mark.parametrize("lens,nh,nkv,fused", [
+    ([128], 2, 2, False), ([64, 1, 200, 129, 33, 31, 32], 8, 2, False), ([300, 17, 513, 128, 256, 5], 8, 2, True),
+    ([1000, 777], 4, 1, True)])
+def test_flash_attn_fwd_head_dim_128(lens, nh, nkv, fused):
+    """head_dim 128 (Llama-3-8B architecture, BASELINE configs[4]): forward kernel with 32-key tiles and 256-byte LDS rows
+    against the f32 reference (output, lse), the padded-lse layout, PyTorch's own flash attention, and the autograd path
+    (HIP forward + PyTorch's flash-attention backward on the saved output / lse)."""
+    from rankpo_amd import ops
+    torch.manual_seed(sum(lens) + 1)
+    T, hd = sum(lens), 128
+    if fused:
+        qkv = torch.randn(T, (nh + 2 * nkv) * hd, device=DEV).to(torch.bfloat16)
+        q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], -1)
+        q, k, v = q.view(T, nh, hd), k.view(T, nkv, hd), v.view(T, nkv, hd)
+    else:
+        q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+        k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+        v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    scale = 1.0 / math.sqrt(hd)
+    ro, rl = ref_attention(q, k, v, lens, scale)
+    for tiles in (ops.attn_tile_table(lens, DEV), ops.attn_tile_table(lens, DEV, nh, nkv)):
+        out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale)
+        assert (out.float() - ro).abs().max() < 2.5e-2
+        assert (lse - rl).abs().max() < 2e-3
+    _, lp = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=max(lens), num_seqs=len(lens))
+    o0 = 0
+    for i, n in enumerate(lens):
+        assert torch.equal(lp[i, :, :n], lse[:, o0:o0 + n])
+        o0 += n
+    po = torch.ops.aten._flash_attention_forward(q.contiguous(), k.contiguous(), v.contiguous(), cu, cu, max(lens),
+                                                 max(lens), 0.0, True, False, scale=scale)[0]
+    assert (out.float() - po.float()).abs().max() < 2.5e-2
+    qa, ka, va = (t.detach().clone().requires_grad_(True) for t in (q.contiguous(), k.contiguous(), v.contiguous()))
+    oa = ops.flash_attn_varlen(qa, ka, va, cu, tiles, max(lens), scale)
+    go = torch.randn_like(oa)
+    oa.backward(go)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    ref_attention(qr, kr, vr, lens, scale)[0].backward(go.float())
+    for a, b in ((qa.grad, qr.grad), (ka.grad, kr.grad), (va.grad, vr.grad)):
+        assert (a.float() - b).abs().max() < 0.03 * max(1.0, b.abs().max().item())
+
+
+def test_flash_attn_fwd128_speed_report():
+    """Prints the head_dim-128 forward rate next to AOTriton's varlen kernel on a cfg-5-like passage batch (not a gate)."""
+    from rankpo_amd import ops
+    torch.manual_seed(0)
+    nh, nkv, hd, N, L = 32, 8, 128, 24, 4096
+    lens = torch.randint(L // 2, L + 1, (N,)); lens[0] = L
+    lens = lens.tolist(); T = sum(lens)
+    q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+    k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+    v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    tiles = ops.attn_tile_table(lens, DEV, nh, nkv)
+    scale = 1.0 / math.sqrt(hd)
+
+    def bench(fn, n=10):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+    ours = bench(lambda: ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale))
+    theirs = bench(lambda: torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False))
+    fl = sum(4 * nh * hd * n * (n + 1) / 2 for n in lens)
+    print(f"\\nflash fwd head_dim 128, {N} sequences: HIP {ours:.2f} ms = {fl / ours / 1e9:.0f} TFLOP/s ; AOTriton {theirs:.2f} ms = {fl / theirs / 1e9:.0f} TFLOP/s")
+    a = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale)[0]
+    b = torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False)[0]
+    assert (a.float() - b.float()).abs().max() < 2.5e-2

@@ -415,3 +415,36 @@ def test_transpose_and_mixed_layout_wgrad(dtype):
             got, ref = ops.wgrad(dy, x), dy.float().t() @ x.float()
             assert got.shape == (n, k) and got.is_contiguous()
             assert (got.float() - ref).abs().max() <= 2.0 ** -7 * ref.abs().max() + 1e-3
+
+
+def test_head_dim_128_packed_training_step_vs_oracle():
+    """Llama-3-8B-style head (head_dim 128, GQA) through the packed encoder path: hand-written forward attention
+    (fa_fwd128_kernel) + PyTorch's flash-attention backward on its saved output / lse; loss, scores and an embedding gradient
+    against the float32 oracle with the bf16 tolerances of the other encoder tests."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE, ops
+    torch.manual_seed(21)
+    cfg = PE.llama_config(vocab_size=512, hidden_size=512, intermediate_size=1024, num_hidden_layers=3,
+                          num_attention_heads=4, num_key_value_heads=2, head_dim=128, pad_token_id=0)
+    enc = PE.LlamaEncoder(cfg)
+    w = {k: v.detach().clone().requires_grad_(True) for k, v in E.state_dict_to_f32(enc).items()}
+    rs = np.random.RandomState(22)
+    qi, qm = _batch(rs, 4, 70, 512)
+    pi, pm = _batch(rs, 12, 150, 512)
+    cb = {"query": {"input_ids": qi, "attention_mask": qm}, "passage": {"input_ids": pi, "attention_mask": pm}}
+    ref_loss, ref_s, _, _ = E.contrastive_step(w, cfg.to_dict(), cb, 0.02)
+    ref_loss.backward()
+    calls = []
+    real = ops.flash_attn_varlen_fwd
+    ops.flash_attn_varlen_fwd = lambda q, *a, **kw: (calls.append(q.shape[-1]), real(q, *a, **kw))[1]
+    try:
+        model = rankpo_amd.ModelForTraining(encoder=enc.to(DEV).to(torch.bfloat16), temperature=0.02).train()
+        out = model(**{k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in cb.items()})
+        out.loss.backward()
+    finally:
+        ops.flash_attn_varlen_fwd = real
+    assert calls and all(c == 128 for c in calls)                        # the head_dim-128 HIP forward ran in every full block
+    assert (out.scores.float().cpu() * 0.02 - ref_s.detach() * 0.02).abs().max() < 2e-2      # cosines
+    assert abs(out.loss.item() - ref_loss.item()) < 0.25 * max(1.0, abs(ref_loss.item()))
+    g, gr = model.model.embed_tokens.weight.grad.float().cpu(), w["embed_tokens.weight"].grad
+    assert torch.isfinite(g).all() and (g - gr).norm() / gr.norm() < 0.1
