@@ -7,7 +7,7 @@ import sys
 
 OURS = ("pool_normalize", "sim_tile", "sim_skinny", "sim_rowwise", "ce_finalize", "first_finalize", "infonce_",
         "grouped_dots", "rankpo_", "adamw_kernel", "sumsq_kernel", "zero_fill", "rmsnorm", "swiglu", "rope_", "fa_",
-        "topk_", "wgrad_")
+        "topk_", "wgrad_", "transpose_kernel", "sim_small")
 
 
 def short(name):
