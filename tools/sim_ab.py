@@ -6,10 +6,11 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from rankpo_amd import _lib
 libs = {"in-tree": _lib.load()}
-other = C.CDLL(os.path.abspath(sys.argv[1]))
-for name in ("rpo_infonce_fwd", "rpo_infonce_workspace_bytes"):
-    getattr(other, name).restype, getattr(other, name).argtypes = _lib.SIGNATURES[name]
-libs[os.path.basename(sys.argv[1])] = other
+for path in sys.argv[1:]:
+    other = C.CDLL(os.path.abspath(path))
+    for name in ("rpo_infonce_fwd", "rpo_infonce_workspace_bytes"):
+        getattr(other, name).restype, getattr(other, name).argtypes = _lib.SIGNATURES[name]
+    libs[os.path.basename(path)] = other
 dev = "cuda:0"; st = torch.cuda.current_stream().cuda_stream
 shapes = [tuple(int(x) for x in s.split("x")) for s in os.environ.get("SHAPES", "16384x16384x2048,8192x8192x2048,4096x4096x4096").split(",")]
 for Q, P, d in shapes:
@@ -35,7 +36,7 @@ for Q, P, d in shapes:
             e1.record(); torch.cuda.synchronize()
             res[n].append(e0.elapsed_time(e1) / reps)
     names = list(libs)
-    same = all(torch.equal(a, b) for a, b in zip(out[names[0]], out[names[1]]))
+    same = all(torch.equal(a, b) for n in names[1:] for a, b in zip(out[names[0]], out[n]))
     for n, ts in res.items():
         ts.sort(); m = ts[len(ts) // 2]
         print(f"{Q}x{P}x{d} {n}: median {m*1e3:.1f} us (min {ts[0]*1e3:.1f}) = {2.0*Q*P*d/m/1e9:.0f} TFLOP/s = {2.0*Q*P*d/m/1e9/2500:.3f} of peak", flush=True)
