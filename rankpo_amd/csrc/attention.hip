@@ -2399,6 +2399,611 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// head_dim 128 backward (round 2; the Llama-3-8B architecture, BASELINE configs[4]).  Same two-launch, atomic-free scheme as at
+// head_dim 64, on the forward's 256-byte LDS rows (chunk ^= 2 (row & 7), 1-KiB DMA piece = 4 rows):
+//   fa_bwd_dq128_kernel    block = 128 queries of one (sequence, head), key tiles of 32 (the forward's (K | V) ring):
+//                          S^T = K Q'^T - lse log2(e) (Q' = Q scale log2(e), re-rounded once per block), dP^T = V dO^T - delta,
+//                          dS^T = exp2(S^T) dP^T, dQ^T += K^T dS^T (K^T by transposed reads of the SAME K image); 48 MFMAs per tile.
+//                          Prologue: delta and the two row constants, written for the dK/dV kernel.
+//   fa_bwd_dkdv128_kernel  block = 4 waves = 128 keys of one (sequence, kv head), ONE wave per SIMD: wave w owns keys
+//                          [32 w, 32 w + 32) -- K' = K scale log2(e) and V fragments (64 registers) and the dK^T / dV^T
+//                          accumulators (128) never leave the register file, no cross-wave sum -- and the block sweeps the
+//                          group's q heads x 32-row query slices (Q | dO | 64 row constants = 16.25 KiB by LDS-DMA, ring of 3):
+//                          S = Q K'^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS; 64 MFMAs per slice and wave.
+// Both are hipcc-scheduled (no hand-placed stream): 2.0x PyTorch's op on cfg 5's shape, see DESIGN.md.
+// ------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
+    const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e, float scale,
+    const float* __restrict__ lse, const bf16_t* __restrict__ o, int64_t so, float* __restrict__ nl_out,
+    float* __restrict__ nd_out, int64_t T, bf16_t* __restrict__ dq, int64_t sdq) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * kKvTile];      // ring of (K tile | V tile), 256-byte rows, 32 keys
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, fr = lane & 15;
+    const FaTile ft = fa_tile(tiles, tcols);
+    if (ft.q0 >= (1 << 30)) return;
+    const int seq = ft.seq, q0 = ft.q0;
+    const int h = ft.h, hk = h / (nh / nkv);
+    const int64_t t0 = cu[seq];
+    const int len = cu[seq + 1] - (int)t0;
+    const int qw = q0 + 32 * wave;
+    short8_t bq[2][4], bdo[2][4];
+    float lq[2], dl[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int qi = qw + 16 * n + fr;
+        const bool ok = qi < len;
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int64_t col = h * kFa128HD + 32 * ks + 8 * g;
+            const short8_t z = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            bq[n][ks] = ok ? *reinterpret_cast<const short8_t*>(q + (t0 + qi) * sq + col) : z;
+            bdo[n][ks] = ok ? *reinterpret_cast<const short8_t*>(dout + (t0 + qi) * sdo + col) : z;
+            const short8_t ov = ok ? *reinterpret_cast<const short8_t*>(o + (t0 + qi) * so + col) : z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                part = fmaf(bf16_to_f32((bf16_t)bdo[n][ks][e]), bf16_to_f32((bf16_t)ov[e]), part);
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        const float lse_q = ok ? lse[(int64_t)h * T + t0 + qi] : 0.f;
+        lq[n] = -lse_q * 1.44269504088896f;
+        dl[n] = ok ? -part : 0.f;
+        if (ok && g == 0) {
+            nl_out[(int64_t)h * T + t0 + qi] = lq[n];                       // head_dim 128: -lse log2(e) (dK/dV scales K, not S)
+            nd_out[(int64_t)h * T + t0 + qi] = dl[n];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const unsigned w = pack_bf16(bf16_to_f32((bf16_t)bq[n][ks][e]) * scale_log2e,
+                                             bf16_to_f32((bf16_t)bq[n][ks][e + 1]) * scale_log2e);
+                bq[n][ks][e] = (short)(w & 0xffff);
+                bq[n][ks][e + 1] = (short)(w >> 16);
+            }
+    }
+    const int last_q = min(q0 + kFaBM - 1, len - 1);
+    const int nkt = last_q / kFa128BN + 1;
+    const int srow = lane >> 4;
+    const char* ksrc = reinterpret_cast<const char*>(k + t0 * sk + hk * kFa128HD);
+    const char* vsrc = reinterpret_cast<const char*>(v + t0 * sv + hk * kFa128HD);
+    const unsigned skb = (unsigned)sk * 2u, svb = (unsigned)sv * 2u;
+    auto stage = [&](int kt, int buf) {
+        char* base = smem + buf * kKvTile;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = 2 * wave + i;
+            const int trow = 4 * u + srow;
+            const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
+            const unsigned row = (unsigned)min(kt * kFa128BN + trow, len - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + (row * skb + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + (row * svb + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + kFa128BN * kFa128Row + u * 1024), 16, 0, 0);
+        }
+    };
+    stage(0, 0);
+    if (nkt > 1) stage(1, 1);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(bq[n][ks]), "+v"(bdo[n][ks]));
+        asm volatile("" : "+v"(lq[n]), "+v"(dl[n]));
+    }
+    float4_t acc[8][2];                                  // dQ^T: [hd tile c][query tile n], rows = hd 16c + 4g + r
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+    const int qq = fr >> 2, pp = fr & 3;
+    const int vsw = 2 * (4 * (g & 1) + qq);
+    unsigned tr_off[8];                                  // K^T: the forward's V^T addressing on the K image
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        tr_off[c] = (4 * g + qq) * kFa128Row + (((2 * c + (pp >> 1)) ^ vsw) << 4) + 8 * (pp & 1);
+    unsigned row_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) row_off[ks] = fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+#define RPO_TR2H(OUT0, OUT1, ADDR)                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=&v"(OUT0), "=&v"(OUT1) : "v"(ADDR) : "memory")
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 2 < nkt) stage(kt + 2, cur == 0 ? 2 : cur - 1);
+        const bool active = (kt * kFa128BN <= qw + 31) && (qw < len);
+        if (active) {
+            const char* Ks = smem + cur * kKvTile;
+            const char* Vs = Ks + kFa128BN * kFa128Row;
+            const unsigned tb = smem_base + cur * kKvTile;
+            u32x2 x0, x1, x2, x3, x4, x5, x6, x7, y0, y1, y2, y3, y4, y5, y6, y7;
+            RPO_TR2H(x0, y0, tb + tr_off[0]);
+            RPO_TR2H(x1, y1, tb + tr_off[1]);
+            RPO_TR2H(x2, y2, tb + tr_off[2]);
+            RPO_TR2H(x3, y3, tb + tr_off[3]);
+            RPO_TR2H(x4, y4, tb + tr_off[4]);
+            RPO_TR2H(x5, y5, tb + tr_off[5]);
+            RPO_TR2H(x6, y6, tb + tr_off[6]);
+            RPO_TR2H(x7, y7, tb + tr_off[7]);
+            float4_t s[2][2], dp[2][2];                   // [key sub-tile m][query tile n], rows = keys 16m + 4g + r
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    s[m][n] = float4_t{lq[n], lq[n], lq[n], lq[n]};
+                    dp[m][n] = float4_t{dl[n], dl[n], dl[n], dl[n]};
+                }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const short8_t ak = *reinterpret_cast<const short8_t*>(Ks + row_off[ks] + m * 16 * kFa128Row);
+                    const short8_t av = *reinterpret_cast<const short8_t*>(Vs + row_off[ks] + m * 16 * kFa128Row);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        s[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, bq[n][ks], s[m][n], 0, 0, 0);
+                        dp[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bdo[n][ks], dp[m][n], 0, 0, 0);
+                    }
+                }
+            }
+            const int kbase = kt * kFa128BN + 4 * g;
+            const bool need_mask = (kt * kFa128BN + kFa128BN - 1 > qw) || (kt * kFa128BN + kFa128BN > len);
+            if (need_mask) {
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    const int qi = qw + 16 * n + fr;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float pv = __builtin_amdgcn_exp2f(s[m][n][r]);
+                            const int key = kbase + 16 * m + r;
+                            pv = (key > qi || key >= len || qi >= len) ? 0.f : pv;
+                            s[m][n][r] = pv * dp[m][n][r];
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) s[m][n][r] = __builtin_amdgcn_exp2f(s[m][n][r]) * dp[m][n][r];
+            }
+            short8_t dsf[2];                              // k-slots = keys {4g + j, 16 + 4g + (j - 4)} of the tile
+#pragma unroll
+            for (int n = 0; n < 2; ++n) dsf[n] = pack_frag(s[0][n], s[1][n]);
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(y0),
+                           "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7)
+                         :
+                         : "memory");
+            const short8_t ktf[8] = {join_tr(x0, y0), join_tr(x1, y1), join_tr(x2, y2), join_tr(x3, y3),
+                                     join_tr(x4, y4), join_tr(x5, y5), join_tr(x6, y6), join_tr(x7, y7)};
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ktf[c], dsf[n], acc[c][n], 0, 0, 0);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+    }
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int qi = qw + 16 * n + fr;
+        if (qi >= len) continue;
+        bf16_t* row = dq + (t0 + qi) * sdq + h * kFa128HD;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            uint2 w;
+            w.x = pack_bf16(acc[c][n][0] * scale, acc[c][n][1] * scale);
+            w.y = pack_bf16(acc[c][n][2] * scale, acc[c][n][3] * scale);
+            *reinterpret_cast<uint2*>(row + 16 * c + 4 * g) = w;
+        }
+    }
+}
+
+constexpr int kD128Sl = 32;                                        // query rows per slice
+constexpr int kD128Img = 2 * kD128Sl * kFa128Row + 256;            // Q | dO | 32 x -lse log2(e) | 32 x -delta = 16640 B
+constexpr int kD128Keys = 128;                                     // keys per block (4 waves x 32)
+
+__global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
+    const int* __restrict__ ktiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ nl,
+    const float* __restrict__ nd, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
+    int64_t sdv, int n_ktiles) {
+    __shared__ __attribute__((aligned(16))) char smem[3 * kD128Img];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, fr = lane & 15;
+    const int per = (n_ktiles + 7) >> 3;
+    const int entry = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (entry >= n_ktiles) return;
+    const int seq = ktiles[3 * entry], hk = ktiles[3 * entry + 1], kb0 = ktiles[3 * entry + 2];
+    const int k0 = kb0 + 32 * wave;                        // this wave's 32 keys
+    const int group = nh / nkv;
+    const int64_t t0 = cu[seq];
+    const int len = cu[seq + 1] - (int)t0;
+    if (kb0 >= len) return;                                // padding entry of the table
+    const int qt0 = kb0;                                   // first query row that can see the block's keys (multiple of 32)
+    const int nsl = (len - qt0 + kD128Sl - 1) / kD128Sl;
+    const int niter = nsl * group;
+
+    short8_t bk[2][4], bv[2][4];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const int key = k0 + 16 * n + fr;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const short8_t z = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+            bk[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(k + (t0 + key) * sk + hk * kFa128HD + 32 * ks + 8 * g) : z;
+            bv[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(v + (t0 + key) * sv + hk * kFa128HD + 32 * ks + 8 * g) : z;
+        }
+    }
+    // staging: wave w moves rows 8w .. 8w + 7 of the Q and of the dO slice (two 1-KiB pieces of 4 rows each); wave 0 also the 64
+    // row constants (lanes 0..31: -lse log2(e), lanes 32..63: -delta)
+    const int srow = lane >> 4;
+    const unsigned sqb = (unsigned)sq * 2u, sdob = (unsigned)sdo * 2u;
+    const float* rc_src = lane < 32 ? nl : nd;
+    auto stage = [&](int hq, int qb, int buf) {
+        char* base = smem + buf * kD128Img;
+        const char* qsrc = reinterpret_cast<const char*>(q + t0 * sq + hq * kFa128HD);
+        const char* dsrc = reinterpret_cast<const char*>(dout + t0 * sdo + hq * kFa128HD);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = 2 * wave + i;
+            const int trow = 4 * u + srow;
+            const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
+            const unsigned row = (unsigned)min(qb + trow, len - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc + (row * sqb + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(dsrc + (row * sdob + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + kD128Sl * kFa128Row + u * 1024), 16, 0, 0);
+        }
+        if (wave == 0) {
+            const float* src = rc_src + (int64_t)hq * T + t0 + (unsigned)min(qb + (lane & 31), len - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + 2 * kD128Sl * kFa128Row), 4, 0, 0);
+        }
+    };
+    int st_h = hk * group, st_s = 0, st_buf = 0, st_n = 0;     // (q head, slice) of the next stage, head-major, slices ascending
+    auto stage_next = [&]() {
+        stage(st_h, qt0 + st_s * kD128Sl, st_buf);
+        if (++st_s == nsl) { st_s = 0; ++st_h; }
+        ++st_n;
+        st_buf = st_buf == 2 ? 0 : st_buf + 1;
+    };
+    stage_next();
+    if (niter > 1) stage_next();
+    // K carries scale log2(e) from here on (one rounding to bf16 per element, once per block): S' = Q K'^T - lse log2(e) is the
+    // exponent of exp2 itself.  Touching the fragments here also puts hipcc's wait for their loads in front of the loop.
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+                const unsigned w = pack_bf16(bf16_to_f32((bf16_t)bk[n][ks][e]) * scale_log2e,
+                                             bf16_to_f32((bf16_t)bk[n][ks][e + 1]) * scale_log2e);
+                bk[n][ks][e] = (short)(w & 0xffff);
+                bk[n][ks][e + 1] = (short)(w >> 16);
+            }
+            asm volatile("" : "+v"(bk[n][ks]), "+v"(bv[n][ks]));
+        }
+    // dV^T / dK^T accumulators [hd tile c][key tile n] (rows = hd 16c + 4g + r, col = key 16n + fr) live in LITERAL accumulator
+    // registers for the whole kernel: dV^T[c][n] = a[8c + 4n : + 3], dK^T[c][n] = a[64 + 8c + 4n : + 3].  As C++ variables (MFMA builtin, or
+    // asm with "+a" operands) hipcc carries them through the loop in VGPRs and copies all 128 to the accumulator file and back in
+    // every iteration (830 v_accvgpr_* per slice).  hipcc does not know a[0:127] to be occupied: its resource line must show no
+    // scratch, and no v_accvgpr_* outside ASMSTART / ASMEND may name them (checked in the ISA; the kernel needs ~200 of 256 VGPRs).
+    asm volatile(
+        "v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\t"
+        "v_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\t"
+        "v_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\t"
+        "v_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\t"
+        "v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\t"
+        "v_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\t"
+        "v_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\t"
+        "v_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\t"
+        "v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\t"
+        "v_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\t"
+        "v_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\t"
+        "v_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\t"
+        "v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\t"
+        "v_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\t"
+        "v_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\t"
+        "v_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\t"
+        "v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\t"
+        "v_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\t"
+        "v_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\t"
+        "v_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\t"
+        "v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\t"
+        "v_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\t"
+        "v_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\t"
+        "v_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\t"
+        "v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\t"
+        "v_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\t"
+        "v_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\t"
+        "v_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\t"
+        "v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\t"
+        "v_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\t"
+        "v_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\t"
+        "v_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0"
+        :
+        :
+        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+    const int qq = fr >> 2, pp = fr & 3;
+    const int vsw = 2 * (4 * (g & 1) + qq);
+    unsigned tr_off[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        tr_off[c] = (4 * g + qq) * kFa128Row + (((2 * c + (pp >> 1)) ^ vsw) << 4) + 8 * (pp & 1);
+    unsigned row_off[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) row_off[ks] = fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+
+    int cur = 0, sl = 0;
+    for (int it = 0; it < niter; ++it) {
+        // slice `it` has landed; the stage behind it may still fly (wave 0 issues 5 DMA instructions per stage, the others 4)
+        if (it + 1 < niter) {
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (st_n < niter) stage_next();                      // slice it + 2 -> the image read in iteration it - 1
+        const int qb = qt0 + sl * kD128Sl;
+        const bool active = (qb + kD128Sl - 1 >= k0) && (k0 < len);
+        if (active) {
+            const char* Qs = smem + cur * kD128Img;
+            const char* Ds = Qs + kD128Sl * kFa128Row;
+            const float* Ls = reinterpret_cast<const float*>(Qs + 2 * kD128Sl * kFa128Row);
+            const unsigned tb = smem_base + cur * kD128Img;
+            // dO^T fragments (A operands of dV^T += dO^T P): d[c] = queries 4g .. 4g + 3 of rows 0-15, dd[c] = of rows 16-31
+            u32x2 d0, d1, d2, d3, d4, d5, d6, d7, dd0, dd1, dd2, dd3, dd4, dd5, dd6, dd7;
+            {
+                const unsigned db = tb + kD128Sl * kFa128Row;
+                RPO_TR2H(d0, dd0, db + tr_off[0]);
+                RPO_TR2H(d1, dd1, db + tr_off[1]);
+                RPO_TR2H(d2, dd2, db + tr_off[2]);
+                RPO_TR2H(d3, dd3, db + tr_off[3]);
+                RPO_TR2H(d4, dd4, db + tr_off[4]);
+                RPO_TR2H(d5, dd5, db + tr_off[5]);
+                RPO_TR2H(d6, dd6, db + tr_off[6]);
+                RPO_TR2H(d7, dd7, db + tr_off[7]);
+            }
+            float4_t s[2][2], dp[2][2];                       // [query tile m][key tile n]; rows = queries 16m + 4g + r, col = key 16n + fr
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float4_t lr = *reinterpret_cast<const float4_t*>(Ls + 16 * m + 4 * g);
+                const float4_t dr = *reinterpret_cast<const float4_t*>(Ls + kD128Sl + 16 * m + 4 * g);
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    s[m][n] = lr;
+                    dp[m][n] = dr;
+                }
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const short8_t aq = *reinterpret_cast<const short8_t*>(Qs + row_off[ks] + m * 16 * kFa128Row);
+                    const short8_t ad = *reinterpret_cast<const short8_t*>(Ds + row_off[ks] + m * 16 * kFa128Row);
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        // asm with VGPR accumulators: the builtin takes its accumulators from the accumulator file, i.e. from a[0:31]
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[m][n]) : "v"(aq), "v"(bk[n][ks]));
+                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(dp[m][n]) : "v"(ad), "v"(bv[n][ks]));
+                    }
+                }
+            }
+            // 8-pass MFMA result -> VALU read: 11 wait states, which hipcc cannot count for asm; the operands pin the statement
+            // between the chains and their first use
+            asm volatile("s_nop 15"
+                         : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(dp[0][0]), "+v"(dp[0][1]),
+                           "+v"(dp[1][0]), "+v"(dp[1][1]));
+            // Q^T fragments (A operands of dK^T += Q^T dS): land under the arithmetic below
+            u32x2 e0, e1, e2, e3, e4, e5, e6, e7, ee0, ee1, ee2, ee3, ee4, ee5, ee6, ee7;
+            RPO_TR2H(e0, ee0, tb + tr_off[0]);
+            RPO_TR2H(e1, ee1, tb + tr_off[1]);
+            RPO_TR2H(e2, ee2, tb + tr_off[2]);
+            RPO_TR2H(e3, ee3, tb + tr_off[3]);
+            RPO_TR2H(e4, ee4, tb + tr_off[4]);
+            RPO_TR2H(e5, ee5, tb + tr_off[5]);
+            RPO_TR2H(e6, ee6, tb + tr_off[6]);
+            RPO_TR2H(e7, ee7, tb + tr_off[7]);
+            const bool need_mask = (qb < k0 + 31) || (qb + kD128Sl > len) || (k0 + 32 > len);
+            if (need_mask) {
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const int qr0 = qb + 16 * m + 4 * g;
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        const int key = k0 + 16 * n + fr;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            float pv = __builtin_amdgcn_exp2f(s[m][n][r]);
+                            pv = (key > qr0 + r || key >= len || qr0 + r >= len) ? 0.f : pv;
+                            s[m][n][r] = pv;
+                            dp[m][n][r] = pv * dp[m][n][r];
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(s[m][n][r]);
+                            s[m][n][r] = pv;
+                            dp[m][n][r] = pv * dp[m][n][r];
+                        }
+            }
+            short8_t pf[2], dsf[2];                         // k-slots = queries {4g + j, 16 + 4g + (j - 4)} of the slice
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                pf[n] = pack_frag(s[0][n], s[1][n]);
+                dsf[n] = pack_frag(dp[0][n], dp[1][n]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(dd0),
+                           "+v"(dd1), "+v"(dd2), "+v"(dd3), "+v"(dd4), "+v"(dd5), "+v"(dd6), "+v"(dd7)
+                         :
+                         : "memory");
+            asm volatile(""
+                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7), "+v"(ee0),
+                           "+v"(ee1), "+v"(ee2), "+v"(ee3), "+v"(ee4), "+v"(ee5), "+v"(ee6), "+v"(ee7)
+                         :
+                         : "memory");
+            const short8_t atd[8] = {join_tr(d0, dd0), join_tr(d1, dd1), join_tr(d2, dd2), join_tr(d3, dd3),
+                                     join_tr(d4, dd4), join_tr(d5, dd5), join_tr(d6, dd6), join_tr(d7, dd7)};
+            const short8_t atq[8] = {join_tr(e0, ee0), join_tr(e1, ee1), join_tr(e2, ee2), join_tr(e3, ee3),
+                                     join_tr(e4, ee4), join_tr(e5, ee5), join_tr(e6, ee6), join_tr(e7, ee7)};
+            // dV^T += dO^T P, dK^T += Q^T dS on the literal accumulators.  hipcc does not see inside the statements: the s_nop covers
+            // a VALU-written operand (packing, fragment assembly) in front of an MFMA.
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[0:3], %0, %2, a[0:3]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[64:67], %1, %4, a[64:67]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[4:7], %0, %3, a[4:7]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[68:71], %1, %5, a[68:71]"
+                         :
+                         : "v"(atd[0]), "v"(atq[0]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
+                         : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[8:11], %0, %2, a[8:11]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[72:75], %1, %4, a[72:75]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[12:15], %0, %3, a[12:15]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[76:79], %1, %5, a[76:79]"
+                         :
+                         : "v"(atd[1]), "v"(atq[1]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
+                         : "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[16:19], %0, %2, a[16:19]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[80:83], %1, %4, a[80:83]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[20:23], %0, %3, a[20:23]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[84:87], %1, %5, a[84:87]"
+                         :
+                         : "v"(atd[2]), "v"(atq[2]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
+                         : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87");
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[24:27], %0, %2, a[24:27]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[88:91], %1, %4, a[88:91]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[28:31], %0, %3, a[28:31]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[92:95], %1, %5, a[92:95]"
+                         :
+                         : "v"(atd[3]), "v"(atq[3]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
+                         : "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[32:35], %0, %2, a[32:35]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[96:99], %1, %4, a[96:99]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[36:39], %0, %3, a[36:39]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[100:103], %1, %5, a[100:103]"
+                         :
+                         : "v"(atd[4]), "v"(atq[4]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
+                         : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103");
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[40:43], %0, %2, a[40:43]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[104:107], %1, %4, a[104:107]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[44:47], %0, %3, a[44:47]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[108:111], %1, %5, a[108:111]"
+                         :
+                         : "v"(atd[5]), "v"(atq[5]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
+                         : "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[48:51], %0, %2, a[48:51]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[112:115], %1, %4, a[112:115]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[52:55], %0, %3, a[52:55]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[116:119], %1, %5, a[116:119]"
+                         :
+                         : "v"(atd[6]), "v"(atq[6]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
+                         : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119");
+            asm volatile("s_nop 1\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[56:59], %0, %2, a[56:59]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[120:123], %1, %4, a[120:123]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[60:63], %0, %3, a[60:63]\n\t"
+                         "v_mfma_f32_16x16x32_bf16 a[124:127], %1, %5, a[124:127]"
+                         :
+                         : "v"(atd[7]), "v"(atq[7]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
+                         : "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+        sl = sl + 1 == nsl ? 0 : sl + 1;
+    }
+#undef RPO_TR2H
+    // the last MFMAs have to leave the pipe before their accumulators are read (hipcc cannot see the dependency)
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#define RPO_D128_OUT(B0, B1, B2, B3, DST, MUL)                                                                      \
+    do {                                                                                                            \
+        float t0_, t1_, t2_, t3_;                                                                                   \
+        asm volatile("v_accvgpr_read_b32 %0, a" #B0 "\n\tv_accvgpr_read_b32 %1, a" #B1 "\n\t"                        \
+                     "v_accvgpr_read_b32 %2, a" #B2 "\n\tv_accvgpr_read_b32 %3, a" #B3                              \
+                     : "=v"(t0_), "=v"(t1_), "=v"(t2_), "=v"(t3_));                                                   \
+        uint2 w_;                                                                                                   \
+        w_.x = pack_bf16(t0_ * (MUL), t1_ * (MUL));                                                                 \
+        w_.y = pack_bf16(t2_ * (MUL), t3_ * (MUL));                                                                 \
+        *reinterpret_cast<uint2*>(DST) = w_;                                                                        \
+    } while (0)
+    {
+        const int key = k0 + 0 + fr;
+        if (key < len) {
+            bf16_t* krow = dk + (t0 + key) * sdk + hk * kFa128HD + 4 * g;
+            bf16_t* vrow = dv + (t0 + key) * sdv + hk * kFa128HD + 4 * g;
+            RPO_D128_OUT(0, 1, 2, 3, vrow + 0, 1.0f);
+            RPO_D128_OUT(64, 65, 66, 67, krow + 0, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(8, 9, 10, 11, vrow + 16, 1.0f);
+            RPO_D128_OUT(72, 73, 74, 75, krow + 16, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(16, 17, 18, 19, vrow + 32, 1.0f);
+            RPO_D128_OUT(80, 81, 82, 83, krow + 32, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(24, 25, 26, 27, vrow + 48, 1.0f);
+            RPO_D128_OUT(88, 89, 90, 91, krow + 48, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(32, 33, 34, 35, vrow + 64, 1.0f);
+            RPO_D128_OUT(96, 97, 98, 99, krow + 64, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(40, 41, 42, 43, vrow + 80, 1.0f);
+            RPO_D128_OUT(104, 105, 106, 107, krow + 80, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(48, 49, 50, 51, vrow + 96, 1.0f);
+            RPO_D128_OUT(112, 113, 114, 115, krow + 96, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(56, 57, 58, 59, vrow + 112, 1.0f);
+            RPO_D128_OUT(120, 121, 122, 123, krow + 112, scale);          // dK = scale * dS^T Q
+        }
+    }
+    {
+        const int key = k0 + 16 + fr;
+        if (key < len) {
+            bf16_t* krow = dk + (t0 + key) * sdk + hk * kFa128HD + 4 * g;
+            bf16_t* vrow = dv + (t0 + key) * sdv + hk * kFa128HD + 4 * g;
+            RPO_D128_OUT(4, 5, 6, 7, vrow + 0, 1.0f);
+            RPO_D128_OUT(68, 69, 70, 71, krow + 0, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(12, 13, 14, 15, vrow + 16, 1.0f);
+            RPO_D128_OUT(76, 77, 78, 79, krow + 16, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(20, 21, 22, 23, vrow + 32, 1.0f);
+            RPO_D128_OUT(84, 85, 86, 87, krow + 32, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(28, 29, 30, 31, vrow + 48, 1.0f);
+            RPO_D128_OUT(92, 93, 94, 95, krow + 48, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(36, 37, 38, 39, vrow + 64, 1.0f);
+            RPO_D128_OUT(100, 101, 102, 103, krow + 64, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(44, 45, 46, 47, vrow + 80, 1.0f);
+            RPO_D128_OUT(108, 109, 110, 111, krow + 80, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(52, 53, 54, 55, vrow + 96, 1.0f);
+            RPO_D128_OUT(116, 117, 118, 119, krow + 96, scale);          // dK = scale * dS^T Q
+            RPO_D128_OUT(60, 61, 62, 63, vrow + 112, 1.0f);
+            RPO_D128_OUT(124, 125, 126, 127, krow + 112, scale);          // dK = scale * dS^T Q
+        }
+    }
+#undef RPO_D128_OUT
+}
+
 }  // namespace
 
 #ifdef RPO_FA_STAMP
@@ -2454,9 +3059,11 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     if (n_q_tiles <= 0 || n_k_tiles <= 0 || total_tokens <= 0) return RPO_ERR_INVALID_ARG;
     // `key_block` states what the entries of `k_tiles` mean: blocks of 256 keys (one-wave-per-SIMD dK/dV kernel) or of 64
     // keys (the 8-wave kernel).  The caller that built the table says so; nothing is read from the environment.
-    if (key_block != 256 && key_block != 64) return RPO_ERR_UNSUPPORTED;
+    // head_dim 128: blocks of 128 keys (fa_bwd_dkdv128_kernel), nothing else.
+    if (head_dim == kFa128HD ? key_block != kD128Keys : (key_block != 256 && key_block != 64)) return RPO_ERR_UNSUPPORTED;
     if (!(q_tile_cols == 2 || (q_tile_cols == 3 && n_q_tiles % 8 == 0))) return RPO_ERR_UNSUPPORTED;
-    if (head_dim != kFaHD || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 || num_heads > 65535)
+    if ((head_dim != kFaHD && head_dim != kFa128HD) || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 ||
+        num_heads > 65535)
         return RPO_ERR_UNSUPPORTED;
     if (q_stride % 8 || k_stride % 8 || v_stride % 8 || out_stride % 8 || dout_stride % 8 || dq_stride % 4 ||
         dk_stride % 4 || dv_stride % 4 || !rpo_aligned16(q) || !rpo_aligned16(k) || !rpo_aligned16(v) ||
@@ -2467,6 +3074,19 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     float* nd = delta;                                       // scratch [2][num_heads][T]: -delta | -lse / scale
     float* nl = delta + num_heads * total_tokens;
     // (round 1 launched fa_delta_kernel here; the dQ kernel now computes and writes both row constants itself)
+    if (head_dim == kFa128HD) {                              // nl = -lse log2(e) here: the dK/dV kernel scales K, not S
+        RPO_LAUNCH(fa_bwd_dq128_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads),
+                   0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
+                   dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,
+                   lse, (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride);
+        const int rc128 = rpo_launch_status();
+        if (rc128 != RPO_OK) return rc128;
+        RPO_LAUNCH(fa_bwd_dkdv128_kernel, dim3((unsigned)(((n_k_tiles + 7) / 8) * 8)), dim3(256), 0, st, (const bf16_t*)q,
+                   (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens,
+                   k_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
+                   (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles);
+        return rpo_launch_status();
+    }
     RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0,
                st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
                dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse,

@@ -180,10 +180,11 @@ class VarlenCtx:
 def _varlen_causal_attention(q, k, v, ctx: VarlenCtx):
     """q [T, nh, hd], k/v [T, nkv, hd] packed; causal attention inside each sequence."""
     if q.is_cuda and q.dtype == torch.bfloat16 and q.shape[-1] in (64, 128) and ctx.tiles is not None:
-        # hand-written HIP kernels: forward for head_dim 64 and 128; backward for 64 (k_tiles given), else PyTorch's
-        # flash-attention backward on the saved (out, padded lse)
+        # hand-written HIP kernels, head_dim 64 and 128: forward, and backward when the key-block table was built (grad mode);
+        # without it PyTorch's flash-attention backward runs on the saved (out, padded lse)
         return _ops.flash_attn_varlen(q, k, v, ctx.cu, ctx.tiles, ctx.max_len, 1.0 / math.sqrt(q.shape[-1]),
-                                      k_tiles=ctx.k_tiles if q.shape[-1] == 64 else None)
+                                      k_tiles=ctx.k_tiles,
+                                      key_block=_ops.ATTN_KEY_BLOCK if q.shape[-1] == 64 else _ops.ATTN_KEY_BLOCK_HD128)
     if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16):
         return torch.ops.aten._flash_attention_forward(q, k, v, ctx.cu, ctx.cu, ctx.max_len, ctx.max_len, 0.0, True,
                                                        False)[0]
@@ -282,12 +283,12 @@ class LlamaAttention(nn.Module):
         if fused:       # one in-place HIP pass over the q and k heads instead of neg / cat / 2 mul / add per tensor
             qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd, grad_inplace=True)
         q, k, v = qkv.split([nq, nk, nk], dim=-1)
-        if (isinstance(attn_mask, VarlenCtx) and fused and attn_mask.k_tiles is not None and self.hd == 64
+        if (isinstance(attn_mask, VarlenCtx) and fused and attn_mask.k_tiles is not None and self.hd in (64, 128)
                 and x.dtype == torch.bfloat16):
             # training on packed tokens: attention reads q / k / v as column blocks of the projection output and its
             # backward writes one d(q|k|v) buffer (no split / cat copies)
             o = _ops.flash_attn_varlen_qkv(qkv.view(L, -1), self.nh, self.nkv, attn_mask.cu, attn_mask.tiles,
-                                           attn_mask.k_tiles, 1.0 / math.sqrt(self.hd))
+                                           attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd)
             return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
         if isinstance(attn_mask, VarlenCtx):
             # packed tokens [1, T, d]: variable-length causal flash attention, no pad tokens anywhere
@@ -523,8 +524,10 @@ class LlamaEncoder(nn.Module):
         tiles = k_tiles = None
         if x.is_cuda and self.config.head_dim in (64, 128) and x.dtype == torch.bfloat16:     # hand-written flash attention
             tiles = _ops.attn_tile_table(lens, x.device, self.config.num_attention_heads, self.config.num_key_value_heads)
-            if torch.is_grad_enabled() and self.config.head_dim == 64:
-                k_tiles = _ops.attn_key_tile_table(lens, x.device, self.config.num_key_value_heads)
+            if torch.is_grad_enabled():
+                k_tiles = _ops.attn_key_tile_table(
+                    lens, x.device, self.config.num_key_value_heads,
+                    _ops.ATTN_KEY_BLOCK if self.config.head_dim == 64 else _ops.ATTN_KEY_BLOCK_HD128)
         ctx = VarlenCtx(cu, lens, max(lens), tiles, k_tiles)
         last_idx = (cu[1:] - 1).to(torch.int64)
         x, delta = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1)

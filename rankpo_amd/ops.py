@@ -567,6 +567,7 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
     return out, lse
 
 
+ATTN_KEY_BLOCK_HD128 = 128   # keys per block of the head_dim-128 dK/dV kernel
 ATTN_KEY_BLOCK = 256     # keys per entry of the dK/dV work list (256: one-wave-per-SIMD kernel; 64: the 8-wave kernel)
 ATTN_SWEEP_DOWN = False  # dK/dV schedule: key blocks of a (sequence, kv head) side by side, sweeping the query slices downwards
 
@@ -574,10 +575,11 @@ ATTN_SWEEP_DOWN = False  # dK/dV schedule: key blocks of a (sequence, kv head) s
 def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = ATTN_KEY_BLOCK, group_order=None):
     """int32 [n, 3] = (sequence id, kv head, first key of a key block): the key blocks of one (sequence, kv head) read the same
     Q / dO rows and are placed on one XCD by the kernel's block -> entry map.  block_n = 256 keys (default, the
-    one-wave-per-SIMD dK/dV kernel) or 64 (the 8-wave kernel, A/B); whoever builds a table with block_n = 64 passes
-    key_block=64 to `flash_attn_varlen(_qkv)` as well -- it is an argument of the C call, not an environment switch."""
-    if block_n not in (64, 256):
-        raise ValueError("attn_key_tile_table: block_n must be 64 or 256")
+    one-wave-per-SIMD dK/dV kernel at head_dim 64), 64 (the 8-wave kernel, A/B) or 128 (`ATTN_KEY_BLOCK_HD128`: the head_dim-128
+    dK/dV kernel); whoever builds a table with another block_n than the default passes the same key_block to
+    `flash_attn_varlen(_qkv)` as well -- it is an argument of the C call, not an environment switch."""
+    if block_n not in (64, 128, 256):
+        raise ValueError("attn_key_tile_table: block_n must be 64, 128 or 256")
     if group_order is None:
         group_order = ATTN_SWEEP_DOWN
     return _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order)
@@ -585,7 +587,7 @@ def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = ATTN_KEY
 
 def _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order=False):
     import numpy as np
-    if block_n != 256:
+    if block_n == 64:
         parts = []
         for s, n in enumerate(lens):
             k0 = np.arange(0, n, block_n, dtype=np.int32)
@@ -626,8 +628,9 @@ def _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order=False)
 
 def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale, grads=None,
                           key_block: int = ATTN_KEY_BLOCK, sweep_down=None):
-    """grads: optional preallocated (dq, dk, dv) [T, heads, 64] views with arbitrary token strides (e.g. the three column
-    blocks of ONE fused d(q|k|v) buffer).  key_block: keys per entry of `k_tiles` (`attn_key_tile_table`'s block_n)."""
+    """grads: optional preallocated (dq, dk, dv) [T, heads, hd] views with arbitrary token strides (e.g. the three column
+    blocks of ONE fused d(q|k|v) buffer).  key_block: keys per entry of `k_tiles` (`attn_key_tile_table`'s block_n): 256 or 64 at
+    head_dim 64, 128 at head_dim 128."""
     lib = _lib.load()
     if sweep_down is None:
         sweep_down = ATTN_SWEEP_DOWN
@@ -642,8 +645,8 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
         dq, dk, dv = grads
         for t, h in ((dq, nh), (dk, nkv), (dv, nkv)):
             if t.shape != (T, h, hd) or t.stride(2) != 1 or t.stride(1) != hd or t.dtype != q.dtype:
-                raise ValueError("flash_attn_varlen_bwd: gradient views must be [T, heads, 64] with contiguous heads")
-    delta = torch.empty((2, nh, T), dtype=torch.float32, device=q.device)     # scratch: -delta | -lse / scale
+                raise ValueError("flash_attn_varlen_bwd: gradient views must be [T, heads, head_dim] with contiguous heads")
+    delta = torch.empty((2, nh, T), dtype=torch.float32, device=q.device)     # scratch: -delta | -lse / scale (hd 128: -lse log2 e)
     with torch.cuda.device(q.device):
         check(lib.rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0),
@@ -655,8 +658,9 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
 
 
 class _FlashAttnVarlen(torch.autograd.Function):
-    """Causal varlen attention, head_dim 64: hand-written HIP forward and backward (k_tiles given), or HIP forward +
-    PyTorch's flash-attention backward op on the saved (out, padded lse) when k_tiles is None."""
+    """Causal varlen attention, head_dim 64 / 128: hand-written HIP forward and backward (k_tiles given, built with the
+    key_block that is passed along), or HIP forward + PyTorch's flash-attention backward op on the saved (out, padded lse) when
+    k_tiles is None."""
 
     @staticmethod
     def forward(ctx, q, k, v, cu, tiles, k_tiles, max_len, scale, key_block):
@@ -685,41 +689,46 @@ def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale, k_tiles=None, key_bloc
 
 
 class _FlashAttnVarlenQKV(torch.autograd.Function):
-    """Same attention on the output of ONE fused q|k|v projection, [T, (nh + 2 nkv) * 64] (rotary already applied): the
-    kernels read q / k / v as strided column blocks and the backward writes dq / dk / dv straight into the column blocks
-    of one d(q|k|v) buffer, which is the operand of the projection's gradient GEMMs (no split / cat copies: the cat
+    """Same attention on the output of ONE fused q|k|v projection, [T, (nh + 2 nkv) * hd] (rotary already applied; hd = 64 or
+    128): the kernels read q / k / v as strided column blocks and the backward writes dq / dk / dv straight into the column
+    blocks of one d(q|k|v) buffer, which is the operand of the projection's gradient GEMMs (no split / cat copies: the cat
     moved 1.6 GB per block on the cfg-2 passage tower)."""
 
     @staticmethod
-    def _views(x, nh, nkv):
-        T = x.shape[0]
-        nq, nk = nh * 64, nkv * 64
-        return (x[:, :nq].unflatten(1, (nh, 64)), x[:, nq:nq + nk].unflatten(1, (nkv, 64)),
-                x[:, nq + nk:].unflatten(1, (nkv, 64)))
+    def _views(x, nh, nkv, hd):
+        nq, nk = nh * hd, nkv * hd
+        return (x[:, :nq].unflatten(1, (nh, hd)), x[:, nq:nq + nk].unflatten(1, (nkv, hd)),
+                x[:, nq + nk:].unflatten(1, (nkv, hd)))
 
     @staticmethod
     def forward(ctx, qkv, nh, nkv, cu, tiles, k_tiles, scale, key_block):
-        q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv)
+        hd = qkv.shape[1] // (nh + 2 * nkv)
+        q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv, hd)
         out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0, num_seqs=cu.numel() - 1)
         ctx.save_for_backward(qkv, out, lse, cu, tiles, k_tiles)
-        ctx.meta = (nh, nkv, scale, key_block)
+        ctx.meta = (nh, nkv, hd, scale, key_block)
         return out
 
     @staticmethod
     def backward(ctx, go):
         qkv, out, lse, cu, tiles, k_tiles = ctx.saved_tensors
-        nh, nkv, scale, key_block = ctx.meta
-        q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv)
+        nh, nkv, hd, scale, key_block = ctx.meta
+        q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv, hd)
         dqkv = torch.empty_like(qkv)
         flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale,
-                              grads=_FlashAttnVarlenQKV._views(dqkv, nh, nkv), key_block=key_block)
+                              grads=_FlashAttnVarlenQKV._views(dqkv, nh, nkv, hd), key_block=key_block)
         return dqkv, None, None, None, None, None, None, None
 
 
-def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block: int = ATTN_KEY_BLOCK):
-    """qkv: [T, (num_heads + 2 num_kv_heads) * 64] bf16, contiguous rows -> out [T, num_heads, 64]."""
-    if qkv.dim() != 2 or qkv.shape[1] != (num_heads + 2 * num_kv_heads) * 64 or not qkv.is_contiguous():
-        raise ValueError("flash_attn_varlen_qkv: qkv must be a contiguous [T, (nh + 2 nkv) * 64] tensor")
+def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None, head_dim: int = 64):
+    """qkv: [T, (num_heads + 2 num_kv_heads) * head_dim] bf16, contiguous rows -> out [T, num_heads, head_dim]; head_dim 64
+    or 128; key_block (None: the head_dim's default) = the block_n `k_tiles` was built with."""
+    if head_dim not in (64, 128):
+        raise ValueError("flash_attn_varlen_qkv: head_dim must be 64 or 128")
+    if qkv.dim() != 2 or qkv.shape[1] != (num_heads + 2 * num_kv_heads) * head_dim or not qkv.is_contiguous():
+        raise ValueError("flash_attn_varlen_qkv: qkv must be a contiguous [T, (nh + 2 nkv) * head_dim] tensor")
+    if key_block is None:
+        key_block = ATTN_KEY_BLOCK if head_dim == 64 else ATTN_KEY_BLOCK_HD128
     return _FlashAttnVarlenQKV.apply(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block)
 
 

@@ -118,38 +118,43 @@ def test_flash_attn_fwd_speed_report():
         assert (x.float() - y.float()).abs().max() < 0.03 * max(1.0, y.float().abs().max().item())
 
 
-def test_flash_attn_qkv_fused_buffer_matches_split_views():
+@pytest.mark.parametrize("hd", [64, 128])
+def test_flash_attn_qkv_fused_buffer_matches_split_views(hd):
     """flash_attn_varlen_qkv (reads q|k|v as column blocks of one projection output, writes ONE d(q|k|v) buffer) must give
     bit-identical results to flash_attn_varlen on separate tensors: same kernels, different strides."""
     from rankpo_amd import ops
     torch.manual_seed(3)
-    nh, nkv, hd = 8, 2, 64
+    nh, nkv = 8, 2
+    kb = ops.ATTN_KEY_BLOCK if hd == 64 else ops.ATTN_KEY_BLOCK_HD128
     lens = [1, 63, 64, 65, 200, 129, 333]
     T = sum(lens)
     cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
     tiles = ops.attn_tile_table(lens, DEV)
-    kt = ops.attn_key_tile_table(lens, DEV, nkv)
+    kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=kb)
     qkv = torch.randn(T, (nh + 2 * nkv) * hd, device=DEV).to(torch.bfloat16).requires_grad_(True)
-    out = ops.flash_attn_varlen_qkv(qkv, nh, nkv, cu, tiles, kt, 0.125)
+    out = ops.flash_attn_varlen_qkv(qkv, nh, nkv, cu, tiles, kt, 0.125, head_dim=hd)
     go = torch.randn_like(out)
     out.backward(go)
     q, k, v = (t.detach().clone().contiguous().requires_grad_(True) for t in
                (qkv[:, :nh * hd].view(T, nh, hd), qkv[:, nh * hd:(nh + nkv) * hd].view(T, nkv, hd),
                 qkv[:, (nh + nkv) * hd:].view(T, nkv, hd)))
-    ref = ops.flash_attn_varlen(q, k, v, cu, tiles, max(lens), 0.125, k_tiles=kt)
+    ref = ops.flash_attn_varlen(q, k, v, cu, tiles, max(lens), 0.125, k_tiles=kt, key_block=kb)
     ref.backward(go)
     assert torch.equal(out, ref)
     dref = torch.cat([q.grad.reshape(T, -1), k.grad.reshape(T, -1), v.grad.reshape(T, -1)], 1)
     assert torch.equal(qkv.grad, dref)
 
 
-def test_flash_attn_bwd_random_shapes_deterministic():
+@pytest.mark.parametrize("hd", [64, 128])
+def test_flash_attn_bwd_random_shapes_deterministic(hd):
     """Random (sequence count, lengths 1..2600, heads, GQA ratio): the hand-written backward (delta + dQ + one-wave-per-SIMD
-    dK/dV with its hand-placed slice body and its masked fallback path) is bit-reproducible run to run and agrees with
-    PyTorch's flash-attention backward on the same bf16 inputs."""
+    dK/dV with its hand-placed slice body and its masked fallback path; head_dim 128: fa_bwd_dq128 / fa_bwd_dkdv128) is
+    bit-reproducible run to run and agrees with PyTorch's flash-attention backward on the same bf16 inputs."""
     from rankpo_amd import ops
-    rs = np.random.RandomState(123)
-    for ci in range(24):
+    rs = np.random.RandomState(123 + hd)
+    scale = hd ** -0.5
+    kb = ops.ATTN_KEY_BLOCK if hd == 64 else ops.ATTN_KEY_BLOCK_HD128
+    for ci in range(24 if hd == 64 else 16):
         nkv = int(rs.choice([1, 2, 4, 8]))
         nh = nkv * int(rs.choice([1, 2, 4]))
         N = int(rs.randint(1, 20))
@@ -157,20 +162,20 @@ def test_flash_attn_bwd_random_shapes_deterministic():
         lens = [int(x) for x in rs.randint(1, hi + 1, size=N)]
         T = sum(lens)
         torch.manual_seed(ci)
-        q = torch.randn(T, nh, 64, device=DEV).to(torch.bfloat16)
-        k = torch.randn(T, nkv, 64, device=DEV).to(torch.bfloat16)
-        v = torch.randn(T, nkv, 64, device=DEV).to(torch.bfloat16)
+        q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+        k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+        v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
         cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
-        tiles = ops.attn_tile_table(lens, DEV)
-        kt = ops.attn_key_tile_table(lens, DEV, nkv)
-        out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, 0.125)
+        tiles = ops.attn_tile_table(lens, DEV) if ci % 2 else ops.attn_tile_table(lens, DEV, nh, nkv)
+        kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=kb)
+        out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale)
         go = torch.randn_like(out)
-        a = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, 0.125)
-        b = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, 0.125)
+        a = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, scale, key_block=kb)
+        b = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, scale, key_block=kb)
         assert all(torch.equal(x, y) for x, y in zip(a, b)), (ci, lens)
-        r = torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False)
+        r = torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False, scale=scale)
         d = torch.ops.aten._flash_attention_backward(go, q, k, v, r[0], r[1], cu, cu, max(lens), max(lens), 0.0, True, r[2],
-                                                     r[3])
+                                                     r[3], scale=scale)
         for name, x, y in zip(("dq", "dk", "dv"), a, d):
             assert torch.isfinite(x.float()).all(), (name, ci, lens)
             err = (x.float() - y.float()).abs().max().item() / max(1.0, y.float().abs().max().item())
@@ -201,11 +206,11 @@ def test_key_block_is_an_abi_argument():
     assert torch.equal(res[256][0], res[64][0])                       # dQ: same kernel either way
     for x, y in zip(res[256][1:], res[64][1:]):
         assert (x.float() - y.float()).abs().max() <= 2.0 ** -6 * max(1.0, y.float().abs().max().item())
-    with pytest.raises(RankPOHipError, match="status -2"):
+    with pytest.raises(RankPOHipError, match="status -2"):           # 128-key blocks belong to head_dim 128 only
         ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, ops.attn_key_tile_table(lens, DEV, nkv), 0.125,
                                   key_block=128)
     with pytest.raises(ValueError):
-        ops.attn_key_tile_table(lens, DEV, nkv, block_n=128)
+        ops.attn_key_tile_table(lens, DEV, nkv, block_n=32)
 
 
 def test_xcd_dealt_tile_list_is_only_a_schedule():
@@ -276,6 +281,53 @@ def test_flash_attn_fwd_head_dim_128(lens, nh, nkv, fused):
     ref_attention(qr, kr, vr, lens, scale)[0].backward(go.float())
     for a, b in ((qa.grad, qr.grad), (ka.grad, kr.grad), (va.grad, vr.grad)):
         assert (a.float() - b).abs().max() < 0.03 * max(1.0, b.abs().max().item())
+    # hand-written head_dim-128 backward (fa_bwd_dq128_kernel + fa_bwd_dkdv128_kernel, 128-key blocks), on the strided views,
+    # with both query-tile list formats: same tolerance as the head_dim-64 kernels, and no worse than PyTorch's op by more
+    # than bf16 noise
+    kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=ops.ATTN_KEY_BLOCK_HD128)
+    for tl in (ops.attn_tile_table(lens, DEV), tiles):
+        qb, kb, vb = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
+        ob = ops.flash_attn_varlen(qb, kb, vb, cu, tl, max(lens), scale, k_tiles=kt, key_block=ops.ATTN_KEY_BLOCK_HD128)
+        assert torch.equal(ob, out)
+        ob.backward(go)
+        for name, a, b, c in (("dq", qb.grad, qr.grad, qa.grad), ("dk", kb.grad, kr.grad, ka.grad), ("dv", vb.grad, vr.grad, va.grad)):
+            err = (a.float() - b).abs().max().item()
+            assert err < 0.03 * max(1.0, b.abs().max().item()), (name, err, b.abs().max().item())
+            rel = ((a.float() - b).norm() / b.norm()).item()
+            rel_pt = ((c.float() - b).norm() / b.norm()).item()
+            assert rel <= 1.5 * rel_pt + 1e-4, (name, rel, rel_pt)
+    from rankpo_amd._lib import RankPOHipError
+    with pytest.raises(RankPOHipError, match="status -2"):           # a 256-key table is not what the head_dim-128 kernel reads
+        ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, ops.attn_key_tile_table(lens, DEV, nkv), scale, key_block=256)
+
+
+def test_flash_attn_bwd128_speed_report():
+    """Prints the head_dim-128 backward rate next to PyTorch's flash-attention backward op on a cfg-5-like passage batch (not a gate)."""
+    from rankpo_amd import ops
+    torch.manual_seed(0)
+    nh, nkv, hd, N, L = 32, 8, 128, 24, 4096
+    lens = torch.randint(L // 2, L + 1, (N,)); lens[0] = L
+    lens = lens.tolist(); T = sum(lens)
+    mk = lambda h: torch.randn(T, h, hd, device=DEV).to(torch.bfloat16).requires_grad_()
+    q, k, v = mk(nh), mk(nkv), mk(nkv)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    tiles = ops.attn_tile_table(lens, DEV, nh, nkv)
+    kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=ops.ATTN_KEY_BLOCK_HD128)
+    go = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+    fl = sum(10 * nh * hd * n * (n + 1) / 2 for n in lens)
+    res = {}
+    for name, ktab in (("HIP", kt), ("PyTorch op", None)):
+        out = ops.flash_attn_varlen(q, k, v, cu, tiles, max(lens), hd ** -0.5, k_tiles=ktab, key_block=ops.ATTN_KEY_BLOCK_HD128)
+        fn = lambda: torch.autograd.grad(out, (q, k, v), go, retain_graph=True)
+        for _ in range(3):
+            g = fn()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize(); res[name] = ((time.perf_counter() - t) / 10 * 1e3, g)
+    for a, b in zip(res["HIP"][1], res["PyTorch op"][1]):
+        assert (a.float() - b.float()).abs().max() < 0.03 * max(1.0, b.float().abs().max().item())
+    print("\nflash bwd head_dim 128, %d sequences: " % N + " ; ".join(f"{n} {ms:.2f} ms = {fl / ms / 1e9:.0f} TFLOP/s" for n, (ms, _) in res.items()))
 
 
 def test_flash_attn_fwd128_speed_report():

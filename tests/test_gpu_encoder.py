@@ -418,9 +418,9 @@ def test_transpose_and_mixed_layout_wgrad(dtype):
 
 
 def test_head_dim_128_packed_training_step_vs_oracle():
-    """Llama-3-8B-style head (head_dim 128, GQA) through the packed encoder path: hand-written forward attention
-    (fa_fwd128_kernel) + PyTorch's flash-attention backward on its saved output / lse; loss, scores and an embedding gradient
-    against the float32 oracle with the bf16 tolerances of the other encoder tests."""
+    """Llama-3-8B-style head (head_dim 128, GQA) through the packed encoder path: hand-written forward (fa_fwd128_kernel) and
+    backward (fa_bwd_dq128_kernel + fa_bwd_dkdv128_kernel) attention on the fused q|k|v buffer; loss, scores and an embedding
+    gradient against the float32 oracle with the bf16 tolerances of the other encoder tests."""
     import rankpo_amd
     from rankpo_amd import encoder as PE, ops
     torch.manual_seed(21)
@@ -434,16 +434,18 @@ def test_head_dim_128_packed_training_step_vs_oracle():
     cb = {"query": {"input_ids": qi, "attention_mask": qm}, "passage": {"input_ids": pi, "attention_mask": pm}}
     ref_loss, ref_s, _, _ = E.contrastive_step(w, cfg.to_dict(), cb, 0.02)
     ref_loss.backward()
-    calls = []
-    real = ops.flash_attn_varlen_fwd
+    calls, bcalls = [], []
+    real, real_b = ops.flash_attn_varlen_fwd, ops.flash_attn_varlen_bwd
     ops.flash_attn_varlen_fwd = lambda q, *a, **kw: (calls.append(q.shape[-1]), real(q, *a, **kw))[1]
+    ops.flash_attn_varlen_bwd = lambda q, *a, **kw: (bcalls.append((q.shape[-1], kw.get("key_block"))), real_b(q, *a, **kw))[1]
     try:
         model = rankpo_amd.ModelForTraining(encoder=enc.to(DEV).to(torch.bfloat16), temperature=0.02).train()
         out = model(**{k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in cb.items()})
         out.loss.backward()
     finally:
-        ops.flash_attn_varlen_fwd = real
+        ops.flash_attn_varlen_fwd, ops.flash_attn_varlen_bwd = real, real_b
     assert calls and all(c == 128 for c in calls)                        # the head_dim-128 HIP forward ran in every full block
+    assert len(bcalls) == cfg.num_hidden_layers - 1 and all(c == (128, 128) for c in bcalls)   # ... and the HIP backward
     assert (out.scores.float().cpu() * 0.02 - ref_s.detach() * 0.02).abs().max() < 2e-2      # cosines
     assert abs(out.loss.item() - ref_loss.item()) < 0.25 * max(1.0, abs(ref_loss.item()))
     g, gr = model.model.embed_tokens.weight.grad.float().cpu(), w["embed_tokens.weight"].grad
