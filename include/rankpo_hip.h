@@ -233,14 +233,16 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
                        int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
                        int64_t out_stride, float* lse, int64_t lse_max_len, rpo_stream_t stream);
 
-/* Backward of rpo_flash_attn_fwd, head_dim 64 only (head_dim 128: RPO_ERR_UNSUPPORTED; the host side pairs the 128
- * forward with PyTorch's flash-attention backward on the saved output / lse) (two launches: dQ, which also computes the row constants, then dK/dV; no atomics, deterministic).  lse: f32 [num_heads][T] as written by the
- * forward with lse_max_len == 0; delta: f32 [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale, the initial accumulators of the dP and S chains).  q_tiles as in the
- * forward (q_tile_cols = its format); k_tiles: int32 [n_k_tiles][3] = (sequence id, kv head, first key of a key block); key_block = the number of
- * keys one entry stands for and thereby the dK/dV kernel that consumes the table: 256 (one wave per SIMD, entries dealt to
- * the 8 XCDs in equal eighths, padded with first key >= 2^30) or 64 (the 8-wave kernel; entries sorted by (sequence, head,
- * key)).  Any other value is RPO_ERR_UNSUPPORTED: the meaning of the table is an argument, never process-global state.
- * dq: [T, num_heads, 64], dk / dv: [T, num_kv_heads, 64] (token strides given), every valid row is written. */
+/* Backward of rpo_flash_attn_fwd, head_dim 64 or 128 (two launches: dQ, which also computes the row constants, then dK/dV; no
+ * atomics, deterministic).  lse: f32 [num_heads][T] as written by the forward with lse_max_len == 0; delta: f32
+ * [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale -- at head_dim 128 -lse log2(e) --, the initial
+ * accumulators of the dP and S chains).  q_tiles as in the forward (q_tile_cols = its format); k_tiles: int32 [n_k_tiles][3] =
+ * (sequence id, kv head, first key of a key block); key_block = the number of keys one entry stands for and thereby the dK/dV
+ * kernel that consumes the table.  head_dim 64: 256 (one wave per SIMD, entries dealt to the 8 XCDs in equal eighths, padded
+ * with first key >= 2^30) or 64 (the 8-wave kernel; entries sorted by (sequence, head, key)); head_dim 128: 128 (one wave per
+ * SIMD, 32 keys per wave; table dealt and padded like the 256 one).  Any other value is RPO_ERR_UNSUPPORTED: the meaning of
+ * the table is an argument, never process-global state.  sweep_down: head_dim 64 / key_block 256 only (ignored elsewhere).
+ * dq: [T, num_heads, hd], dk / dv: [T, num_kv_heads, hd] (token strides given), every valid row is written. */
 int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, int64_t q_stride,
                        int64_t k_stride, int64_t v_stride, int64_t out_stride, int64_t dout_stride,
                        const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles, int64_t q_tile_cols, const int* k_tiles,
