@@ -54,5 +54,26 @@ def main(path, title):
                   f"{float(r['AverageNs']) / 1e3:.2f} | {int(r['MinNs']) / 1e3:.2f} | {int(r['MaxNs']) / 1e3:.2f} |")
 
 
+def timed_region(trace_path, skip, count):
+    """From `*_kernel_trace.csv`: launches [skip, skip + count) of each hand-written attention kernel in time order = the timed
+    steps of bench.py (its pre-size and warm-up steps come first, its parity sample and sweep after), the window bench.py's own
+    HIP-event average covers."""
+    by = {}
+    for r in csv.DictReader(open(trace_path)):
+        n = r["Kernel_Name"]
+        if "fa_" in n:
+            by.setdefault(short(n), []).append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+    print(f"\n## attention kernels over the timed steps only (launches {skip}..{skip + count - 1} of each in time order, from the kernel trace)\n")
+    print("| kernel | launches | avg us | min us | max us |\n|---|---:|---:|---:|---:|")
+    tot = 0.0
+    for n, v in sorted(by.items()):
+        d = [x[1] for x in sorted(v)[skip:skip + count]]
+        tot += sum(d) / len(d) if "bwd" in n else 0.0
+        print(f"| {n} | {len(d)} | {sum(d) / len(d) / 1e3:.1f} | {min(d) / 1e3:.1f} | {max(d) / 1e3:.1f} |")
+    print(f"\nbackward entry point (dQ + dK/dV kernels) = {tot / 1e3:.1f} us per call under the profiler")
+
+
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else "rocprofv3 kernel stats")
+    if len(sys.argv) > 5:
+        timed_region(sys.argv[3], int(sys.argv[4]), int(sys.argv[5]))
