@@ -361,12 +361,16 @@ def oracle_step(w, cd, batch, temperature):
 
 def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
     """Step-loss parity on identical tokens: the cpu_baseline sample through (i) the product's fast path
-    (packed tokens, hand-written attention, fused ops, storage dtype of the run) and (ii) a CONTROL: the oracle's own eager
-    arithmetic (HF eager semantics, modeling.py:219) run in the same storage dtype on the GPU -- i.e. what the reference's
-    stock bf16 path produces from these weights.  Both are compared with the float32 oracle; the fast path passes when its
-    error is at most 1.5x the control's (the tolerance IS the reduced-precision error of the stock path, measured here,
-    not a guessed constant).  Statistics: RMS and max of the cosine errors over all [Q, P] scores, the loss, and the
-    relative error of two weight gradients."""
+    (packed tokens, hand-written attention, fused ops, storage dtype of the run) and two CONTROLS in the same storage dtype on
+    the GPU: (ii) the oracle's own eager arithmetic (HF eager semantics, modeling.py:219), and (iii) the same encoder with
+    PyTorch's stock flash-attention kernels both ways (`hand_attention = False`) -- the reference trains with
+    attn_implementation="flash_attention_2" (scripts/train/run_contrastive.sh), and every flash-attention backward takes
+    delta = rowsum(dO o O) from the bf16-ROUNDED output where eager autograd sums P dP inside the softmax backward, which
+    shows on the q / k projection gradients only (`tools/grad_error_map.py`: 0.016-0.023 there against eager's 0.009, the
+    same with PyTorch's kernels as with the hand-written ones).  All three are compared with the float32 oracle; the fast
+    path passes when its error is at most 1.5x the LARGER control error (the tolerance IS the reduced-precision error of
+    the stock paths, measured here, not a guessed constant).  Statistics: RMS and max of the cosine errors over all [Q, P]
+    scores, the loss, and the relative error of two weight gradients."""
     from oracle import encoder_ref as E
     dev_batch = {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in sample_batch.items()}
     names = list(ref["grads"])
@@ -381,13 +385,24 @@ def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
             out["grad_rel_err:" + n] = float((grads[n].float().cpu() - gr).norm() / gr.norm().clamp_min(1e-30))
         return out
 
-    out = model(**dev_batch)
-    got = torch.autograd.grad(out["loss"], [params[n] for n in names]) if names else ()   # .grad buffers stay untouched
-    fast = stats(out["loss"].detach(), out["scores"].detach(), dict(zip(names, got)))
+    def product_run():
+        out = model(**dev_batch)
+        got = torch.autograd.grad(out["loss"], [params[n] for n in names]) if names else ()   # .grad buffers stay untouched
+        return stats(out["loss"].detach(), out["scores"].detach(), dict(zip(names, got)))
+
+    fast = product_run()
+    controls = {}
+    if getattr(model.model, "hand_attention", False) and dtype == torch.bfloat16:
+        model.model.hand_attention = False
+        try:
+            controls["control_stock_flash"] = product_run()
+        finally:
+            model.model.hand_attention = True
     wd = {k: v.detach().to(device, dtype).requires_grad_(k in names) for k, v in model.model.state_dict().items()}
     loss_c, s_c = E.contrastive_step(wd, cfg.to_dict(), dev_batch, temperature, dtype=dtype)[:2]
     got_c = torch.autograd.grad(loss_c, [wd[n] for n in names]) if names else ()
-    ctrl = stats(loss_c.detach(), s_c.detach(), dict(zip(names, got_c)))
+    controls["control_stock_eager"] = stats(loss_c.detach(), s_c.detach(), dict(zip(names, got_c)))
+    ctrl = {k: max(c[k] for c in controls.values()) for k in controls["control_stock_eager"] if k != "loss"}
     # floors: float32 round-off (both paths are then ~1e-7 on a cosine and the ratio of two round-off errors means nothing).
     # The MAX over a few hundred scores built from a few dozen embeddings is an extreme-value statistic of two independent
     # rounding-error samples: it gets a factor 2, the RMS and the other aggregates 1.5 (a first version used 1.5 on the max
@@ -398,11 +413,12 @@ def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
         tol["grad_rel_err:" + n] = 1.5 * ctrl["grad_rel_err:" + n] + 1e-4
     failed = [k for k, t in tol.items() if not fast[k] <= t]
     rnd = lambda d: {k: round(v, 7) for k, v in d.items()}
-    return {"oracle_f32_loss": round(ref["loss"], 6), "fast_path": rnd(fast), "control_stock_eager": rnd(ctrl),
+    return {"oracle_f32_loss": round(ref["loss"], 6), "fast_path": rnd(fast), **{k: rnd(v) for k, v in controls.items()},
             "tolerance": rnd(tol), "pass": not failed, "failed": failed,
-            "rule": "fast-path error <= 1.5 x the error of the stock eager path in the same storage dtype (2 x for the max "
-                    "cosine error, an extreme-value statistic), both against the float32 oracle on the same tokens and "
-                    "weights (loss: 1.5 x max(control loss error, control cosine RMS error / T))"}
+            "rule": "fast-path error <= 1.5 x the larger error of the stock paths in the same storage dtype (eager attention; "
+                    "PyTorch's flash-attention kernels) (2 x for the max cosine error, an extreme-value statistic), all "
+                    "against the float32 oracle on the same tokens and weights (loss: 1.5 x max(control loss error, control "
+                    "cosine RMS error / T))"}
 
 
 class _StdoutToStderr:

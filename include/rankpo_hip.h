@@ -235,8 +235,8 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
 
 /* Backward of rpo_flash_attn_fwd, head_dim 64 or 128 (two launches: dQ, which also computes the row constants, then dK/dV; no
  * atomics, deterministic).  lse: f32 [num_heads][T] as written by the forward with lse_max_len == 0; delta: f32
- * [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale -- at head_dim 128 -lse log2(e) --, the initial
- * accumulators of the dP and S chains).  q_tiles as in the forward (q_tile_cols = its format); k_tiles: int32 [n_k_tiles][3] =
+ * [2][num_heads][T] scratch (written here: -rowsum(dout * out) and -lse / scale, the initial accumulators of the dP and S
+ * chains).  q_tiles as in the forward (q_tile_cols = its format); k_tiles: int32 [n_k_tiles][3] =
  * (sequence id, kv head, first key of a key block); key_block = the number of keys one entry stands for and thereby the dK/dV
  * kernel that consumes the table.  head_dim 64: 256 (one wave per SIMD, entries dealt to the 8 XCDs in equal eighths, padded
  * with first key >= 2^30) or 64 (the 8-wave kernel; entries sorted by (sequence, head, key)); head_dim 128: 128 (one wave per

@@ -582,9 +582,9 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
 // MFMA chains: nd[h][t] = -delta = -sum_d dO O and nl[h][t] = -lse / scale, so that S' = Q K^T - lse / scale gives
 // p = exp2(scale log2(e) S') with no subtraction, and dP' = dO V^T - delta is dS / (p scale) as it leaves the chain.  The dQ kernel
 // computes them in its prologue and writes them for the dK/dV kernel (round 1: a separate fa_delta_kernel, 0.32 ms per call).
-// The dQ kernel itself goes one step further: its block-resident Q fragments are multiplied by scale log2(e) once (re-rounded to
-// bf16: the exponent moves by ~1e-3 at |s| = 10, below the bf16 rounding of p) and its S chain starts from -lse log2(e), so
-// the chain's result IS the exponent: one multiplication per score less (backward entry point 7.45 -> 7.34 ms).
+// (Tried and dropped: block-resident Q fragments pre-multiplied by scale log2(e) and re-rounded to bf16, so that the chain's
+// result is the exponent itself -- one multiplication per score less, backward 7.45 -> 7.34 ms, but the extra rounding of Q
+// doubles the error of dQ at a logit spread of 3: 0.0066 instead of 0.0033 relative L2, `tools/fa_accuracy.py`.)
 
 // K / V tiles: the same LDS-DMA ring as the forward kernel.
 constexpr int kDqTile = kKvTile;
@@ -634,24 +634,12 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
         }
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
-        const float lse_q = ok ? lse[(int64_t)h * T + t0 + qi] : 0.f;
-        lq[n] = -lse_q * 1.44269504088896f;
+        lq[n] = ok ? -lse[(int64_t)h * T + t0 + qi] / scale : 0.f;
         dl[n] = ok ? -part : 0.f;
         if (ok && g == 0) {
-            nl_out[(int64_t)h * T + t0 + qi] = -lse_q / scale;
+            nl_out[(int64_t)h * T + t0 + qi] = lq[n];
             nd_out[(int64_t)h * T + t0 + qi] = dl[n];
         }
-        // Q carries scale log2(e) from here on (one rounding to bf16 per element, once per block): S' leaves its MFMA chain as
-        // the exponent of exp2 itself, no multiplication per score
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const unsigned w = pack_bf16(bf16_to_f32((bf16_t)bq[n][ks][e]) * scale_log2e,
-                                             bf16_to_f32((bf16_t)bq[n][ks][e + 1]) * scale_log2e);
-                bq[n][ks][e] = (short)(w & 0xffff);
-                bq[n][ks][e + 1] = (short)(w >> 16);
-            }
     }
     const int last_q = min(q0 + kFaBM - 1, len - 1);
     const int nkt = last_q / kFaBN + 1;
@@ -757,7 +745,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float pv = __builtin_amdgcn_exp2f(s[m][n][r]);
+                            float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
                             const int key = kbase + 16 * m + r;
                             pv = (key > qi || key >= len || qi >= len) ? 0.f : pv;
                             s[m][n][r] = pv * dp[m][n][r];                // dS / scale (scale: epilogue)
@@ -770,7 +758,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            s[m][n][r] = __builtin_amdgcn_exp2f(s[m][n][r]) * dp[m][n][r];
+                            s[m][n][r] = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e) * dp[m][n][r];
             }
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -2403,14 +2391,14 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
 // head_dim 128 backward (round 2; the Llama-3-8B architecture, BASELINE configs[4]).  Same two-launch, atomic-free scheme as at
 // head_dim 64, on the forward's 256-byte LDS rows (chunk ^= 2 (row & 7), 1-KiB DMA piece = 4 rows):
 //   fa_bwd_dq128_kernel    block = 128 queries of one (sequence, head), key tiles of 32 (the forward's (K | V) ring):
-//                          S^T = K Q'^T - lse log2(e) (Q' = Q scale log2(e), re-rounded once per block), dP^T = V dO^T - delta,
-//                          dS^T = exp2(S^T) dP^T, dQ^T += K^T dS^T (K^T by transposed reads of the SAME K image); 48 MFMAs per tile.
+//                          S^T = K Q^T - lse / scale, dP^T = V dO^T - delta, dS^T = exp2(scale log2(e) S^T) dP^T,
+//                          dQ^T += K^T dS^T (K^T by transposed reads of the SAME K image); 48 MFMAs per tile.
 //                          Prologue: delta and the two row constants, written for the dK/dV kernel.
 //   fa_bwd_dkdv128_kernel  block = 4 waves = 128 keys of one (sequence, kv head), ONE wave per SIMD: wave w owns keys
-//                          [32 w, 32 w + 32) -- K' = K scale log2(e) and V fragments (64 registers) and the dK^T / dV^T
+//                          [32 w, 32 w + 32) -- its K and V fragments (64 registers) and the dK^T / dV^T
 //                          accumulators (128) never leave the register file, no cross-wave sum -- and the block sweeps the
 //                          group's q heads x 32-row query slices (Q | dO | 64 row constants = 16.25 KiB by LDS-DMA, ring of 3):
-//                          S = Q K'^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS; 64 MFMAs per slice and wave.
+//                          S = Q K^T, dP = dO V^T, dV^T += dO^T P, dK^T += Q^T dS; 64 MFMAs per slice and wave.
 // Both are hipcc-scheduled (no hand-placed stream): 2.0x PyTorch's op on cfg 5's shape, see DESIGN.md.
 // ------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
@@ -2451,21 +2439,12 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
         part += __shfl_xor(part, 16, 64);
         part += __shfl_xor(part, 32, 64);
         const float lse_q = ok ? lse[(int64_t)h * T + t0 + qi] : 0.f;
-        lq[n] = -lse_q * 1.44269504088896f;
+        lq[n] = -lse_q / scale;
         dl[n] = ok ? -part : 0.f;
         if (ok && g == 0) {
-            nl_out[(int64_t)h * T + t0 + qi] = lq[n];                       // head_dim 128: -lse log2(e) (dK/dV scales K, not S)
+            nl_out[(int64_t)h * T + t0 + qi] = lq[n];
             nd_out[(int64_t)h * T + t0 + qi] = dl[n];
         }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const unsigned w = pack_bf16(bf16_to_f32((bf16_t)bq[n][ks][e]) * scale_log2e,
-                                             bf16_to_f32((bf16_t)bq[n][ks][e + 1]) * scale_log2e);
-                bq[n][ks][e] = (short)(w & 0xffff);
-                bq[n][ks][e + 1] = (short)(w >> 16);
-            }
     }
     const int last_q = min(q0 + kFaBM - 1, len - 1);
     const int nkt = last_q / kFa128BN + 1;
@@ -2564,7 +2543,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float pv = __builtin_amdgcn_exp2f(s[m][n][r]);
+                            float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
                             const int key = kbase + 16 * m + r;
                             pv = (key > qi || key >= len || qi >= len) ? 0.f : pv;
                             s[m][n][r] = pv * dp[m][n][r];
@@ -2576,7 +2555,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
 #pragma unroll
                     for (int m = 0; m < 2; ++m)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) s[m][n][r] = __builtin_amdgcn_exp2f(s[m][n][r]) * dp[m][n][r];
+                        for (int r = 0; r < 4; ++r) s[m][n][r] = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e) * dp[m][n][r];
             }
             short8_t dsf[2];                              // k-slots = keys {4g + j, 16 + 4g + (j - 4)} of the tile
 #pragma unroll
@@ -2612,7 +2591,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
 }
 
 constexpr int kD128Sl = 32;                                        // query rows per slice
-constexpr int kD128Img = 2 * kD128Sl * kFa128Row + 256;            // Q | dO | 32 x -lse log2(e) | 32 x -delta = 16640 B
+constexpr int kD128Img = 2 * kD128Sl * kFa128Row + 256;            // Q | dO | 32 x -lse / scale | 32 x -delta = 16640 B
 constexpr int kD128Keys = 128;                                     // keys per block (4 waves x 32)
 
 __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
@@ -2650,7 +2629,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
         }
     }
     // staging: wave w moves rows 8w .. 8w + 7 of the Q and of the dO slice (two 1-KiB pieces of 4 rows each); wave 0 also the 64
-    // row constants (lanes 0..31: -lse log2(e), lanes 32..63: -delta)
+    // row constants (lanes 0..31: -lse / scale, lanes 32..63: -delta)
     const int srow = lane >> 4;
     const unsigned sqb = (unsigned)sq * 2u, sdob = (unsigned)sdo * 2u;
     const float* rc_src = lane < 32 ? nl : nd;
@@ -2684,21 +2663,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
     };
     stage_next();
     if (niter > 1) stage_next();
-    // K carries scale log2(e) from here on (one rounding to bf16 per element, once per block): S' = Q K'^T - lse log2(e) is the
-    // exponent of exp2 itself.  Touching the fragments here also puts hipcc's wait for their loads in front of the loop.
+    // touching the fragments here puts hipcc's wait for their loads in front of the loop
 #pragma unroll
     for (int n = 0; n < 2; ++n)
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int e = 0; e < 8; e += 2) {
-                const unsigned w = pack_bf16(bf16_to_f32((bf16_t)bk[n][ks][e]) * scale_log2e,
-                                             bf16_to_f32((bf16_t)bk[n][ks][e + 1]) * scale_log2e);
-                bk[n][ks][e] = (short)(w & 0xffff);
-                bk[n][ks][e + 1] = (short)(w >> 16);
-            }
-            asm volatile("" : "+v"(bk[n][ks]), "+v"(bv[n][ks]));
-        }
+        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(bk[n][ks]), "+v"(bv[n][ks]));
     // dV^T / dK^T accumulators [hd tile c][key tile n] (rows = hd 16c + 4g + r, col = key 16n + fr) live in LITERAL accumulator
     // registers for the whole kernel: dV^T[c][n] = a[8c + 4n : + 3], dK^T[c][n] = a[64 + 8c + 4n : + 3].  As C++ variables (MFMA builtin, or
     // asm with "+a" operands) hipcc carries them through the loop in VGPRs and copies all 128 to the accumulator file and back in
@@ -2832,7 +2801,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
                         const int key = k0 + 16 * n + fr;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            float pv = __builtin_amdgcn_exp2f(s[m][n][r]);
+                            float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
                             pv = (key > qr0 + r || key >= len || qr0 + r >= len) ? 0.f : pv;
                             s[m][n][r] = pv;
                             dp[m][n][r] = pv * dp[m][n][r];
@@ -2846,7 +2815,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
                     for (int n = 0; n < 2; ++n)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const float pv = __builtin_amdgcn_exp2f(s[m][n][r]);
+                            const float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
                             s[m][n][r] = pv;
                             dp[m][n][r] = pv * dp[m][n][r];
                         }
@@ -3074,7 +3043,7 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     float* nd = delta;                                       // scratch [2][num_heads][T]: -delta | -lse / scale
     float* nl = delta + num_heads * total_tokens;
     // (round 1 launched fa_delta_kernel here; the dQ kernel now computes and writes both row constants itself)
-    if (head_dim == kFa128HD) {                              // nl = -lse log2(e) here: the dK/dV kernel scales K, not S
+    if (head_dim == kFa128HD) {
         RPO_LAUNCH(fa_bwd_dq128_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads),
                    0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
                    dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,

@@ -388,6 +388,8 @@ class LlamaEncoder(nn.Module):
         self.gradient_checkpointing = False
         self.checkpoint_layers = None      # None = all layers when gradient_checkpointing, else the first k
         self.pack_fill = True              # packed path: round the token count up to a multiple of 256 with a filler sequence
+        self.hand_attention = True         # False: PyTorch's own flash-attention ops both ways (the "stock flash" control of
+        #                                    bench.step_parity; a Python attribute, not an environment switch)
         self.apply(self._init)
 
     def _init(self, m):
@@ -522,7 +524,8 @@ class LlamaEncoder(nn.Module):
         cu = torch.zeros(N + 1, dtype=torch.int32, device=x.device)
         cu[1:] = torch.tensor(lens, dtype=torch.int64).cumsum(0).to(torch.int32).to(x.device, non_blocking=True)
         tiles = k_tiles = None
-        if x.is_cuda and self.config.head_dim in (64, 128) and x.dtype == torch.bfloat16:     # hand-written flash attention
+        if (x.is_cuda and self.config.head_dim in (64, 128) and x.dtype == torch.bfloat16
+                and self.hand_attention):                                                        # hand-written flash attention
             tiles = _ops.attn_tile_table(lens, x.device, self.config.num_attention_heads, self.config.num_key_value_heads)
             if torch.is_grad_enabled():
                 k_tiles = _ops.attn_key_tile_table(

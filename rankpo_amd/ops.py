@@ -646,7 +646,7 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
         for t, h in ((dq, nh), (dk, nkv), (dv, nkv)):
             if t.shape != (T, h, hd) or t.stride(2) != 1 or t.stride(1) != hd or t.dtype != q.dtype:
                 raise ValueError("flash_attn_varlen_bwd: gradient views must be [T, heads, head_dim] with contiguous heads")
-    delta = torch.empty((2, nh, T), dtype=torch.float32, device=q.device)     # scratch: -delta | -lse / scale (hd 128: -lse log2 e)
+    delta = torch.empty((2, nh, T), dtype=torch.float32, device=q.device)     # scratch: -delta | -lse / scale
     with torch.cuda.device(q.device):
         check(lib.rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), dout.data_ptr(),
                                      q.stride(0), k.stride(0), v.stride(0), out.stride(0), dout.stride(0),

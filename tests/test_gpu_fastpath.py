@@ -1,11 +1,12 @@
-"""Gated parity of the EXACT encoder path bench.py times (reference modeling.py:206-238, 278-314): head_dim 64,
-bf16, query + passage batches in ONE packed pass (`pooled_last_token_multi`), the fused q|k|v flash attention
+"""Gated parity of the EXACT encoder path bench.py times (reference modeling.py:206-238, 278-314): head_dim 64
+(cfg 2) and 128 with checkpointed blocks (cfg 5), bf16, query + passage batches in ONE packed pass (`pooled_last_token_multi`), the fused q|k|v flash attention
 (`flash_attn_varlen_qkv`), the last block on the pooled rows only (`forward_last_rows`) and the filler sequence that rounds
 the packed token count up to a multiple of 256 (needs >= 4096 packed tokens).
 
-The tolerance is not a guessed constant: the same tokens and weights also go through a CONTROL -- the oracle's eager
-arithmetic (HF eager semantics) in bf16 on the GPU, i.e. the reference's stock reduced-precision path -- and the fast path
-must be no further from the float32 oracle than 1.5x the control (2x on the max cosine error, an extreme-value statistic;
+The tolerance is not a guessed constant: the same tokens and weights also go through two CONTROLS -- the oracle's eager
+arithmetic (HF eager semantics) in bf16 on the GPU, and the same encoder with PyTorch's stock flash-attention kernels (the
+reference trains with flash_attention_2) -- and the fast path must be no further from the float32 oracle than 1.5x the larger
+control error (2x on the max cosine error, an extreme-value statistic;
 `bench.step_parity`, the same rule the bench line's
 `step_loss_parity` asserts).  Also here: left-padded / holed masks through the product's `embed` (a2's reference edge case).
 """
@@ -22,10 +23,10 @@ DEV = "cuda:0"
 T_CONTRASTIVE = 0.02
 
 
-def _cfg(PE):
-    # head_dim 64, GQA 8 / 2, llama3 rope scaling: the cfg-2 block at 1/4 width and 1/4 depth
+def _cfg(PE, hd=64):
+    # head_dim 64, GQA 8 / 2, llama3 rope scaling: the cfg-2 block at 1/4 width and 1/4 depth; head_dim 128 (4 / 2 heads): cfg 5's
     return PE.llama_config(vocab_size=2048, hidden_size=512, intermediate_size=1024, num_hidden_layers=4,
-                           num_attention_heads=8, num_key_value_heads=2, head_dim=64, pad_token_id=0,
+                           num_attention_heads=512 // hd, num_key_value_heads=2, head_dim=hd, pad_token_id=0,
                            rope_scaling=dict(PE.LLAMA3_ROPE, original_max_position_embeddings=128))
 
 
@@ -51,18 +52,22 @@ def _batch():
     return b, tot
 
 
-def _model(PE, rankpo_amd, seed=0):
+def _model(PE, rankpo_amd, seed=0, hd=64):
     torch.manual_seed(seed)
-    cfg = _cfg(PE)
+    cfg = _cfg(PE, hd)
     enc = PE.LlamaEncoder(cfg).to(DEV).to(torch.bfloat16)
     return cfg, enc, rankpo_amd.ModelForTraining(encoder=enc, temperature=T_CONTRASTIVE).train()
 
 
-def test_bench_path_parity_hd64_bf16_packed_filler():
+@pytest.mark.parametrize("hd,ckpt", [(64, False), (128, True)])
+def test_bench_path_parity_bf16_packed_filler(hd, ckpt):
+    """hd 64: the path of the headline number (cfg 2, no block checkpointed); hd 128 + every block checkpointed: cfg 5's."""
     import rankpo_amd
     from rankpo_amd import encoder as PE, ops
     bench = importlib.import_module("bench")
-    cfg, enc, model = _model(PE, rankpo_amd)
+    cfg, enc, model = _model(PE, rankpo_amd, hd=hd)
+    if ckpt:
+        model.gradient_checkpointing_enable()
     batch, tot = _batch()
 
     # spies: the branches under test must be the ones that run
@@ -74,11 +79,11 @@ def test_bench_path_parity_hd64_bf16_packed_filler():
         return real_qkv(qkv, *a, **kw)
 
     def spy_last(self, *a, **kw):
-        seen["last_rows"] += 1
+        seen["last_rows"] += int(enc.hand_attention)          # (step_parity's stock-flash control run is not counted)
         return real_last(self, *a, **kw)
 
     def spy_multi(batches):
-        seen["multi"] += len(batches)
+        seen["multi"] += len(batches) * int(enc.hand_attention)
         return real_multi(batches)
     ops.flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows, enc.pooled_last_token_multi = spy_qkv, spy_last, spy_multi
     try:
@@ -90,8 +95,9 @@ def test_bench_path_parity_hd64_bf16_packed_filler():
         enc.pooled_last_token_multi = real_multi
     print("\nfast path parity:", rep)
     padded_T = (tot + 255) // 256 * 256
-    assert seen["multi"] == 2 and seen["last_rows"] == 1
-    assert seen["qkv_T"] == [padded_T] * (cfg.num_hidden_layers - 1), (seen, tot)      # filler fired, every full block fused
+    assert seen["multi"] == 2 and seen["last_rows"] == (2 if ckpt else 1)      # the checkpointed last block is recomputed too
+    # filler fired, every full block ran the fused attention (a checkpointed block runs it again in its recomputation)
+    assert seen["qkv_T"] == [padded_T] * ((cfg.num_hidden_layers - 1) * (2 if ckpt else 1)), (seen, tot)
     assert rep["pass"], rep
     # absolute sanity next to the relative rule: a bf16 encoder is still within a few 1e-3 of the f32 cosine
     assert rep["fast_path"]["cos_max_err"] < 2e-2
