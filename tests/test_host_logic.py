@@ -257,6 +257,16 @@ def _forward_worker(rank, world, port, ret):
         chk = red.flat.clone()
         dist.all_reduce(chk, op=dist.ReduceOp.MAX)
         ok = ok and torch.equal(chk, red.flat)
+        # RankPOTrainer.resolve_metrics: ONE all-reduce of the 9-metric vector = the reference's nine
+        # gather_for_metrics(x).mean() calls over equal per-rank batches (rankpo_trainer.py:496-520); sft_loss is dropped
+        # when its weight is 0, key order as the reference builds its dict
+        from rankpo_amd.rankpo_trainer import METRIC_KEYS
+        tr = rankpo_amd.RankPOTrainer(PE.LlamaEncoder(cfg), None, reference_free=True, rankpo_weight=1.0, sft_weight=0.0)
+        mvec = torch.arange(len(METRIC_KEYS), dtype=torch.float32) + 10.0 * rank
+        got = tr.resolve_metrics(("eval_", mvec))
+        want = {f"eval_{k}": i + 10.0 * (world - 1) / 2 for i, k in enumerate(METRIC_KEYS) if k != "sft_loss"}
+        ok = ok and list(got) == list(want) and all(abs(got[k] - want[k]) < 1e-6 for k in want)
+        ok = ok and torch.equal(mvec, torch.arange(len(METRIC_KEYS), dtype=torch.float32) + 10.0 * rank)   # caller's vector untouched
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
@@ -389,12 +399,13 @@ def test_key_block_table_properties():
     entries that the kernel skips."""
     from rankpo_amd import ops
     rs = np.random.RandomState(0)
-    for nkv, lens in ((8, rs.randint(1, 4097, size=37).tolist()), (2, [5, 300, 257, 256, 1]), (1, [1000])):
-        t = ops.attn_key_tile_table(lens, "cpu", nkv).numpy()
+    for bn, nkv, lens in ((256, 8, rs.randint(1, 4097, size=37).tolist()), (256, 2, [5, 300, 257, 256, 1]), (256, 1, [1000]),
+                          (128, 8, rs.randint(1, 4097, size=23).tolist()), (128, 2, [5, 300, 129, 128, 1])):   # 128: head_dim 128
+        t = ops.attn_key_tile_table(lens, "cpu", nkv, block_n=bn).numpy()
         assert t.shape[0] % 8 == 0
         per = t.shape[0] // 8
         real = t[t[:, 2] < (1 << 30)]
-        want = {(s, h, k) for s, n in enumerate(lens) for h in range(nkv) for k in range(0, n, 256)}
+        want = {(s, h, k) for s, n in enumerate(lens) for h in range(nkv) for k in range(0, n, bn)}
         assert len(real) == len(want) and set(map(tuple, real.tolist())) == want
         owner = {}
         for x in range(8):
