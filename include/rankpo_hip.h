@@ -242,13 +242,18 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
  * with first key >= 2^30) or 64 (the 8-wave kernel; entries sorted by (sequence, head, key)); head_dim 128: 128 (one wave per
  * SIMD, 32 keys per wave; table dealt and padded like the 256 one).  Any other value is RPO_ERR_UNSUPPORTED: the meaning of
  * the table is an argument, never process-global state.  sweep_down: head_dim 64 / key_block 256 only (ignored elsewhere).
- * dq: [T, num_heads, hd], dk / dv: [T, num_kv_heads, hd] (token strides given), every valid row is written. */
+ * dq: [T, num_heads, hd], dk / dv: [T, num_kv_heads, hd] (token strides given), every valid row is written.
+ * rope_cos / rope_sin (both NULL, or both f32 [rope_period][hd / 2], 16-byte aligned; token t uses row t % rope_period; the
+ * tables rpo_rope rotated q and k with): dq and dk then leave as the gradients w.r.t. the PRE-rotary q / k -- the inverse
+ * rotation of rpo_rope(backward = 1) applied in the kernels' epilogues in f32 before the one rounding to bf16, instead of a
+ * separate pass over d(q|k).  Not offered with key_block 64 (RPO_ERR_UNSUPPORTED). */
 int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, int64_t q_stride,
                        int64_t k_stride, int64_t v_stride, int64_t out_stride, int64_t dout_stride,
                        const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles, int64_t q_tile_cols, const int* k_tiles,
                        int64_t n_k_tiles, int64_t key_block, int64_t sweep_down, int64_t total_tokens, int64_t num_heads,
                        int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta, void* dq, void* dk, void* dv,
-                       int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, rpo_stream_t stream);
+                       int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, const float* rope_cos, const float* rope_sin,
+                       int64_t rope_period, rpo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (8) exact top-k over score rows, merged chunk by chunk ("next" row f3: the k-selection of faiss.IndexFlatIP.search,

@@ -81,6 +81,21 @@ __device__ __forceinline__ short8_t join_tr(const u32x2& lo, const u32x2& hi) {
     return __builtin_bit_cast(short8_t, w);
 }
 
+// Inverse rotary embedding folded into the backward epilogues (round 2): the attention backward is asked for the gradients
+// w.r.t. the PRE-rotary q / k (y1 = x1 cos - x2 sin, y2 = x2 cos + x1 sin with (x1, x2) = (x[j], x[j + hd / 2]), HF layout) ->
+// dx1 = dy1 cos + dy2 sin, dx2 = dy2 cos - dy1 sin.  In every dQ^T / dK^T accumulator layout of this file a lane holds rows j
+// and j + hd / 2 of the same token (hd tiles c and c + 2 at head_dim 64, c and c + 4 at 128), so the rotation is lane-local,
+// in f32, BEFORE the one rounding to bf16 (the separate rpo_rope pass re-read the rounded gradient and rounded it again, and
+// moved 0.28 ms of HBM traffic per block on cfg 2).  cos / sin: f32 [period][hd / 2], token t uses row t % period.
+__device__ __forceinline__ void inv_rope4(float4_t& lo, float4_t& hi, const float4_t& c, const float4_t& sn) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float a = lo[r], b = hi[r];
+        lo[r] = fmaf(a, c[r], b * sn[r]);
+        hi[r] = fmaf(b, c[r], -(a * sn[r]));
+    }
+}
+
 // Query-tile work list, two formats (`tcols`, an argument of the C entry points):
 //   2: int32 [n][2] = (sequence id, first query row), heaviest tiles first; grid = (n, heads), the head is blockIdx.y.
 //   3: int32 [n][3] = (sequence id, first query row, head), n % 8 == 0, grid = (n): block b takes entry (b & 7) * n / 8 + (b >> 3),
@@ -594,7 +609,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
     const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e, float scale,
     const float* __restrict__ lse, const bf16_t* __restrict__ o, int64_t so, float* __restrict__ nl_out,
-    float* __restrict__ nd_out, int64_t T, bf16_t* __restrict__ dq, int64_t sdq) {
+    float* __restrict__ nd_out, int64_t T, bf16_t* __restrict__ dq, int64_t sdq, const float* __restrict__ rcos,
+    const float* __restrict__ rsin, int64_t rperiod) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kDqTile];      // ring of (K tile | V tile), chunk ^= row & 7
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -791,10 +807,19 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
         if (qi >= len) continue;
         bf16_t* row = dq + (t0 + qi) * sdq + h * kFaHD;
 #pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c][n] *= scale;
+        if (rcos) {                                         // rows 16c + 4g + r pair with 16 (c + 2) + 4g + r
+            const int64_t tr = ((t0 + qi) % rperiod) * (kFaHD / 2) + 4 * g;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                inv_rope4(acc[c][n], acc[c + 2][n], *reinterpret_cast<const float4_t*>(rcos + tr + 16 * c),
+                          *reinterpret_cast<const float4_t*>(rsin + tr + 16 * c));
+        }
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint2 w;
-            w.x = pack_bf16(acc[c][n][0] * scale, acc[c][n][1] * scale);
-            w.y = pack_bf16(acc[c][n][2] * scale, acc[c][n][3] * scale);
+            w.x = pack_bf16(acc[c][n][0], acc[c][n][1]);
+            w.y = pack_bf16(acc[c][n][2], acc[c][n][3]);
             *reinterpret_cast<uint2*>(row + 16 * c + 4 * g) = w;
         }
     }
@@ -1662,7 +1687,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
     const int* __restrict__ ktiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ nl,
     const float* __restrict__ nd, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
-    int64_t sdv, int n_ktiles, int gshift) {
+    int64_t sdv, int n_ktiles, int gshift, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2375,10 +2400,19 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
         bf16_t* krow = dk + (t0 + key) * sdk + hk * kFaHD + 4 * g;
         bf16_t* vrow = dv + (t0 + key) * sdv + hk * kFaHD + 4 * g;
 #pragma unroll
+        for (int c = 0; c < 4; ++c) dka[c][n] *= scale;
+        if (rcos) {                                         // dK w.r.t. the pre-rotary k (inv_rope4)
+            const int64_t tr = ((t0 + key) % rperiod) * (kFaHD / 2) + 4 * g;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                inv_rope4(dka[c][n], dka[c + 2][n], *reinterpret_cast<const float4_t*>(rcos + tr + 16 * c),
+                          *reinterpret_cast<const float4_t*>(rsin + tr + 16 * c));
+        }
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
             uint2 w;
-            w.x = pack_bf16(dka[c][n][0] * scale, dka[c][n][1] * scale);
-            w.y = pack_bf16(dka[c][n][2] * scale, dka[c][n][3] * scale);
+            w.x = pack_bf16(dka[c][n][0], dka[c][n][1]);
+            w.y = pack_bf16(dka[c][n][2], dka[c][n][3]);
             *reinterpret_cast<uint2*>(krow + 16 * c) = w;
             w.x = pack_bf16(dva[c][n][0], dva[c][n][1]);
             w.y = pack_bf16(dva[c][n][2], dva[c][n][3]);
@@ -2406,7 +2440,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
     const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e, float scale,
     const float* __restrict__ lse, const bf16_t* __restrict__ o, int64_t so, float* __restrict__ nl_out,
-    float* __restrict__ nd_out, int64_t T, bf16_t* __restrict__ dq, int64_t sdq) {
+    float* __restrict__ nd_out, int64_t T, bf16_t* __restrict__ dq, int64_t sdq, const float* __restrict__ rcos,
+    const float* __restrict__ rsin, int64_t rperiod) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kKvTile];      // ring of (K tile | V tile), 256-byte rows, 32 keys
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2581,10 +2616,19 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
         if (qi >= len) continue;
         bf16_t* row = dq + (t0 + qi) * sdq + h * kFa128HD;
 #pragma unroll
+        for (int c = 0; c < 8; ++c) acc[c][n] *= scale;
+        if (rcos) {                                         // rows 16c + 4g + r pair with 16 (c + 4) + 4g + r
+            const int64_t tr = ((t0 + qi) % rperiod) * (kFa128HD / 2) + 4 * g;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                inv_rope4(acc[c][n], acc[c + 4][n], *reinterpret_cast<const float4_t*>(rcos + tr + 16 * c),
+                          *reinterpret_cast<const float4_t*>(rsin + tr + 16 * c));
+        }
+#pragma unroll
         for (int c = 0; c < 8; ++c) {
             uint2 w;
-            w.x = pack_bf16(acc[c][n][0] * scale, acc[c][n][1] * scale);
-            w.y = pack_bf16(acc[c][n][2] * scale, acc[c][n][3] * scale);
+            w.x = pack_bf16(acc[c][n][0], acc[c][n][1]);
+            w.y = pack_bf16(acc[c][n][2], acc[c][n][3]);
             *reinterpret_cast<uint2*>(row + 16 * c + 4 * g) = w;
         }
     }
@@ -2599,7 +2643,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
     const int* __restrict__ ktiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ nl,
     const float* __restrict__ nd, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
-    int64_t sdv, int n_ktiles) {
+    int64_t sdv, int n_ktiles, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kD128Img];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2913,64 +2957,97 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
 #undef RPO_TR2H
     // the last MFMAs have to leave the pipe before their accumulators are read (hipcc cannot see the dependency)
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
-#define RPO_D128_OUT(B0, B1, B2, B3, DST, MUL)                                                                      \
+#define RPO_D128_RD(B0, B1, B2, B3, X)                                                                              \
     do {                                                                                                            \
         float t0_, t1_, t2_, t3_;                                                                                   \
         asm volatile("v_accvgpr_read_b32 %0, a" #B0 "\n\tv_accvgpr_read_b32 %1, a" #B1 "\n\t"                        \
                      "v_accvgpr_read_b32 %2, a" #B2 "\n\tv_accvgpr_read_b32 %3, a" #B3                              \
                      : "=v"(t0_), "=v"(t1_), "=v"(t2_), "=v"(t3_));                                                   \
-        uint2 w_;                                                                                                   \
-        w_.x = pack_bf16(t0_ * (MUL), t1_ * (MUL));                                                                 \
-        w_.y = pack_bf16(t2_ * (MUL), t3_ * (MUL));                                                                 \
-        *reinterpret_cast<uint2*>(DST) = w_;                                                                        \
+        X = float4_t{t0_, t1_, t2_, t3_};                                                                           \
     } while (0)
+    auto store4 = [](bf16_t* dst, const float4_t& x) {
+        uint2 w;
+        w.x = pack_bf16(x[0], x[1]);
+        w.y = pack_bf16(x[2], x[3]);
+        *reinterpret_cast<uint2*>(dst) = w;
+    };
     {
+        float4_t kq[8], vq[8];                          // dK^T / dV^T quads of key tile 0: rows = hd 16c + 4g + r
+        RPO_D128_RD(0, 1, 2, 3, vq[0]);
+        RPO_D128_RD(64, 65, 66, 67, kq[0]);
+        RPO_D128_RD(8, 9, 10, 11, vq[1]);
+        RPO_D128_RD(72, 73, 74, 75, kq[1]);
+        RPO_D128_RD(16, 17, 18, 19, vq[2]);
+        RPO_D128_RD(80, 81, 82, 83, kq[2]);
+        RPO_D128_RD(24, 25, 26, 27, vq[3]);
+        RPO_D128_RD(88, 89, 90, 91, kq[3]);
+        RPO_D128_RD(32, 33, 34, 35, vq[4]);
+        RPO_D128_RD(96, 97, 98, 99, kq[4]);
+        RPO_D128_RD(40, 41, 42, 43, vq[5]);
+        RPO_D128_RD(104, 105, 106, 107, kq[5]);
+        RPO_D128_RD(48, 49, 50, 51, vq[6]);
+        RPO_D128_RD(112, 113, 114, 115, kq[6]);
+        RPO_D128_RD(56, 57, 58, 59, vq[7]);
+        RPO_D128_RD(120, 121, 122, 123, kq[7]);
         const int key = k0 + 0 + fr;
         if (key < len) {
             bf16_t* krow = dk + (t0 + key) * sdk + hk * kFa128HD + 4 * g;
             bf16_t* vrow = dv + (t0 + key) * sdv + hk * kFa128HD + 4 * g;
-            RPO_D128_OUT(0, 1, 2, 3, vrow + 0, 1.0f);
-            RPO_D128_OUT(64, 65, 66, 67, krow + 0, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(8, 9, 10, 11, vrow + 16, 1.0f);
-            RPO_D128_OUT(72, 73, 74, 75, krow + 16, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(16, 17, 18, 19, vrow + 32, 1.0f);
-            RPO_D128_OUT(80, 81, 82, 83, krow + 32, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(24, 25, 26, 27, vrow + 48, 1.0f);
-            RPO_D128_OUT(88, 89, 90, 91, krow + 48, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(32, 33, 34, 35, vrow + 64, 1.0f);
-            RPO_D128_OUT(96, 97, 98, 99, krow + 64, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(40, 41, 42, 43, vrow + 80, 1.0f);
-            RPO_D128_OUT(104, 105, 106, 107, krow + 80, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(48, 49, 50, 51, vrow + 96, 1.0f);
-            RPO_D128_OUT(112, 113, 114, 115, krow + 96, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(56, 57, 58, 59, vrow + 112, 1.0f);
-            RPO_D128_OUT(120, 121, 122, 123, krow + 112, scale);          // dK = scale * dS^T Q
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kq[c] *= scale;                          // dK = scale * dS^T Q
+            if (rcos) {                                                          // ... w.r.t. the pre-rotary k (inv_rope4)
+                const int64_t tr = ((t0 + key) % rperiod) * (kFa128HD / 2) + 4 * g;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    inv_rope4(kq[c], kq[c + 4], *reinterpret_cast<const float4_t*>(rcos + tr + 16 * c),
+                              *reinterpret_cast<const float4_t*>(rsin + tr + 16 * c));
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                store4(krow + 16 * c, kq[c]);
+                store4(vrow + 16 * c, vq[c]);
+            }
         }
     }
     {
+        float4_t kq[8], vq[8];                          // dK^T / dV^T quads of key tile 1: rows = hd 16c + 4g + r
+        RPO_D128_RD(4, 5, 6, 7, vq[0]);
+        RPO_D128_RD(68, 69, 70, 71, kq[0]);
+        RPO_D128_RD(12, 13, 14, 15, vq[1]);
+        RPO_D128_RD(76, 77, 78, 79, kq[1]);
+        RPO_D128_RD(20, 21, 22, 23, vq[2]);
+        RPO_D128_RD(84, 85, 86, 87, kq[2]);
+        RPO_D128_RD(28, 29, 30, 31, vq[3]);
+        RPO_D128_RD(92, 93, 94, 95, kq[3]);
+        RPO_D128_RD(36, 37, 38, 39, vq[4]);
+        RPO_D128_RD(100, 101, 102, 103, kq[4]);
+        RPO_D128_RD(44, 45, 46, 47, vq[5]);
+        RPO_D128_RD(108, 109, 110, 111, kq[5]);
+        RPO_D128_RD(52, 53, 54, 55, vq[6]);
+        RPO_D128_RD(116, 117, 118, 119, kq[6]);
+        RPO_D128_RD(60, 61, 62, 63, vq[7]);
+        RPO_D128_RD(124, 125, 126, 127, kq[7]);
         const int key = k0 + 16 + fr;
         if (key < len) {
             bf16_t* krow = dk + (t0 + key) * sdk + hk * kFa128HD + 4 * g;
             bf16_t* vrow = dv + (t0 + key) * sdv + hk * kFa128HD + 4 * g;
-            RPO_D128_OUT(4, 5, 6, 7, vrow + 0, 1.0f);
-            RPO_D128_OUT(68, 69, 70, 71, krow + 0, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(12, 13, 14, 15, vrow + 16, 1.0f);
-            RPO_D128_OUT(76, 77, 78, 79, krow + 16, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(20, 21, 22, 23, vrow + 32, 1.0f);
-            RPO_D128_OUT(84, 85, 86, 87, krow + 32, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(28, 29, 30, 31, vrow + 48, 1.0f);
-            RPO_D128_OUT(92, 93, 94, 95, krow + 48, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(36, 37, 38, 39, vrow + 64, 1.0f);
-            RPO_D128_OUT(100, 101, 102, 103, krow + 64, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(44, 45, 46, 47, vrow + 80, 1.0f);
-            RPO_D128_OUT(108, 109, 110, 111, krow + 80, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(52, 53, 54, 55, vrow + 96, 1.0f);
-            RPO_D128_OUT(116, 117, 118, 119, krow + 96, scale);          // dK = scale * dS^T Q
-            RPO_D128_OUT(60, 61, 62, 63, vrow + 112, 1.0f);
-            RPO_D128_OUT(124, 125, 126, 127, krow + 112, scale);          // dK = scale * dS^T Q
+#pragma unroll
+            for (int c = 0; c < 8; ++c) kq[c] *= scale;                          // dK = scale * dS^T Q
+            if (rcos) {                                                          // ... w.r.t. the pre-rotary k (inv_rope4)
+                const int64_t tr = ((t0 + key) % rperiod) * (kFa128HD / 2) + 4 * g;
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    inv_rope4(kq[c], kq[c + 4], *reinterpret_cast<const float4_t*>(rcos + tr + 16 * c),
+                              *reinterpret_cast<const float4_t*>(rsin + tr + 16 * c));
+            }
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                store4(krow + 16 * c, kq[c]);
+                store4(vrow + 16 * c, vq[c]);
+            }
         }
     }
-#undef RPO_D128_OUT
+#undef RPO_D128_RD
 }
 
 }  // namespace
@@ -3022,9 +3099,13 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
                                   int64_t q_tile_cols, const int* k_tiles, int64_t n_k_tiles, int64_t key_block,
                                   int64_t sweep_down, int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta,
                                   void* dq, void* dk, void* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
-                                  rpo_stream_t stream) {
+                                  const float* rope_cos, const float* rope_sin, int64_t rope_period, rpo_stream_t stream) {
     if (!q || !k || !v || !out || !dout || !cu_seqlens || !q_tiles || !k_tiles || !lse || !delta || !dq || !dk || !dv)
         return RPO_ERR_INVALID_ARG;
+    // rope_cos / rope_sin (both or neither): dq / dk leave as gradients w.r.t. the PRE-rotary q / k (inverse rotation in the
+    // epilogues); not offered by the 8-wave dK/dV kernel (key_block 64), whose epilogue splits a row's halves over two passes
+    if ((rope_cos == nullptr) != (rope_sin == nullptr) || (rope_cos && rope_period <= 0)) return RPO_ERR_INVALID_ARG;
+    if (rope_cos && (key_block == 64 || !rpo_aligned16(rope_cos) || !rpo_aligned16(rope_sin))) return RPO_ERR_UNSUPPORTED;
     if (n_q_tiles <= 0 || n_k_tiles <= 0 || total_tokens <= 0) return RPO_ERR_INVALID_ARG;
     // `key_block` states what the entries of `k_tiles` mean: blocks of 256 keys (one-wave-per-SIMD dK/dV kernel) or of 64
     // keys (the 8-wave kernel).  The caller that built the table says so; nothing is read from the environment.
@@ -3047,19 +3128,19 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
         RPO_LAUNCH(fa_bwd_dq128_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads),
                    0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
                    dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,
-                   lse, (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride);
+                   lse, (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride, rope_cos, rope_sin, rope_period);
         const int rc128 = rpo_launch_status();
         if (rc128 != RPO_OK) return rc128;
         RPO_LAUNCH(fa_bwd_dkdv128_kernel, dim3((unsigned)(((n_k_tiles + 7) / 8) * 8)), dim3(256), 0, st, (const bf16_t*)q,
                    (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens,
                    k_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
-                   (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles);
+                   (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles, rope_cos, rope_sin, rope_period);
         return rpo_launch_status();
     }
     RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0,
                st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
                dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse,
-               (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride);
+               (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride, rope_cos, rope_sin, rope_period);
     int rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
     const unsigned dkdv_grid = (unsigned)(((n_k_tiles + 7) / 8) * 8);
@@ -3085,12 +3166,12 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
             RPO_LAUNCH(fa_bwd_dkdv4_kernel<true>, dim3(dkdv_grid), dim3(256), kDkdv4Lds, st, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
                        (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
-                       (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles, gshift);
+                       (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles, gshift, rope_cos, rope_sin, rope_period);
         else
             RPO_LAUNCH(fa_bwd_dkdv4_kernel<false>, dim3(dkdv_grid), dim3(256), kDkdv4Lds, st, (const bf16_t*)q, (const bf16_t*)k,
                        (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
                        (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
-                       (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles, gshift);
+                       (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles, gshift, rope_cos, rope_sin, rope_period);
     }
     return rpo_launch_status();
 }

@@ -170,6 +170,10 @@ class RopeTables:
         return (cos[:, None, :], sin[:, None, :]) if packed else (cos[None, None], sin[None, None])
 
 
+FOLD_ROPE = True     # packed training path: rotary + attention as ONE autograd node, inverse rotary in the dQ / dK epilogues
+#                      (False: two nodes, a separate rpo_rope pass over d(q|k) -- the A/B arm of `bench.py --no-fold-rope`)
+
+
 class VarlenCtx:
     """cu_seqlens (int32, device), the host copy of the lengths and the longest length of a packed batch."""
 
@@ -280,13 +284,20 @@ class LlamaAttention(nn.Module):
         nq, nk = self.nh * self.hd, self.nkv * self.hd
         qkv = self._fused(x, (self.q_proj, self.k_proj, self.v_proj))            # [N, L, nq + 2 nk]
         fused = _ops.fused_encoder_ops_ok(x, self.hd)
+        if (isinstance(attn_mask, VarlenCtx) and fused and attn_mask.k_tiles is not None and self.hd in (64, 128)
+                and x.dtype == torch.bfloat16 and FOLD_ROPE):
+            # training on packed tokens: rotary + attention as one autograd node -- the rotary pass runs in place on the
+            # projection output, attention reads q / k / v as its column blocks, and the backward writes ONE d(q|k|v)
+            # buffer (no split / cat copies) with the inverse rotation already applied in the dQ / dK epilogues
+            o = _ops.rope_flash_attn_varlen_qkv(qkv, rope.cos32, rope.sin32, self.nh, self.nkv, attn_mask.cu,
+                                                attn_mask.tiles, attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd)
+            return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
         if fused:       # one in-place HIP pass over the q and k heads instead of neg / cat / 2 mul / add per tensor
             qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd, grad_inplace=True)
         q, k, v = qkv.split([nq, nk, nk], dim=-1)
         if (isinstance(attn_mask, VarlenCtx) and fused and attn_mask.k_tiles is not None and self.hd in (64, 128)
                 and x.dtype == torch.bfloat16):
-            # training on packed tokens: attention reads q / k / v as column blocks of the projection output and its
-            # backward writes one d(q|k|v) buffer (no split / cat copies)
+            # A/B arm (FOLD_ROPE = False): the rotary pass and the attention as two autograd nodes
             o = _ops.flash_attn_varlen_qkv(qkv.view(L, -1), self.nh, self.nkv, attn_mask.cu, attn_mask.tiles,
                                            attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd)
             return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)

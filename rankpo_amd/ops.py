@@ -627,11 +627,17 @@ def _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order=False)
 
 
 def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale, grads=None,
-                          key_block: int = ATTN_KEY_BLOCK, sweep_down=None):
+                          key_block: int = ATTN_KEY_BLOCK, sweep_down=None, rope=None):
     """grads: optional preallocated (dq, dk, dv) [T, heads, hd] views with arbitrary token strides (e.g. the three column
     blocks of ONE fused d(q|k|v) buffer).  key_block: keys per entry of `k_tiles` (`attn_key_tile_table`'s block_n): 256 or 64 at
-    head_dim 64, 128 at head_dim 128."""
+    head_dim 64, 128 at head_dim 128.  rope = (cos, sin), f32 [period, hd / 2] (the tables q and k were rotated with): dq / dk
+    come back as the gradients w.r.t. the PRE-rotary q / k (inverse rotation in the kernels' epilogues, include/rankpo_hip.h)."""
     lib = _lib.load()
+    if rope is not None:
+        rc, rs = rope
+        if (rc.dtype != torch.float32 or rs.dtype != torch.float32 or rc.shape != rs.shape or rc.dim() != 2
+                or rc.shape[1] * 2 != q.shape[-1] or not rc.is_contiguous() or not rs.is_contiguous()):
+            raise ValueError("flash_attn_varlen_bwd: rope must be (cos, sin), contiguous f32 [period, head_dim / 2]")
     if sweep_down is None:
         sweep_down = ATTN_SWEEP_DOWN
     T, nh, hd = q.shape
@@ -653,6 +659,9 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
                                      cu_seqlens.data_ptr(), q_tiles.data_ptr(), q_tiles.shape[0], q_tiles.shape[1], k_tiles.data_ptr(),
                                      k_tiles.shape[0], key_block, int(bool(sweep_down)), T, nh, nkv, hd, scale, lse.data_ptr(), delta.data_ptr(),
                                      dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0), dk.stride(0), dv.stride(0),
+                                     rope[0].data_ptr() if rope is not None else None,
+                                     rope[1].data_ptr() if rope is not None else None,
+                                     rope[0].shape[0] if rope is not None else 0,
                                      _stream(q)), "rpo_flash_attn_bwd")
     return dq, dk, dv
 
@@ -720,6 +729,61 @@ class _FlashAttnVarlenQKV(torch.autograd.Function):
         return dqkv, None, None, None, None, None, None, None
 
 
+class _RopeFlashAttnVarlenQKV(torch.autograd.Function):
+    """Rotary embedding + the attention of `_FlashAttnVarlenQKV` as ONE autograd node: forward = `rpo_rope` in place on the q and k
+    heads of the fresh projection output, then the attention forward; backward = the attention backward with the INVERSE rotation
+    folded into the dQ / dK epilogues (f32, before the one rounding to bf16), so d(q|k|v) comes back w.r.t. the pre-rotary
+    projection output and no separate pass re-reads and re-rounds the q / k gradient (0.28 ms per block on cfg 2)."""
+
+    @staticmethod
+    def forward(ctx, qkv, cos, sin, nh, nkv, cu, tiles, k_tiles, scale, key_block):
+        x = qkv.view(-1, qkv.shape[-1])                      # [T, W]; `qkv` itself may carry leading batch dims ([1, T, W])
+        hd = x.shape[1] // (nh + 2 * nkv)
+        lib = _lib.load()
+        with torch.cuda.device(x.device):
+            check(lib.rpo_rope(x.data_ptr(), x.data_ptr(), x.shape[1], cos.data_ptr(), sin.data_ptr(), x.shape[0],
+                               nh + nkv, hd, cos.shape[0], _dt(x), 0, _stream(x)), "rpo_rope")
+        # autograd wants a tensor modified in place among the outputs, and it must not be a view made outside (hence the
+        # caller's own tensor, not a reshaped view of it)
+        ctx.mark_dirty(qkv)
+        ctx.set_materialize_grads(False)
+        q, k, v = _FlashAttnVarlenQKV._views(x, nh, nkv, hd)
+        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0, num_seqs=cu.numel() - 1)
+        ctx.save_for_backward(qkv, out, lse, cu, tiles, k_tiles, cos, sin)
+        ctx.meta = (nh, nkv, hd, scale, key_block)
+        return out, qkv
+
+    @staticmethod
+    def backward(ctx, go, g_rotated):
+        if g_rotated is not None:
+            raise RuntimeError("rope_flash_attn_varlen_qkv: the rotated q|k|v buffer is internal, nothing may use it downstream")
+        qkv, out, lse, cu, tiles, k_tiles, cos, sin = ctx.saved_tensors
+        nh, nkv, hd, scale, key_block = ctx.meta
+        q, k, v = _FlashAttnVarlenQKV._views(qkv.view(-1, qkv.shape[-1]), nh, nkv, hd)
+        dqkv = torch.empty_like(qkv)
+        flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale,
+                              grads=_FlashAttnVarlenQKV._views(dqkv.view(-1, qkv.shape[-1]), nh, nkv, hd), key_block=key_block,
+                              rope=(cos, sin))
+        return dqkv, None, None, None, None, None, None, None, None, None
+
+
+def rope_flash_attn_varlen_qkv(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None,
+                               head_dim: int = 64):
+    """qkv: the FRESH output of the fused q|k|v projection, [T, (num_heads + 2 num_kv_heads) * head_dim] (leading dims of size 1
+    allowed: [1, T, W]; pass the projection's own tensor, not a reshaped view of it) bf16, contiguous, NOT yet rotated (it is
+    rotated in place here); cos / sin: f32 [period, head_dim / 2] (row t % period for token t) -> attention
+    output [T, num_heads, head_dim].  The gradient that comes back is w.r.t. the un-rotated projection output."""
+    if head_dim not in (64, 128):
+        raise ValueError("rope_flash_attn_varlen_qkv: head_dim must be 64 or 128")
+    if qkv.shape[-1] != (num_heads + 2 * num_kv_heads) * head_dim or not qkv.is_contiguous():
+        raise ValueError("rope_flash_attn_varlen_qkv: qkv must be a contiguous [..., T, (nh + 2 nkv) * head_dim] tensor")
+    if key_block is None:
+        key_block = ATTN_KEY_BLOCK if head_dim == 64 else ATTN_KEY_BLOCK_HD128
+    if key_block == 64:
+        raise ValueError("rope_flash_attn_varlen_qkv: the 64-key dK/dV kernel has no rotary epilogue; use rope_ + flash_attn_varlen_qkv")
+    return _RopeFlashAttnVarlenQKV.apply(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block)[0]
+
+
 def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None, head_dim: int = 64):
     """qkv: [T, (num_heads + 2 num_kv_heads) * head_dim] bf16, contiguous rows -> out [T, num_heads, head_dim]; head_dim 64
     or 128; key_block (None: the head_dim's default) = the block_n `k_tiles` was built with."""
@@ -764,5 +828,5 @@ def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
 
 __all__ = ["pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
-           "flash_attn_varlen", "flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
+           "flash_attn_varlen", "flash_attn_varlen_qkv", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
            "attn_key_tile_table"]

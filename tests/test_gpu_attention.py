@@ -146,6 +146,66 @@ def test_flash_attn_qkv_fused_buffer_matches_split_views(hd):
 
 
 @pytest.mark.parametrize("hd", [64, 128])
+def test_rope_folded_into_attention_backward(hd):
+    """ops.rope_flash_attn_varlen_qkv (rotary in place + attention as one autograd node; backward = attention backward with the
+    inverse rotation in the dQ / dK epilogues, rpo_flash_attn_bwd's rope_cos / rope_sin) against the two separate nodes
+    (ops.rope_ + ops.flash_attn_varlen_qkv): same output bit for bit, d(q|k|v) equal to bf16 round-off and no further from the
+    float32 reference (it has one rounding less); the v columns are bit-identical; the 64-key kernel refuses the tables."""
+    from rankpo_amd import ops
+    from rankpo_amd._lib import RankPOHipError
+    torch.manual_seed(17 + hd)
+    nh, nkv = 8, 2
+    lens = [1, 63, 64, 65, 200, 129, 333, 31]
+    T, W = sum(lens), (nh + 2 * nkv) * hd
+    scale = hd ** -0.5
+    kb = ops.ATTN_KEY_BLOCK if hd == 64 else ops.ATTN_KEY_BLOCK_HD128
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    tiles = ops.attn_tile_table(lens, DEV, nh, nkv)
+    kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=kb)
+    ang = torch.rand(T, hd // 2, device=DEV) * 6.283
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    leaf = torch.randn(T, W, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    go = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+
+    def run(fused):
+        leaf.grad = None
+        x = leaf * 1.0                                      # the fresh projection output (a non-leaf the ops may rotate in place)
+        if fused:
+            out = ops.rope_flash_attn_varlen_qkv(x, cos, sin, nh, nkv, cu, tiles, kt, scale, head_dim=hd)
+        else:
+            out = ops.flash_attn_varlen_qkv(ops.rope_(x, cos, sin, nh + nkv, hd, grad_inplace=True), nh, nkv, cu, tiles, kt,
+                                            scale, head_dim=hd)
+        out.backward(go)
+        return out.detach(), leaf.grad.clone()
+    o_sep, g_sep = run(False)
+    o_fus, g_fus = run(True)
+    assert torch.equal(o_sep, o_fus)
+    nq = (nh + nkv) * hd
+    assert torch.equal(g_sep[:, nq:], g_fus[:, nq:])                                  # dV: untouched by the rotary
+    assert (g_sep.float() - g_fus.float()).abs().max() <= 2.0 ** -6 * g_sep.float().abs().max()
+    # float32 reference: rotary (HF layout) + attention through autograd
+    xr = leaf.detach().float().requires_grad_(True)
+    q, k, v = xr[:, :nh * hd].view(T, nh, hd), xr[:, nh * hd:nq].view(T, nkv, hd), xr[:, nq:].view(T, nkv, hd)
+    c2, s2 = torch.cat([cos, cos], -1)[:, None], torch.cat([sin, sin], -1)[:, None]
+    rot = lambda t: torch.cat([-t[..., hd // 2:], t[..., :hd // 2]], -1)
+    ro, _ = ref_attention(q * c2 + rot(q) * s2, k * c2 + rot(k) * s2, v, lens, scale)
+    ro.backward(go.float())
+    e_sep = ((g_sep.float() - xr.grad)[:, :nq].norm() / xr.grad[:, :nq].norm()).item()
+    e_fus = ((g_fus.float() - xr.grad)[:, :nq].norm() / xr.grad[:, :nq].norm()).item()
+    print(f"\nhead_dim {hd}: d(q|k) relative L2 error vs f32: separate rotary pass {e_sep:.5f}, folded {e_fus:.5f}")
+    assert e_fus <= 1.02 * e_sep + 1e-5 and e_fus < 0.01
+    if hd == 64:
+        x = (leaf * 1.0).detach()
+        q, k, v = x[:, :nh * hd].view(T, nh, hd), x[:, nh * hd:nq].view(T, nkv, hd), x[:, nq:].view(T, nkv, hd)
+        out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale)
+        with pytest.raises(RankPOHipError, match="status -2"):
+            ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, ops.attn_key_tile_table(lens, DEV, nkv, block_n=64),
+                                      scale, key_block=64, rope=(cos, sin))
+        with pytest.raises(ValueError):
+            ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, scale, rope=(cos.double(), sin.double()))
+
+
+@pytest.mark.parametrize("hd", [64, 128])
 def test_flash_attn_bwd_random_shapes_deterministic(hd):
     """Random (sequence count, lengths 1..2600, heads, GQA ratio): the hand-written backward (delta + dQ + one-wave-per-SIMD
     dK/dV with its hand-placed slice body and its masked fallback path; head_dim 128: fa_bwd_dq128 / fa_bwd_dkdv128) is

@@ -1,6 +1,6 @@
 """Gated parity of the EXACT encoder path bench.py times (reference modeling.py:206-238, 278-314): head_dim 64
-(cfg 2) and 128 with checkpointed blocks (cfg 5), bf16, query + passage batches in ONE packed pass (`pooled_last_token_multi`), the fused q|k|v flash attention
-(`flash_attn_varlen_qkv`), the last block on the pooled rows only (`forward_last_rows`) and the filler sequence that rounds
+(cfg 2) and 128 with checkpointed blocks (cfg 5), bf16, query + passage batches in ONE packed pass (`pooled_last_token_multi`), the fused rotary + q|k|v flash attention
+(`rope_flash_attn_varlen_qkv`), the last block on the pooled rows only (`forward_last_rows`) and the filler sequence that rounds
 the packed token count up to a multiple of 256 (needs >= 4096 packed tokens).
 
 The tolerance is not a guessed constant: the same tokens and weights also go through two CONTROLS -- the oracle's eager
@@ -72,10 +72,10 @@ def test_bench_path_parity_bf16_packed_filler(hd, ckpt):
 
     # spies: the branches under test must be the ones that run
     seen = {"qkv_T": [], "last_rows": 0, "multi": 0}
-    real_qkv, real_last, real_multi = ops.flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows, enc.pooled_last_token_multi
+    real_qkv, real_last, real_multi = ops.rope_flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows, enc.pooled_last_token_multi
 
     def spy_qkv(qkv, *a, **kw):
-        seen["qkv_T"].append(qkv.shape[0])
+        seen["qkv_T"].append(qkv.shape[-2])
         return real_qkv(qkv, *a, **kw)
 
     def spy_last(self, *a, **kw):
@@ -85,13 +85,13 @@ def test_bench_path_parity_bf16_packed_filler(hd, ckpt):
     def spy_multi(batches):
         seen["multi"] += len(batches) * int(enc.hand_attention)
         return real_multi(batches)
-    ops.flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows, enc.pooled_last_token_multi = spy_qkv, spy_last, spy_multi
+    ops.rope_flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows, enc.pooled_last_token_multi = spy_qkv, spy_last, spy_multi
     try:
         w = {k: v.detach().to("cpu", torch.float32).requires_grad_(True) for k, v in enc.state_dict().items()}
         ref = bench.oracle_step(w, cfg.to_dict(), batch, T_CONTRASTIVE)
         rep = bench.step_parity(model, cfg, T_CONTRASTIVE, batch, ref, DEV, torch.bfloat16)
     finally:
-        ops.flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows = real_qkv, real_last
+        ops.rope_flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows = real_qkv, real_last
         enc.pooled_last_token_multi = real_multi
     print("\nfast path parity:", rep)
     padded_T = (tot + 255) // 256 * 256
