@@ -478,7 +478,8 @@ def main():
     ap.add_argument("--no-fill", action="store_true", help="A/B: no filler sequence rounding the packed token count to 256")
     ap.add_argument("--no-linear-tn", action="store_true", help="A/B: torch's own operand layout for the input-gradient GEMMs")
     ap.add_argument("--no-wgrad-mixed", action="store_true", help="A/B: weight-gradient GEMMs as autograd issues them")
-    ap.add_argument("--no-fold-rope", action="store_true", help="A/B: rotary and attention as two autograd nodes (separate inverse-rotary pass)")
+    ap.add_argument("--fold-rope", type=int, default=2, choices=(0, 1, 2),
+                    help="A/B: 2 = rotary folded into the attention forward (q) and backward epilogues, 1 = backward only, 0 = separate passes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -534,8 +535,7 @@ def main():
         rankpo_amd.ops.LINEAR_TN = False
     if args.no_wgrad_mixed:
         rankpo_amd.ops.WGRAD_MIXED = False
-    if args.no_fold_rope:
-        rankpo_amd.encoder.FOLD_ROPE = False
+    rankpo_amd.encoder.FOLD_ROPE = args.fold_rope
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
                                         negatives_cross_device=multi, unpad=not args.padded).train()
     hook_attn_tables()

@@ -226,12 +226,17 @@ int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, c
  *      entries whose first query row is >= 2^30 are padding.
  * out: [T, num_heads * hd] (token stride out_stride), lse = log sum_j exp(scale * <q_i, k_j>)
  * over the keys j <= i of the same sequence, f32, laid out [num_heads][T] when lse_max_len == 0 or padded
- * [N][num_heads][lse_max_len] (the layout PyTorch's flash-attention backward reads) when lse_max_len > 0. */
+ * [N][num_heads][lse_max_len] (the layout PyTorch's flash-attention backward reads) when lse_max_len > 0.
+ * rope_cos / rope_sin (both NULL, or both f32 [rope_period][hd / 2], 16-byte aligned; token t uses row t % rope_period): q
+ * arrives UN-rotated and is rotated IN PLACE (q is written!) by the block that owns each (128 queries x head) piece -- the same
+ * arithmetic as rpo_rope -- so that the separate rotary pass only has the k heads left; k must arrive rotated (every query
+ * block reads it).  The backward entry point reads the rotated q from memory. */
 int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
                        int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles, int64_t tile_cols,
                        int64_t total_tokens,
                        int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
-                       int64_t out_stride, float* lse, int64_t lse_max_len, rpo_stream_t stream);
+                       int64_t out_stride, float* lse, int64_t lse_max_len, const float* rope_cos, const float* rope_sin,
+                       int64_t rope_period, rpo_stream_t stream);
 
 /* Backward of rpo_flash_attn_fwd, head_dim 64 or 128 (two launches: dQ, which also computes the row constants, then dK/dV; no
  * atomics, deterministic).  lse: f32 [num_heads][T] as written by the forward with lse_max_len == 0; delta: f32

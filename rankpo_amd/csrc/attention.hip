@@ -96,6 +96,28 @@ __device__ __forceinline__ void inv_rope4(float4_t& lo, float4_t& hi, const floa
     }
 }
 
+// Forward rotary of a block's OWN Q fragments (round 2): the forward kernel loads its 128 queries x 1 head once anyway, so it
+// rotates them in registers (same arithmetic as rope_kernel: y1 = x1 cos - x2 sin, y2 = x2 cos + x1 sin, f32, one rounding) and
+// writes them back in place -- every q element belongs to exactly one block, and the backward kernels read the rotated q from
+// memory.  The separate rpo_rope pass then only has the k heads left (8 of 40 on cfg 2).  lo / hi = the lane's 8 elements of
+// the low / high half of the head (hd j .. j + 7 and j + hd / 2 ..), c0 / c1 / s0 / s1 = cos / sin of j .. j + 3, j + 4 .. j + 7.
+__device__ __forceinline__ void rope_frag(short8_t& lo, short8_t& hi, const float4_t& c0, const float4_t& c1,
+                                          const float4_t& s0, const float4_t& s1) {
+    typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+    float y1[8], y2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float cc = e < 4 ? c0[e & 3] : c1[e & 3], ss = e < 4 ? s0[e & 3] : s1[e & 3];
+        const float a = bf16_to_f32((bf16_t)lo[e]), b = bf16_to_f32((bf16_t)hi[e]);
+        y1[e] = a * cc - b * ss;
+        y2[e] = b * cc + a * ss;
+    }
+    const u32x4 wl = {pack_bf16(y1[0], y1[1]), pack_bf16(y1[2], y1[3]), pack_bf16(y1[4], y1[5]), pack_bf16(y1[6], y1[7])};
+    const u32x4 wh = {pack_bf16(y2[0], y2[1]), pack_bf16(y2[2], y2[3]), pack_bf16(y2[4], y2[5]), pack_bf16(y2[6], y2[7])};
+    lo = __builtin_bit_cast(short8_t, wl);
+    hi = __builtin_bit_cast(short8_t, wh);
+}
+
 // Query-tile work list, two formats (`tcols`, an argument of the C entry points):
 //   2: int32 [n][2] = (sequence id, first query row), heaviest tiles first; grid = (n, heads), the head is blockIdx.y.
 //   3: int32 [n][3] = (sequence id, first query row, head), n % 8 == 0, grid = (n): block b takes entry (b & 7) * n / 8 + (b >> 3),
@@ -118,7 +140,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
     int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
     float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
-    int64_t lse_head_stride, int lse_packed) {
+    int64_t lse_head_stride, int lse_packed, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod,
+    bf16_t* q_rw) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kKvTile];       // ring of (K tile | V tile), 128-byte rows
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -133,6 +156,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 
     // Q^T fragments (B operand): lane = query fr of tile n, k = hd 32 ks + 8 g .. + 7
     short8_t bq[2][2];
+    float4_t rc[2][2], rs[2][2];                         // rotary tables of the lane's 8 frequencies (only when rcos is given)
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int qi = qw + 16 * n + fr;
@@ -140,6 +164,14 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
         for (int ks = 0; ks < 2; ++ks) {
             if (qi < len) bq[n][ks] = *reinterpret_cast<const short8_t*>(q + (t0 + qi) * sq + h * kFaHD + 32 * ks + 8 * g);
             else bq[n][ks] = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if (rcos && qi < len) {
+            const int64_t tr = ((t0 + qi) % rperiod) * (kFaHD / 2) + 8 * g;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                rc[n][i] = *reinterpret_cast<const float4_t*>(rcos + tr + 4 * i);
+                rs[n][i] = *reinterpret_cast<const float4_t*>(rsin + tr + 4 * i);
+            }
         }
     }
     const int last_q = min(q0 + kFaBM - 1, len - 1);
@@ -170,6 +202,17 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(bq[n][ks]));
+    if (rcos) {                                          // rotary on the block's own Q, written back in place (rope_frag)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int qi = qw + 16 * n + fr;
+            if (qi >= len) continue;
+            rope_frag(bq[n][0], bq[n][1], rc[n][0], rc[n][1], rs[n][0], rs[n][1]);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                *reinterpret_cast<short8_t*>(q_rw + (t0 + qi) * sq + h * kFaHD + 32 * ks + 8 * g) = bq[n][ks];
+        }
+    }
 
     float4_t oacc[4][2];                                 // O^T: [hd tile c][query tile n], rows = hd 16c + 4g + r
 #pragma unroll
@@ -382,7 +425,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
     int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
     float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
-    int64_t lse_head_stride, int lse_packed) {
+    int64_t lse_head_stride, int lse_packed, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod,
+    bf16_t* q_rw) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kKvTile];       // ring of (K tile | V tile), 256-byte rows, 32 keys
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -433,6 +477,23 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
     for (int n = 0; n < 2; ++n)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(bq[n][ks]));
+    if (rcos) {                                          // rotary on the block's own Q, written back in place (rope_frag): the
+#pragma unroll                                           // lane's hd 32 ks + 8g + e pairs with 32 (ks + 2) + 8g + e
+        for (int n = 0; n < 2; ++n) {
+            const int qi = qw + 16 * n + fr;
+            if (qi >= len) continue;
+            const int64_t tr = ((t0 + qi) % rperiod) * (kFa128HD / 2) + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                rope_frag(bq[n][ks], bq[n][ks + 2], *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks),
+                          *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks + 4),
+                          *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks),
+                          *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks + 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                *reinterpret_cast<short8_t*>(q_rw + (t0 + qi) * sq + h * kFa128HD + 32 * ks + 8 * g) = bq[n][ks];
+        }
+    }
 
     float4_t oacc[8][2];                                 // O^T: [hd tile c][query tile n], rows = hd 16c + 4g + r
 #pragma unroll
@@ -3067,9 +3128,13 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
                                   int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles,
                                   int64_t tile_cols, int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim,
                                   float scale, void* out, int64_t out_stride, float* lse, int64_t lse_max_len,
-                                  rpo_stream_t stream) {
+                                  const float* rope_cos, const float* rope_sin, int64_t rope_period, rpo_stream_t stream) {
     if (!q || !k || !v || !cu_seqlens || !tiles || !out || !lse || ntiles <= 0 || total_tokens <= 0)
         return RPO_ERR_INVALID_ARG;
+    // rope_cos / rope_sin (both or neither): q arrives UN-rotated and is rotated IN PLACE by the block that owns it (k must
+    // arrive rotated: every query block reads it)
+    if ((rope_cos == nullptr) != (rope_sin == nullptr) || (rope_cos && rope_period <= 0)) return RPO_ERR_INVALID_ARG;
+    if (rope_cos && (!rpo_aligned16(rope_cos) || !rpo_aligned16(rope_sin))) return RPO_ERR_UNSUPPORTED;
     if (!(tile_cols == 2 || (tile_cols == 3 && ntiles % 8 == 0))) return RPO_ERR_UNSUPPORTED;
     if ((head_dim != kFaHD && head_dim != kFa128HD) || num_heads <= 0 || num_kv_heads <= 0 || num_heads % num_kv_heads != 0 ||
         num_heads > 65535)
@@ -3084,12 +3149,14 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
         RPO_LAUNCH(fa_fwd128_kernel, grid, dim3(kFaThreads), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
                    k_stride, v_stride, cu_seqlens, tiles, (int)tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,
                    (bf16_t*)out, out_stride, lse, lse_max_len > 0 ? num_heads * lse_max_len : 0,
-                   lse_max_len > 0 ? lse_max_len : total_tokens, lse_max_len > 0 ? 0 : 1);
+                   lse_max_len > 0 ? lse_max_len : total_tokens, lse_max_len > 0 ? 0 : 1, rope_cos, rope_sin, rope_period,
+                   (bf16_t*)const_cast<void*>(q));
     else
         RPO_LAUNCH(fa_fwd_kernel, grid, dim3(kFaThreads), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
                    k_stride, v_stride, cu_seqlens, tiles, (int)tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,
                    (bf16_t*)out, out_stride, lse, lse_max_len > 0 ? num_heads * lse_max_len : 0,
-                   lse_max_len > 0 ? lse_max_len : total_tokens, lse_max_len > 0 ? 0 : 1);
+                   lse_max_len > 0 ? lse_max_len : total_tokens, lse_max_len > 0 ? 0 : 1, rope_cos, rope_sin, rope_period,
+                   (bf16_t*)const_cast<void*>(q));
     return rpo_launch_status();
 }
 

@@ -170,8 +170,9 @@ class RopeTables:
         return (cos[:, None, :], sin[:, None, :]) if packed else (cos[None, None], sin[None, None])
 
 
-FOLD_ROPE = True     # packed training path: rotary + attention as ONE autograd node, inverse rotary in the dQ / dK epilogues
-#                      (False: two nodes, a separate rpo_rope pass over d(q|k) -- the A/B arm of `bench.py --no-fold-rope`)
+FOLD_ROPE = 2        # packed training path: rotary + attention as ONE autograd node; 2 = q rotated by the attention forward block
+#                      that loads it + inverse rotary in the dQ / dK epilogues, 1 = the epilogues only, 0 = two nodes with
+#                      separate rpo_rope passes both ways (the A/B arms of `bench.py --fold-rope`)
 
 
 class VarlenCtx:
@@ -290,7 +291,8 @@ class LlamaAttention(nn.Module):
             # projection output, attention reads q / k / v as its column blocks, and the backward writes ONE d(q|k|v)
             # buffer (no split / cat copies) with the inverse rotation already applied in the dQ / dK epilogues
             o = _ops.rope_flash_attn_varlen_qkv(qkv, rope.cos32, rope.sin32, self.nh, self.nkv, attn_mask.cu,
-                                                attn_mask.tiles, attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd)
+                                                attn_mask.tiles, attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd,
+                                                fold_forward=FOLD_ROPE >= 2)
             return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
         if fused:       # one in-place HIP pass over the q and k heads instead of neg / cat / 2 mul / add per tensor
             qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd, grad_inplace=True)

@@ -545,10 +545,20 @@ def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, blo
     return torch.from_numpy(np.concatenate(out, 0)).to(device, non_blocking=True)
 
 
-def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0):
+def _check_rope_tables(rope, hd, who):
+    rc, rs = rope
+    if (rc.dtype != torch.float32 or rs.dtype != torch.float32 or rc.shape != rs.shape or rc.dim() != 2
+            or rc.shape[1] * 2 != hd or not rc.is_contiguous() or not rs.is_contiguous()):
+        raise ValueError(f"{who}: rope must be (cos, sin), contiguous f32 [period, head_dim / 2]")
+
+
+def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0, rope=None):
     """q [T, nh, hd], k / v [T, nkv, hd], hd = 64 or 128 (last two dims contiguous, token stride free); returns
-    (out [T, nh, hd] bf16, lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0)."""
+    (out [T, nh, hd] bf16, lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0).  rope = (cos, sin),
+    f32 [period, hd / 2]: q arrives UN-rotated and the kernel rotates it IN PLACE (k must arrive rotated), see the header."""
     lib = _lib.load()
+    if rope is not None:
+        _check_rope_tables(rope, q.shape[-1], "flash_attn_varlen_fwd")
     T, nh, hd = q.shape
     nkv = k.shape[1]
     if (q.dtype != torch.bfloat16 or hd not in (64, 128) or q.stride(2) != 1 or q.stride(1) != hd or k.stride(1) != hd
@@ -562,7 +572,10 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
     with torch.cuda.device(q.device):
         check(lib.rpo_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0),
                                      cu_seqlens.data_ptr(), tiles.data_ptr(), tiles.shape[0], tiles.shape[1], T, nh, nkv, hd, scale,
-                                     out.data_ptr(), nh * hd, lse.data_ptr(), padded_lse_len, _stream(q)),
+                                     out.data_ptr(), nh * hd, lse.data_ptr(), padded_lse_len,
+                                     rope[0].data_ptr() if rope is not None else None,
+                                     rope[1].data_ptr() if rope is not None else None,
+                                     rope[0].shape[0] if rope is not None else 0, _stream(q)),
               "rpo_flash_attn_fwd")
     return out, lse
 
@@ -634,10 +647,7 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
     come back as the gradients w.r.t. the PRE-rotary q / k (inverse rotation in the kernels' epilogues, include/rankpo_hip.h)."""
     lib = _lib.load()
     if rope is not None:
-        rc, rs = rope
-        if (rc.dtype != torch.float32 or rs.dtype != torch.float32 or rc.shape != rs.shape or rc.dim() != 2
-                or rc.shape[1] * 2 != q.shape[-1] or not rc.is_contiguous() or not rs.is_contiguous()):
-            raise ValueError("flash_attn_varlen_bwd: rope must be (cos, sin), contiguous f32 [period, head_dim / 2]")
+        _check_rope_tables(rope, q.shape[-1], "flash_attn_varlen_bwd")
     if sweep_down is None:
         sweep_down = ATTN_SWEEP_DOWN
     T, nh, hd = q.shape
@@ -730,25 +740,29 @@ class _FlashAttnVarlenQKV(torch.autograd.Function):
 
 
 class _RopeFlashAttnVarlenQKV(torch.autograd.Function):
-    """Rotary embedding + the attention of `_FlashAttnVarlenQKV` as ONE autograd node: forward = `rpo_rope` in place on the q and k
-    heads of the fresh projection output, then the attention forward; backward = the attention backward with the INVERSE rotation
+    """Rotary embedding + the attention of `_FlashAttnVarlenQKV` as ONE autograd node: forward = `rpo_rope` in place on the k heads
+    of the fresh projection output, then the attention forward, which rotates (and writes back) the q block it loads anyway; backward = the attention backward with the INVERSE rotation
     folded into the dQ / dK epilogues (f32, before the one rounding to bf16), so d(q|k|v) comes back w.r.t. the pre-rotary
     projection output and no separate pass re-reads and re-rounds the q / k gradient (0.28 ms per block on cfg 2)."""
 
     @staticmethod
-    def forward(ctx, qkv, cos, sin, nh, nkv, cu, tiles, k_tiles, scale, key_block):
+    def forward(ctx, qkv, cos, sin, nh, nkv, cu, tiles, k_tiles, scale, key_block, fold_forward):
         x = qkv.view(-1, qkv.shape[-1])                      # [T, W]; `qkv` itself may carry leading batch dims ([1, T, W])
         hd = x.shape[1] // (nh + 2 * nkv)
         lib = _lib.load()
+        # fold_forward: the rotary pass covers the k heads only (column block [nh hd, (nh + nkv) hd)): q is rotated by the
+        # attention forward itself, by the block that owns it (flash_attn_varlen_fwd's `rope`)
+        ptr = x.data_ptr() + (nh * hd * x.element_size() if fold_forward else 0)
         with torch.cuda.device(x.device):
-            check(lib.rpo_rope(x.data_ptr(), x.data_ptr(), x.shape[1], cos.data_ptr(), sin.data_ptr(), x.shape[0],
-                               nh + nkv, hd, cos.shape[0], _dt(x), 0, _stream(x)), "rpo_rope")
+            check(lib.rpo_rope(ptr, ptr, x.shape[1], cos.data_ptr(), sin.data_ptr(), x.shape[0],
+                               nkv if fold_forward else nh + nkv, hd, cos.shape[0], _dt(x), 0, _stream(x)), "rpo_rope")
         # autograd wants a tensor modified in place among the outputs, and it must not be a view made outside (hence the
         # caller's own tensor, not a reshaped view of it)
         ctx.mark_dirty(qkv)
         ctx.set_materialize_grads(False)
         q, k, v = _FlashAttnVarlenQKV._views(x, nh, nkv, hd)
-        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0, num_seqs=cu.numel() - 1)
+        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0, num_seqs=cu.numel() - 1,
+                                         rope=(cos, sin) if fold_forward else None)
         ctx.save_for_backward(qkv, out, lse, cu, tiles, k_tiles, cos, sin)
         ctx.meta = (nh, nkv, hd, scale, key_block)
         return out, qkv
@@ -764,11 +778,11 @@ class _RopeFlashAttnVarlenQKV(torch.autograd.Function):
         flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale,
                               grads=_FlashAttnVarlenQKV._views(dqkv.view(-1, qkv.shape[-1]), nh, nkv, hd), key_block=key_block,
                               rope=(cos, sin))
-        return dqkv, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None
 
 
 def rope_flash_attn_varlen_qkv(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None,
-                               head_dim: int = 64):
+                               head_dim: int = 64, fold_forward: bool = True):
     """qkv: the FRESH output of the fused q|k|v projection, [T, (num_heads + 2 num_kv_heads) * head_dim] (leading dims of size 1
     allowed: [1, T, W]; pass the projection's own tensor, not a reshaped view of it) bf16, contiguous, NOT yet rotated (it is
     rotated in place here); cos / sin: f32 [period, head_dim / 2] (row t % period for token t) -> attention
@@ -781,7 +795,8 @@ def rope_flash_attn_varlen_qkv(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles
         key_block = ATTN_KEY_BLOCK if head_dim == 64 else ATTN_KEY_BLOCK_HD128
     if key_block == 64:
         raise ValueError("rope_flash_attn_varlen_qkv: the 64-key dK/dV kernel has no rotary epilogue; use rope_ + flash_attn_varlen_qkv")
-    return _RopeFlashAttnVarlenQKV.apply(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block)[0]
+    return _RopeFlashAttnVarlenQKV.apply(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block,
+                                         bool(fold_forward))[0]
 
 
 def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None, head_dim: int = 64):

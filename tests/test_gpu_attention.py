@@ -147,8 +147,9 @@ def test_flash_attn_qkv_fused_buffer_matches_split_views(hd):
 
 @pytest.mark.parametrize("hd", [64, 128])
 def test_rope_folded_into_attention_backward(hd):
-    """ops.rope_flash_attn_varlen_qkv (rotary in place + attention as one autograd node; backward = attention backward with the
-    inverse rotation in the dQ / dK epilogues, rpo_flash_attn_bwd's rope_cos / rope_sin) against the two separate nodes
+    """ops.rope_flash_attn_varlen_qkv (one autograd node: rotary pass on the k heads, q rotated in place by the attention forward
+    block that loads it (rpo_flash_attn_fwd's rope_cos / rope_sin); backward = attention backward with the inverse rotation in
+    the dQ / dK epilogues, rpo_flash_attn_bwd's rope_cos / rope_sin) against the two separate nodes
     (ops.rope_ + ops.flash_attn_varlen_qkv): same output bit for bit, d(q|k|v) equal to bf16 round-off and no further from the
     float32 reference (it has one rounding less); the v columns are bit-identical; the 64-key kernel refuses the tables."""
     from rankpo_amd import ops
@@ -180,6 +181,14 @@ def test_rope_folded_into_attention_backward(hd):
     o_sep, g_sep = run(False)
     o_fus, g_fus = run(True)
     assert torch.equal(o_sep, o_fus)
+    # the forward's own piece: q rotated IN PLACE by the block that owns it = what the rotary kernel writes, bit for bit
+    x_ref = ops.rope_((leaf * 1.0).detach(), cos, sin, nh + nkv, hd)
+    x_own = x_ref.clone()
+    x_own[:, :nh * hd] = leaf.detach()[:, :nh * hd]                                   # q columns back to un-rotated, k stays rotated
+    vw = lambda t: (t[:, :nh * hd].unflatten(1, (nh, hd)), t[:, nh * hd:(nh + nkv) * hd].unflatten(1, (nkv, hd)),
+                    t[:, (nh + nkv) * hd:].unflatten(1, (nkv, hd)))
+    o_own, _ = ops.flash_attn_varlen_fwd(*vw(x_own), cu, tiles, scale, rope=(cos, sin))
+    assert torch.equal(x_own, x_ref) and torch.equal(o_own, o_sep)
     nq = (nh + nkv) * hd
     assert torch.equal(g_sep[:, nq:], g_fus[:, nq:])                                  # dV: untouched by the rotary
     assert (g_sep.float() - g_fus.float()).abs().max() <= 2.0 ** -6 * g_sep.float().abs().max()
