@@ -272,11 +272,11 @@ def _forward_worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("world", [2, 4])
 def test_gloo_model_forward_cross_device(world):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_forward_worker, args=(world, 29713, ret), nprocs=world, join=True)
+    mp.spawn(_forward_worker, args=(world, 29713 + world, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
 
 
