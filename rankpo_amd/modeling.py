@@ -122,7 +122,7 @@ class ModelForTraining(nn.Module):
         """modeling.py:206-238: encoder -> last-token / CLS pooling -> (normalize) -> contiguous [N, d]."""
         if inputs is None:
             return None
-        if self.unpad and self.pooling_mode == "last" and hasattr(self.model, "pooled_last_token"):
+        if self._one_pass_configured():
             # right-padded batches (what both collators produce): run the encoder on the real tokens only and
             # normalise the N pooled rows; identical to the padded path on every pooled row.
             pooled = self.model.pooled_last_token(inputs["input_ids"], inputs["attention_mask"])
@@ -133,12 +133,17 @@ class ModelForTraining(nn.Module):
         attention_mask = inputs["attention_mask"]
         return ops.pool_normalize(last_hidden_state, attention_mask, self.pooling_mode, self.normalize_embeddings)
 
+    def _one_pass_configured(self) -> bool:
+        """Whether this model runs both towers as ONE packed encoder pass.  A property of the CONFIGURATION (constructor
+        flag, pooling mode, encoder class), never of a batch: it decides the sequence of collectives under
+        `negatives_cross_device`, which has to be the same on every rank whatever rows each rank happens to hold."""
+        return self.unpad and self.pooling_mode == "last" and hasattr(self.model, "pooled_last_token_multi")
+
     def _embed_both(self, query, passage):
         """The normalised pooled rows of both batches as ONE [B + B G, d] block `q ‖ p` through ONE packed encoder pass, or
         None when the batches do not qualify for the unpadded path (sequences are independent, so the rows are the ones the
         two separate `embed` calls produce)."""
-        if (query is not None and passage is not None and self.unpad and self.pooling_mode == "last"
-                and hasattr(self.model, "pooled_last_token_multi")):
+        if query is not None and passage is not None and self._one_pass_configured():
             pooled = self.model.pooled_last_token_multi([(query["input_ids"], query["attention_mask"]),
                                                         (passage["input_ids"], passage["attention_mask"])])
             if pooled is not None:
@@ -167,10 +172,17 @@ class ModelForTraining(nn.Module):
             # modeling.py:287-290, MI355X-first: ONE all-gather of this rank's `q ‖ p` block instead of two collectives
             # (xGMI is point-to-point: 2 x (W - 1) messages of 32 / 192 KiB become W - 1 of 224 KiB), issued on RCCL's
             # stream as soon as the pooled rows exist and waited for just before the scoring kernel.
-            both = self._embed_both(query, passage)
-            if both is not None:
+            # The SEQUENCE of collectives is decided by the configuration alone (`_one_pass_configured`), never by what this
+            # rank's batch looks like: a rank whose batch falls off the packed path (an empty row, a left-padded or holed mask)
+            # still contributes ONE [B + B G, d] block to the ONE all-gather its peers issue.
+            if self._one_pass_configured():
+                both = self._embed_both(query, passage)
                 nq = query["input_ids"].shape[0]
-                q_reps, p_reps = both[:nq], both[nq:]
+                if both is not None:
+                    q_reps, p_reps = both[:nq], both[nq:]
+                else:                       # this rank's batch only: general padded path, same collective
+                    q_reps, p_reps = self.embed(query), self.embed(passage)
+                    both = torch.cat([q_reps.detach(), p_reps.detach()], 0)
                 gather = FusedQPGather(both, nq)
             else:
                 # towers one after the other (padded / CLS encoders): the passage gather is in flight during the query tower

@@ -215,16 +215,27 @@ def _forward_worker(rank, world, port, ret):
         cfg = PE.llama_config(vocab_size=16, hidden_size=8, intermediate_size=8, num_hidden_layers=1,
                               num_attention_heads=2, num_key_value_heads=1, pad_token_id=0)
         ok = True
-        for fused in (True, False):
+        # arms: "one_pass" = both towers in one packed pass -> ONE q||p all-gather; "two_towers" = configured (unpad=False) to run
+        # the towers one after the other -> passage gather in flight during the query tower; "mixed" = one-pass configuration in
+        # which ONLY RANK 1's batch falls off the packed path (a left-padded / holed row): the collective sequence must not
+        # depend on the batch, so that rank still joins the ONE all-gather its peers issue (round 2 issued two there: a hang
+        # or silently mis-sized gather on RCCL)
+        for arm in ("one_pass", "two_towers", "mixed"):
             model = rankpo_amd.ModelForTraining(encoder=PE.LlamaEncoder(cfg), temperature=0.02,
-                                                negatives_cross_device=True, normalize_embeddings=True).train()
+                                                negatives_cross_device=True, normalize_embeddings=True,
+                                                unpad=arm != "two_towers").train()
             assert (model.process_rank, model.world_size) == (rank, world)
+            assert model._one_pass_configured() == (arm != "two_towers")
             q = torch.tensor(g[f"w{world}_r{rank}_q"], requires_grad=True)
             p = torch.tensor(g[f"w{world}_r{rank}_p"], requires_grad=True)
             model.embed = lambda x: x["reps"]
-            if fused:       # one packed pass -> ONE q||p all-gather
+            calls = []
+            real_ag, real_agt = dist.all_gather, dist.all_gather_into_tensor
+            dist.all_gather = lambda *a, **k: (calls.append("all_gather"), real_ag(*a, **k))[1]
+            dist.all_gather_into_tensor = lambda *a, **k: (calls.append("all_gather_into_tensor"), real_agt(*a, **k))[1]
+            if arm == "one_pass" or (arm == "mixed" and rank != 1):
                 model._embed_both = lambda qd, pd: torch.cat([qd["reps"], pd["reps"]], 0)
-            else:           # towers one after the other -> passage gather in flight during the query tower
+            else:
                 model._embed_both = lambda qd, pd: None
             real = ops.infonce_loss
             ops.infonce_loss = _torch_infonce
@@ -232,6 +243,13 @@ def _forward_worker(rank, world, port, ret):
                 out = model(query={"reps": q, "input_ids": q}, passage={"reps": p, "input_ids": p})
             finally:
                 ops.infonce_loss = real
+                dist.all_gather, dist.all_gather_into_tensor = real_ag, real_agt
+            # every rank issued the same number of collectives: one (one-pass configuration) or two (two towers)
+            ncoll = torch.tensor([len(calls)])
+            lo, hi = ncoll.clone(), ncoll.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            ok = ok and int(lo) == int(hi) == (2 if arm == "two_towers" else 1)
             out["loss"].backward()
             ok = ok and abs(out.loss.item() - float(g[f"w{world}_r{rank}_loss"])) < 1e-9
             ok = ok and np.allclose(out.scores.numpy(), g[f"w{world}_r{rank}_scores"], rtol=1e-9, atol=1e-9)
