@@ -368,7 +368,7 @@ def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
     delta = rowsum(dO o O) from the bf16-ROUNDED output where eager autograd sums P dP inside the softmax backward, which
     shows on the q / k projection gradients only (`tools/grad_error_map.py`: 0.016-0.023 there against eager's 0.009, the
     same with PyTorch's kernels as with the hand-written ones).  All three are compared with the float32 oracle; the fast
-    path passes when its error is at most 1.5x the LARGER control error (the tolerance IS the reduced-precision error of
+    path passes when its error is at most 1.5x the LARGER control error (every statistic, the max included) (the tolerance IS the reduced-precision error of
     the stock paths, measured here, not a guessed constant).  Statistics: RMS and max of the cosine errors over all [Q, P]
     scores, the loss, and the relative error of two weight gradients."""
     from oracle import encoder_ref as E
@@ -404,10 +404,10 @@ def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
     controls["control_stock_eager"] = stats(loss_c.detach(), s_c.detach(), dict(zip(names, got_c)))
     ctrl = {k: max(c[k] for c in controls.values()) for k in controls["control_stock_eager"] if k != "loss"}
     # floors: float32 round-off (both paths are then ~1e-7 on a cosine and the ratio of two round-off errors means nothing).
-    # The MAX over a few hundred scores built from a few dozen embeddings is an extreme-value statistic of two independent
-    # rounding-error samples: it gets a factor 2, the RMS and the other aggregates 1.5 (a first version used 1.5 on the max
-    # of 48 scores from 16 embeddings and tripped at a ratio of 1.7 with the RMS ratio at 1.4).
-    tol = {"cos_rms_err": 1.5 * ctrl["cos_rms_err"] + 5e-6, "cos_max_err": 2.0 * ctrl["cos_max_err"] + 5e-6,
+    # One factor, 1.5, for every statistic.  (Round 2 ran the max at 2.0 after a red run at a ratio of 1.7; its cause -- Q
+    # pre-scaled and re-rounded in the backward kernels -- was removed afterwards, and the driver's run of that round measured
+    # 1.04 on the max with the RMS ratio below 1, so the wider factor had nothing left to cover.)
+    tol = {"cos_rms_err": 1.5 * ctrl["cos_rms_err"] + 5e-6, "cos_max_err": 1.5 * ctrl["cos_max_err"] + 5e-6,
            "loss_abs_err": 1.5 * max(ctrl["loss_abs_err"], ctrl["cos_rms_err"] / temperature) + 5e-6 / temperature}
     for n in names:
         tol["grad_rel_err:" + n] = 1.5 * ctrl["grad_rel_err:" + n] + 1e-4
@@ -416,9 +416,8 @@ def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
     return {"oracle_f32_loss": round(ref["loss"], 6), "fast_path": rnd(fast), **{k: rnd(v) for k, v in controls.items()},
             "tolerance": rnd(tol), "pass": not failed, "failed": failed,
             "rule": "fast-path error <= 1.5 x the larger error of the stock paths in the same storage dtype (eager attention; "
-                    "PyTorch's flash-attention kernels) (2 x for the max cosine error, an extreme-value statistic), all "
-                    "against the float32 oracle on the same tokens and weights (loss: 1.5 x max(control loss error, control "
-                    "cosine RMS error / T))"}
+                    "PyTorch's flash-attention kernels), all against the float32 oracle on the same tokens and weights "
+                    "(loss: 1.5 x max(control loss error, control cosine RMS error / T))"}
 
 
 class _StdoutToStderr:
@@ -436,11 +435,131 @@ class _StdoutToStderr:
         os.close(self._saved)
 
 
+COMM_KEYS = ("backend", "ranks_seen", "world_size", "collectives_per_step", "allgather_calls_per_step", "allgather_bytes_per_rank",
+             "allgather_wait_us", "allgather_wait_us_max", "allreduce_bytes", "allreduce_buckets", "allreduce_exposed_ms",
+             "allreduce_exposed_ms_max", "late_buckets", "loss_min_over_ranks", "loss_max_over_ranks", "loss_equal_over_ranks",
+             "params_in_sync", "ms_per_step_min_over_ranks", "ms_per_step_max_over_ranks", "timer")
+
+
+class CommProbe:
+    """Brackets the two places where the launch stream WAITS for a collective -- `EmbeddingGather.wait` (the q||p all-gather,
+    modeling.py:287-290 of the reference) and `FlatGradAllReducer.finish` (the bucketed gradient mean) -- with HIP events on the
+    launch stream (wall-clock stamps in the CPU rehearsal): the bracket measures what the collective costs the step, i.e.
+    its EXPOSED time; a collective that finished under the kernels queued before the wait reads ~0."""
+
+    def __init__(self, use_events: bool):
+        self.use_events = use_events
+        self.enabled = False
+        self.gather, self.reduce = [], []          # (start, end) pairs
+        self.gather_bytes = 0
+        self.collectives = 0
+
+    def _stamp(self):
+        if self.use_events:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            return e
+        return time.perf_counter()
+
+    def install(self):
+        from rankpo_amd import distributed as D
+        probe = self
+        g_init, g_wait, r_finish = D.EmbeddingGather.__init__, D.EmbeddingGather.wait, D.FlatGradAllReducer.finish
+        real_ar, real_ag, real_agt = dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor
+
+        def count(fn):
+            def counted(*a, **k):
+                if probe.enabled:
+                    probe.collectives += 1
+                return fn(*a, **k)
+            return counted
+        dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor = count(real_ar), count(real_ag), count(real_agt)
+
+        def init(g, x):
+            g_init(g, x)
+            if probe.enabled:
+                probe.gather_bytes = g.x.numel() * g.x.element_size()
+
+        def wait(g):
+            if not probe.enabled:
+                return g_wait(g)
+            a = probe._stamp()
+            out = g_wait(g)
+            probe.gather.append((a, probe._stamp()))
+            return out
+
+        def finish(r):
+            if not probe.enabled:
+                return r_finish(r)
+            a = probe._stamp()
+            out = r_finish(r)
+            probe.reduce.append((a, probe._stamp()))
+            return out
+        D.EmbeddingGather.__init__, D.EmbeddingGather.wait, D.FlatGradAllReducer.finish = init, wait, finish
+
+    def _ms(self, pairs):
+        if self.use_events:
+            return [a.elapsed_time(b) for a, b in pairs]
+        return [1e3 * (b - a) for a, b in pairs]
+
+
+def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=None):
+    """The N > 1 part of the JSON line (also emitted by the world-1 `--force-dist` rehearsal and, on gloo, by
+    `--rehearse-launch`): what the communicator saw and what the collectives cost, measured in this run.  Collective calls:
+    every rank must call this."""
+    def red(x, op):
+        t = torch.tensor([float(x)], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=op)
+        return t.item()
+    ones = torch.ones(1, dtype=torch.float32, device=device)
+    dist.all_reduce(ones)                                              # what the backend's communicator spans
+    g_us = [1e3 * m for m in probe._ms(probe.gather)]
+    r_ms = probe._ms(probe.reduce)
+    loss = float(last_loss)
+    lmin, lmax = red(loss, dist.ReduceOp.MIN), red(loss, dist.ReduceOp.MAX)
+    in_sync = None
+    if flat_param is not None:                                        # replicas still hold the same parameters after the steps
+        cs = flat_param.float().abs().sum().double().reshape(1) if flat_param.dtype != torch.float64 else flat_param.abs().sum().reshape(1)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        in_sync = bool(lo.item() == hi.item())
+    ms = 1e3 * elapsed / max(1, steps)
+    mean = lambda v: (sum(v) / len(v)) if v else None
+    rnd = lambda v, n=3: None if v is None else round(v, n)
+    return {
+        "backend": dist.get_backend(), "ranks_seen": int(round(ones.item())), "world_size": dist.get_world_size(),
+        "collectives_per_step": round(probe.collectives / max(1, steps), 2),
+        "allgather_calls_per_step": round(len(probe.gather) / max(1, steps), 2), "allgather_bytes_per_rank": probe.gather_bytes,
+        "allgather_wait_us": rnd(mean(g_us), 1), "allgather_wait_us_max": rnd(max(g_us) if g_us else None, 1),
+        "allreduce_bytes": reducer.flat.numel() * reducer.flat.element_size(), "allreduce_buckets": len(reducer.buckets),
+        "allreduce_exposed_ms": rnd(mean(r_ms)), "allreduce_exposed_ms_max": rnd(max(r_ms) if r_ms else None),
+        "late_buckets": reducer.late_buckets,
+        "loss_min_over_ranks": lmin, "loss_max_over_ranks": lmax, "loss_equal_over_ranks": bool(lmin == lmax),
+        "params_in_sync": in_sync,
+        "ms_per_step_min_over_ranks": rnd(red(ms, dist.ReduceOp.MIN)), "ms_per_step_max_over_ranks": rnd(red(ms, dist.ReduceOp.MAX)),
+        "timer": ("HIP events on the launch stream around EmbeddingGather.wait / FlatGradAllReducer.finish" if probe.use_events
+                  else "host clock (CPU rehearsal)"),
+    }
+
+
+def _under_profiler():
+    """rocprofv3 (and rocprof) preload their tool library into the program they run; with counters it initialises the GPU before
+    main() starts.  Spawning rank processes from such a process is the exec-after-GPU-init hop this pool forbids."""
+    pre = os.environ.get("LD_PRELOAD", "")
+    return ("rocprof" in pre.lower() or any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ))
+
+
 def self_launch(n):
     """Spawn `n` rank processes of this script under torch.distributed.run (one per GPU, RCCL rendezvous on 127.0.0.1) and
     relay their output; rank 0 prints the JSON line.  Returns the launcher's exit code."""
     import socket
     import subprocess
+    if _under_profiler():
+        print("bench.py: refusing to start rank processes from under a profiler (its preloaded tool library may already have "
+              "initialised the GPU in this process).  Profile the single-process form instead: "
+              "rocprofv3 ... -- python3 bench.py --gpus 1 [--force-dist]", file=sys.stderr)
+        return 2
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -453,15 +572,40 @@ def self_launch(n):
 
 
 def rehearse_launch(rank, world):
-    """What every rank does around the timed region, without a GPU: process group up (gloo), barrier, MAX over ranks."""
+    """What every rank does around the timed region, without a GPU: process group up (gloo), barrier, MAX over ranks, and the
+    `comm` block of the N > 1 line built by the same code from a toy replica (one all-gather + a bucketed gradient mean per
+    step through the product's own EmbeddingGather / FlatGradAllReducer)."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29655")
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dist.barrier()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    from rankpo_amd.distributed import EmbeddingGather, FlatGradAllReducer
+    probe = CommProbe(use_events=False)
+    probe.install()
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(16, 4)
+    red_ = FlatGradAllReducer(list(lin.parameters()), bucket_mb=1e-4)
+    probe.enabled = True
+    steps, t0, loss = 3, time.perf_counter(), None
+    for i in range(steps):
+        x = torch.full((6, 16), float(rank + i + 1))
+        emb = lin(x)
+        allrows = EmbeddingGather(emb).wait()                    # [W * 6, 4]
+        loss = allrows.detach().pow(2).mean()                    # over the gathered rows: the same value on every rank
+        red_.arm()
+        (emb.pow(2).mean()).backward()
+        scale = red_.finish()
+        with torch.no_grad():
+            for p_ in lin.parameters():
+                p_ -= 0.1 * scale * p_.grad
+        red_.zero_()
+    probe.enabled = False
+    flat = torch.cat([p_.detach().reshape(-1) for p_ in lin.parameters()])
+    comm = comm_block(probe, torch.device("cpu"), red_, loss, time.perf_counter() - t0, steps, flat_param=flat)
     if rank == 0:
-        print(json.dumps({"rehearsal": "launch", "n_gpus": world, "max_over_ranks": t.item()}), flush=True)
+        print(json.dumps({"rehearsal": "launch", "n_gpus": world, "max_over_ranks": t.item(), "comm": comm}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -569,6 +713,10 @@ def main():
     timed = TimedLib(_lib.load())
     if not args.no_kernel_timing:
         _lib._lib = timed
+    probe = None
+    if multi:
+        probe = CommProbe(use_events=True)
+        probe.install()
     if args.workload == "cfg4":
         # RankPO stage (rankpo_trainer.py:570-587): policy = the bare encoder, no reference model (reference_free),
         # metrics stay on the device (one host copy per LOG step, not per micro-step)
@@ -606,20 +754,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timed.enabled = not args.no_kernel_timing
+    if probe is not None:
+        probe.enabled = True
     t0 = time.perf_counter()
     for i in range(args.warmup, args.warmup + args.steps):
         losses.append(ts.step(micro(i)))
     torch.cuda.synchronize()
+    t_local = time.perf_counter() - t0          # this rank's own K steps (before it waits for the slowest rank)
     if multi:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     timed.enabled = False
     note(f"timed {args.steps} steps in {elapsed:.3f} s")
+    comm = None
     if multi:
+        probe.enabled = False
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
+        comm = comm_block(probe, device, ts.opt.reducer, losses[-1], t_local, args.steps, flat_param=ts.opt.flat_param)
     pairs = world * B * (1 + K) * gas * args.steps
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
@@ -643,6 +797,8 @@ def main():
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
             "peak_mem_GiB": round(peak_mem, 2),
         }
+        if comm is not None:
+            out["comm"] = comm
         if kernels:
             top = kernels[0]
             # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed

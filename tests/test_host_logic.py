@@ -310,12 +310,31 @@ def test_bench_launches_its_own_ranks():
                        timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1 and json.loads(lines[0]) == {"rehearsal": "launch", "n_gpus": 2, "max_over_ranks": 2.0}
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert {k: line[k] for k in ("rehearsal", "n_gpus", "max_over_ranks")} == {"rehearsal": "launch", "n_gpus": 2, "max_over_ranks": 2.0}
+    # the `comm` block of the N > 1 line (built by the same code, on gloo): every field present and populated, the backend saw
+    # both ranks, one all-gather + one bucket all-reduce per step, the redundantly computed loss identical on both ranks, the
+    # replicas' parameters still identical after the steps
+    import importlib
+    comm = line["comm"]
+    assert tuple(comm) == importlib.import_module("bench").COMM_KEYS
+    assert all(v is not None for v in comm.values()), comm
+    assert comm["backend"] == "gloo" and comm["ranks_seen"] == comm["world_size"] == 2
+    assert comm["allgather_calls_per_step"] == 1.0 and comm["collectives_per_step"] == 1.0 + comm["allreduce_buckets"]
+    assert comm["late_buckets"] == 0 and comm["loss_equal_over_ranks"] is True and comm["params_in_sync"] is True
+    assert comm["loss_min_over_ranks"] == comm["loss_max_over_ranks"] > 0
+    assert 0 < comm["ms_per_step_min_over_ranks"] <= comm["ms_per_step_max_over_ranks"]
+    assert comm["allgather_wait_us"] >= 0 and comm["allreduce_exposed_ms"] >= 0
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", "29717", bench, "--gpus", "2", "--rehearse-launch"],
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     assert [json.loads(ln)["n_gpus"] for ln in r.stdout.splitlines() if ln.startswith("{")] == [2]
+    # from under a profiler (its tool library is preloaded and may have initialised the GPU) the parent must not spawn ranks
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-launch"], capture_output=True, text=True,
+                       timeout=120, env=dict(env, ROCPROF_REHEARSAL_MARKER="1"))   # a key of the family rocprofv3 exports, harmless by itself
+    assert r.returncode == 2 and "refusing to start rank processes from under a profiler" in r.stderr
     # a world-size mismatch is refused, not silently run
     r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-launch"], capture_output=True, text=True,
                        timeout=120, env=dict(env, WORLD_SIZE="1", RANK="0"))

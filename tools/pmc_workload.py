@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""ONE pass over every hand-written entry point of the training step at its cfg-2 shape (and the head_dim-128 attention at
+cfg 5's), through the C ABI, for the rocprofv3 counter passes behind `profiles/rNN_pmc_traffic.json`:
+
+    rocprofv3 --pmc FETCH_SIZE  --kernel-trace --output-format csv -d <dir>/fetch -- python3 tools/pmc_workload.py
+    rocprofv3 --pmc WRITE_SIZE  --kernel-trace --output-format csv -d <dir>/write -- python3 tools/pmc_workload.py
+    rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d <dir>/tcc -- python3 tools/pmc_workload.py
+    python3 tools/pmc_workload.py --algo > <dir>/algo.json          (no profiler: algorithmic bytes + HIP-event times)
+    python3 tools/pmc_assemble.py <dir> profiles/rNN_pmc_traffic.json
+
+Every kernel is launched REPS times (default 2, the assembler takes the median dispatch); attention runs with the rotary fold on
+(q rotated by the forward, inverse rotation in the dQ / dK epilogues), as the encoder calls it.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from rankpo_amd import _lib, ops  # noqa: E402
+
+ALGO = "--algo" in sys.argv
+REPS = int(os.environ.get("REPS", "2"))
+DEV = "cuda:0"
+bf = torch.bfloat16
+lib = _lib.load()
+st = lambda: torch.cuda.current_stream().cuda_stream
+torch.manual_seed(0)
+report = {}
+
+
+def run(entry, kernels, shape, algo_bytes, fn, algo_flops=0):
+    """entry: C entry point (or a label when one entry point is measured at several shapes); kernels: kernel names it launches."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(REPS):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / REPS
+    report[entry] = {"kernels": kernels, "shape": shape, "algo_bytes": int(algo_bytes), "algo_flops": int(algo_flops),
+                     "event_us": round(us, 1)}
+    print(f"{entry:28s} {us:10.1f} us  {algo_bytes / us / 1e3:8.1f} GB/s algorithmic", file=sys.stderr, flush=True)
+
+
+# ---- streaming kernels of the Llama block, cfg-2 packed tokens -----------------------------------------------------------------
+T, d, ff = 151552, 2048, 8192                                  # 592 x 256 tokens: a typical packed cfg-2 step
+gu = torch.randn(T, 2 * ff, device=DEV, dtype=bf)
+prod = torch.empty(T, ff, device=DEV, dtype=bf)
+run("rpo_swiglu_fwd", ["swiglu_fwd_kernel"], f"{T} x {ff} bf16 (halves of one gate|up buffer)", 3 * T * ff * 2,
+    lambda: lib.rpo_swiglu_fwd(gu.data_ptr(), gu.data_ptr() + ff * 2, prod.data_ptr(), T, ff, 2 * ff, ff, 1, st()))
+dgu = torch.empty_like(gu)
+run("rpo_swiglu_bwd", ["swiglu_bwd_kernel"], f"{T} x {ff} bf16, product rewritten over dprod", 6 * T * ff * 2,
+    lambda: lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * 2, prod.data_ptr(), dgu.data_ptr(), dgu.data_ptr() + ff * 2,
+                               prod.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, ff, 1, st()))
+del gu, dgu, prod
+nh, nkv, hd = 32, 8, 64
+W = (nh + 2 * nkv) * hd
+qkv = torch.randn(T, W, device=DEV, dtype=bf)
+fr = torch.outer(torch.arange(T, device=DEV).float() % 4096, 1.0 / (5e5 ** (torch.arange(0, hd, 2, device=DEV).float() / hd)))
+cs, sn = fr.cos().contiguous(), fr.sin().contiguous()
+kptr = qkv.data_ptr() + nh * hd * 2
+run("rpo_rope", ["rope_kernel"], f"{T} tokens x {nkv} k heads x {hd} in place inside the fused q|k|v row (the fold leaves k only)",
+    2 * T * nkv * hd * 2 + T * hd * 4,
+    lambda: lib.rpo_rope(kptr, kptr, W, cs.data_ptr(), sn.data_ptr(), T, nkv, hd, T, 1, 0, st()))
+del qkv
+x = torch.randn(T, d, device=DEV, dtype=bf)
+dl = torch.randn(T, d, device=DEV, dtype=bf)
+w = torch.ones(d, device=DEV, dtype=bf)
+xo, y = torch.empty_like(x), torch.empty_like(x)
+rstd = torch.empty(T, device=DEV)
+run("rpo_add_rmsnorm_fwd", ["add_rmsnorm_fwd_kernel"], f"{T} x {d} bf16 with residual add", 4 * T * d * 2 + 4 * T,
+    lambda: lib.rpo_add_rmsnorm_fwd(x.data_ptr(), dl.data_ptr(), w.data_ptr(), 1e-5, xo.data_ptr(), y.data_ptr(), rstd.data_ptr(),
+                                    T, d, 1, st()))
+nw = lib.rpo_add_rmsnorm_waves(T)
+dwp = torch.empty(nw, d, device=DEV)
+dx = torch.empty_like(x)
+run("rpo_add_rmsnorm_bwd", ["add_rmsnorm_bwd_kernel"], f"{T} x {d} bf16 with residual gradient", 4 * T * d * 2 + 4 * T + nw * d * 4,
+    lambda: lib.rpo_add_rmsnorm_bwd(y.data_ptr(), xo.data_ptr(), w.data_ptr(), rstd.data_ptr(), dl.data_ptr(), dx.data_ptr(),
+                                    dwp.data_ptr(), T, d, 1, st()))
+xt = torch.empty(d, T, device=DEV, dtype=bf)
+run("rpo_transpose", ["transpose_kernel"], f"[{T}, {d}] bf16 -> [{d}, {T}]", 2 * T * d * 2,
+    lambda: lib.rpo_transpose(x.data_ptr(), xt.data_ptr(), T, d, d, T, 1, st()))
+del x, dl, xo, y, dx, xt
+
+# ---- optimizer -------------------------------------------------------------------------------------------------------------------
+n = 1_235_828_736
+par = torch.zeros(n, device=DEV, dtype=bf)
+mas = torch.zeros(n, device=DEV)
+grd = torch.full((n,), 1e-3, device=DEV, dtype=bf)
+m1, m2 = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+sc = torch.ones(1, device=DEV)
+part = torch.empty(1024, device=DEV)
+run("rpo_adamw_step", ["adamw_kernel"], "1.236 G bf16 parameters + f32 master / m / v", n * (2 * 2 + 24),
+    lambda: lib.rpo_adamw_step(par.data_ptr(), mas.data_ptr(), grd.data_ptr(), m1.data_ptr(), m2.data_ptr(), n, 1, 1e-5, 0.9, 0.999,
+                               1e-8, 0.0, 0.1, 0.001, sc.data_ptr(), st()))
+run("rpo_sumsq_partial", ["sumsq_kernel"], "1.236 G bf16", n * 2,
+    lambda: lib.rpo_sumsq_partial(grd.data_ptr(), n, 1, part.data_ptr(), 1024, st()))
+del par, mas, grd, m1, m2
+
+# ---- similarity + InfoNCE on the scaled sweep -----------------------------------------------------------------------------------
+Q = 16384
+q = torch.nn.functional.normalize(torch.randn(Q, d, device=DEV), dim=-1).to(bf)
+p = torch.nn.functional.normalize(torch.randn(Q, d, device=DEV), dim=-1).to(bf)
+scores = torch.empty(Q, Q, device=DEV, dtype=bf)
+lse, loss = torch.empty(Q, device=DEV), torch.empty((), device=DEV)
+nws = lib.rpo_infonce_workspace_bytes(Q, Q, d, 1)
+ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+run("rpo_infonce_fwd", ["sim_tile256_kernel", "ce_finalize_kernel"], f"Q = P = {Q}, d = {d} bf16", 2 * Q * d * 2 + Q * Q * 2 + 4 * Q,
+    lambda: lib.rpo_infonce_fwd(q.data_ptr(), p.data_ptr(), Q, Q, d, 1, 0.02, 0, scores.data_ptr(), lse.data_ptr(), loss.data_ptr(),
+                                ws.data_ptr(), nws, st()), algo_flops=2 * Q * Q * d)
+del q, p, scores, ws
+
+
+# ---- flash attention, rotary fold on ---------------------------------------------------------------------------------------------
+def attention(tag, nh, nkv, hd, N, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(L // 2, L + 1, (N,), generator=g)
+    lens[0] = L
+    lens = lens.tolist()
+    lens += [(-sum(lens)) % 256 or 256]                                # the encoder's filler sequence
+    T = sum(lens)
+    W = (nh + 2 * nkv) * hd
+    qkv = torch.randn(T, W, device=DEV).to(bf)
+    pos = torch.cat([torch.arange(n) for n in lens]).to(DEV).float()
+    fr = torch.outer(pos, 1.0 / (5e5 ** (torch.arange(0, hd, 2, device=DEV).float() / hd)))
+    rope = (fr.cos().contiguous(), fr.sin().contiguous())
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    tiles = ops.attn_tile_table(lens, DEV, nh, nkv)
+    kb = ops.ATTN_KEY_BLOCK if hd == 64 else ops.ATTN_KEY_BLOCK_HD128
+    kt = ops.attn_key_tile_table(lens, DEV, nkv, kb)
+    views = lambda t: (t[:, :nh * hd].unflatten(1, (nh, hd)), t[:, nh * hd:(nh + nkv) * hd].unflatten(1, (nkv, hd)),
+                       t[:, (nh + nkv) * hd:].unflatten(1, (nkv, hd)))
+    scale = 1.0 / hd ** 0.5
+    state = {}
+
+    def fwd():
+        # (each call rotates q in place once more: a rotation keeps magnitudes, and traffic / time do not depend on the angle)
+        qv, kv_, vv = views(qkv)
+        state["out"], state["lse"] = ops.flash_attn_varlen_fwd(qv, kv_, vv, cu, tiles, scale, rope=rope)
+    pairs = sum(n * (n + 1) // 2 for n in lens)
+    fwd_k = ["fa_fwd_kernel"] if hd == 64 else ["fa_fwd128_kernel"]
+    bwd_k = ["fa_bwd_dq_kernel", "fa_bwd_dkdv4_kernel"] if hd == 64 else ["fa_bwd_dq128_kernel", "fa_bwd_dkdv128_kernel"]
+    shape = f"{len(lens)} sequences (filler included), T = {T}, {nh} q heads / {nkv} kv heads, head_dim {hd}, rotary folded in"
+    run(f"rpo_flash_attn_fwd{tag}", fwd_k, shape, 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh, fwd, algo_flops=4 * hd * pairs * nh)
+    go = torch.randn_like(state["out"])
+    dqkv = torch.empty_like(qkv)
+
+    def bwd():
+        qv, kv_, vv = views(qkv)
+        ops.flash_attn_varlen_bwd(qv, kv_, vv, state["out"], go, state["lse"], cu, tiles, kt, scale, grads=views(dqkv), key_block=kb,
+                                  rope=rope)
+    run(f"rpo_flash_attn_bwd{tag}", bwd_k, shape, 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, bwd, algo_flops=10 * hd * pairs * nh)
+
+
+attention("", 32, 8, 64, 48, 4096, 0)                # cfg 2: the passage tower of one step
+attention("@hd128", 32, 8, 128, 24, 4096, 1)         # cfg 5 (Llama-3-8B architecture)
+torch.cuda.synchronize()
+if ALGO:
+    print(json.dumps(report, indent=1))
