@@ -35,6 +35,14 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak
 MFMA_F32_PEAK_TFLOPS = 157.3
+PMC_FILE = "profiles/r03_pmc_traffic.json"
+
+# MFMA products an entry point EXECUTES per algorithmic product (recomputation it does by design), so that the line shows both
+# rates: what the matrix pipe does and what the caller gets.
+EXECUTED_OVER_ALGO = {
+    "rpo_flash_attn_bwd": (7, 5, "two launches, no atomics: the dQ kernel recomputes S and dP (3 products: S, dP, dQ), the dK/dV "
+                                 "kernel computes S, dP, dV, dK (4); 5 are algorithmic"),
+}
 
 WORKLOADS = {
     # name: (arch, B, K, Lq, Lp, temperature, dtype).  K = 1 + "rankpo": chosen/rejected pairs (BASELINE configs[3]).
@@ -123,11 +131,13 @@ def _algo(name, a):
     if name == "rpo_flash_attn_fwd":
         T, nh, nkv, hd = a[10], a[11], a[12], a[13]          # a[9] = tile_cols
         pairs = _attn_pairs(T)                            # causal (query, key) pairs of this packed batch
-        return 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh, 4 * hd * pairs * nh
+        fold = (2 * T * nh * hd + 4 * T * hd) if a[19] is not None else 0      # rotary fold: rotated q written back, tables read
+        return 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh + fold, 4 * hd * pairs * nh
     if name == "rpo_flash_attn_bwd":
         T, nh, nkv, hd = a[18], a[19], a[20], a[21]        # a[13] = q_tile_cols, a[16] = key_block, a[17] = sweep_down
         pairs = _attn_pairs(T)
-        return 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, 10 * hd * pairs * nh
+        fold = 4 * T * hd if a[31] is not None else 0                          # rotary fold: cos / sin rows read by the epilogues
+        return 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh + fold, 10 * hd * pairs * nh
     if name == "rpo_transpose":
         rows, cols, dt = a[2], a[3], a[6]
         return 2 * rows * cols * _es(dt), 0
@@ -165,15 +175,18 @@ class TimedLib:
             rc = fn(*a)
             e1.record(s)
             b, f = _algo(name, a)
-            self.records.append((name, e0, e1, b, f))
+            hd = a[13] if name == "rpo_flash_attn_fwd" else a[21] if name == "rpo_flash_attn_bwd" else 0
+            self.records.append((name, e0, e1, b, f, hd))
             return rc
         return wrapped
 
     def summary(self):
         agg = {}
-        for name, e0, e1, b, f in self.records:
+        for name, e0, e1, b, f, hd in self.records:
             ms = e0.elapsed_time(e1)
             d = agg.setdefault(name, dict(calls=0, ms=0.0, bytes=0, flops=0))
+            if hd:
+                d["head_dim"] = hd
             d["calls"] += 1
             d["ms"] += ms
             d["bytes"] += b
@@ -185,10 +198,17 @@ class TimedLib:
             tfs = d["flops"] / d["calls"] / (avg_us * 1e-6) / 1e12
             # the roofline that bounds the entry point: MFMA when its flops / byte exceed the machine balance
             bound = "mfma" if d["flops"] * HBM_PEAK_GBS * 1e9 > d["bytes"] * MFMA_BF16_PEAK_TFLOPS * 1e12 else "hbm"
-            out.append(dict(entry=name, calls=d["calls"], avg_us=round(avg_us, 2), total_ms=round(d["ms"], 3),
-                            algo_bytes=d["bytes"] // d["calls"], algo_flops=d["flops"] // d["calls"], bound=bound,
-                            achieved_GBs=round(gbs, 2), frac_hbm=round(gbs / HBM_PEAK_GBS, 5),
-                            achieved_TFLOPs=round(tfs, 2), frac_mfma=round(tfs / MFMA_BF16_PEAK_TFLOPS, 5)))
+            row = dict(entry=name, calls=d["calls"], avg_us=round(avg_us, 2), total_ms=round(d["ms"], 3),
+                       algo_bytes=d["bytes"] // d["calls"], algo_flops=d["flops"] // d["calls"], bound=bound,
+                       achieved_GBs=round(gbs, 2), frac_hbm=round(gbs / HBM_PEAK_GBS, 5),
+                       achieved_TFLOPs=round(tfs, 2), frac_mfma=round(tfs / MFMA_BF16_PEAK_TFLOPS, 5))
+            if name in EXECUTED_OVER_ALGO:
+                ex, al, why = EXECUTED_OVER_ALGO[name]
+                row.update(executed_TFLOPs=round(tfs * ex / al, 2), frac_mfma_executed=round(tfs * ex / al / MFMA_BF16_PEAK_TFLOPS, 5),
+                           executed_note=f"{ex} MFMA products executed per {al} algorithmic: {why}")
+            if d.get("head_dim"):
+                row["head_dim"] = d["head_dim"]
+            out.append(row)
         out.sort(key=lambda r: -r["total_ms"])
         return out
 
@@ -801,38 +821,29 @@ def main():
             out["comm"] = comm
         if kernels:
             top = kernels[0]
-            # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed
-            # rocprofv3 passes (profiles/r02_pmc_traffic.json: 2 x FETCH_SIZE + WRITE_SIZE over algorithmic bytes,
-            # measured per kernel at the same shapes) give the ratio that is applied to this run's bytes.
+            # HBM traffic per launch: PMC counters cannot be read from inside this process; the committed rocprofv3 passes
+            # (profiles/r03_pmc_traffic.json, taken at the commit it names: 2 x FETCH_SIZE + WRITE_SIZE per kernel, separate
+            # passes, tools/pmc_workload.py at the cfg-2 / cfg-5 shapes) give the traffic / algorithmic ratio of THIS entry
+            # point's kernels, which is applied to this run's algorithmic bytes.
             traffic, tsrc = None, None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                key = {"rpo_swiglu_fwd": "swiglu_fwd_kernel", "rpo_swiglu_bwd": "swiglu_bwd_kernel",
-                       "rpo_adamw_step": "adamw_kernel", "rpo_rope": "rope_kernel",
-                       "rpo_sumsq_partial": "sumsq_kernel"}.get(top["entry"])
-                if key in pmc:
-                    traffic = int(top["algo_bytes"] * pmc[key]["traffic_over_algorithmic"])
-                    tsrc = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, "
-                            "FETCH x2 gfx950 correction), ratio %.3f applied to this run's algorithmic bytes"
-                            % pmc[key]["traffic_over_algorithmic"])
+                pmc = json.load(open(os.path.join(ROOT, PMC_FILE)))
+                key = top["entry"] + ("@hd128" if top.get("head_dim") == 128 else "")
+                if key in pmc and pmc[key].get("traffic_over_algorithmic"):
+                    ratio = pmc[key]["traffic_over_algorithmic"]
+                    traffic = int(top["algo_bytes"] * ratio)
+                    tsrc = (f"{PMC_FILE} (commit {pmc.get('_meta', {}).get('head')}): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                            f"passes, FETCH x2 gfx950 correction, kernels {pmc[key]['kernels']} on {pmc[key]['shape']}: ratio "
+                            f"{ratio:.3f} applied to this run's algorithmic bytes")
             except Exception:
                 pass
             if top["bound"] == "mfma":
-                mtraffic, msrc = None, None
-                try:
-                    pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-                    if top["entry"] in pmc:
-                        ratio = pmc[top["entry"]]["traffic_over_algorithmic"]
-                        mtraffic = int(top["algo_bytes"] * ratio)
-                        msrc = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, FETCH "
-                                "x2 gfx950 correction) of this entry point's kernels on the cfg-2 passage batch, ratio %.2f "
-                                "applied to this run's algorithmic bytes" % ratio)
-                except Exception:
-                    pass
                 out["roofline"] = {"kernel": top["entry"], "bound": "mfma", "achieved": top["achieved_TFLOPs"],
                                    "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": top["frac_mfma"],
-                                   "traffic": mtraffic, "traffic_source": msrc, "avg_us": top["avg_us"],
+                                   "traffic": traffic, "traffic_source": tsrc, "avg_us": top["avg_us"],
                                    "algo_flops": top["algo_flops"], "algo_bytes": top["algo_bytes"]}
+                if "executed_TFLOPs" in top:
+                    out["roofline"].update({k: top[k] for k in ("executed_TFLOPs", "frac_mfma_executed", "executed_note")})
             else:
                 out["roofline"] = {"kernel": top["entry"], "bound": "hbm", "achieved": top["achieved_GBs"],
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": traffic,

@@ -356,7 +356,7 @@ def test_bench_attention_flops_follow_the_kernel_arguments():
         ops.attn_tile_table(lens, "cpu")
         T = sum(lens)
         assert T % 256 == 0
-        a = [None] * 22
+        a = [None] * 35
         a[16:22] = 256, 0, T, 32, 8, 64
         nbytes, flops = bench._algo("rpo_flash_attn_bwd", a)
         assert flops == 10 * 64 * 32 * sum(n * (n + 1) // 2 for n in lens) > 0

@@ -146,7 +146,10 @@ def attention(tag, nh, nkv, hd, N, L, seed):
     fwd_k = ["fa_fwd_kernel"] if hd == 64 else ["fa_fwd128_kernel"]
     bwd_k = ["fa_bwd_dq_kernel", "fa_bwd_dkdv4_kernel"] if hd == 64 else ["fa_bwd_dq128_kernel", "fa_bwd_dkdv128_kernel"]
     shape = f"{len(lens)} sequences (filler included), T = {T}, {nh} q heads / {nkv} kv heads, head_dim {hd}, rotary folded in"
-    run(f"rpo_flash_attn_fwd{tag}", fwd_k, shape, 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh, fwd, algo_flops=4 * hd * pairs * nh)
+    # algorithmic bytes with the fold: q, k, v read + out, lse written, + the rotated q written back and the cos / sin rows read
+    # (what the separate rotary pass over the q heads would have moved twice)
+    run(f"rpo_flash_attn_fwd{tag}", fwd_k, shape, 2 * T * (2 * nh + 2 * nkv) * hd + 4 * T * nh + 2 * T * nh * hd + 4 * T * hd, fwd,
+        algo_flops=4 * hd * pairs * nh)
     go = torch.randn_like(state["out"])
     dqkv = torch.empty_like(qkv)
 
@@ -154,7 +157,8 @@ def attention(tag, nh, nkv, hd, N, L, seed):
         qv, kv_, vv = views(qkv)
         ops.flash_attn_varlen_bwd(qv, kv_, vv, state["out"], go, state["lse"], cu, tiles, kt, scale, grads=views(dqkv), key_block=kb,
                                   rope=rope)
-    run(f"rpo_flash_attn_bwd{tag}", bwd_k, shape, 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh, bwd, algo_flops=10 * hd * pairs * nh)
+    run(f"rpo_flash_attn_bwd{tag}", bwd_k, shape, 2 * T * (4 * nh + 4 * nkv) * hd + 12 * T * nh + 4 * T * hd, bwd,
+        algo_flops=10 * hd * pairs * nh)
 
 
 attention("", 32, 8, 64, 48, 4096, 0)                # cfg 2: the passage tower of one step
