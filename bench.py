@@ -163,7 +163,7 @@ class TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
-        if not name.startswith("rpo_") or name in ("rpo_version", "rpo_status_string", "rpo_last_hip_error", "rpo_infonce_workspace_bytes"):
+        if not name.startswith("rpo_") or name in ("rpo_version", "rpo_status_string", "rpo_last_hip_error", "rpo_infonce_workspace_bytes", "rpo_add_rmsnorm_waves"):
             return fn
 
         def wrapped(*a):
@@ -867,6 +867,18 @@ def main():
                                              f"through the same {arch} weights: {toks} tokens, median of {len(times)} timed "
                                              f"steps after 1 untimed; pairs/s extrapolated linearly in tokens to "
                                              f"{toks_per_pair:.0f} tokens per full-length pair"}
+            try:        # what the port's time is worth in REFERENCE time (tools/time_reference.py, build container)
+                rc = json.load(open(os.path.join(ROOT, "profiles", "ref_cpu_container.json")))
+                por = rc["port_over_reference"]
+                out["cpu_baseline"].update({
+                    "port_over_reference": por,
+                    "reference_equivalent_value": round(out["cpu_baseline"]["value"] * por, 5),
+                    "port_over_reference_source": ("profiles/ref_cpu_container.json: the reference itself (imported, unmodified) and this "
+                                                   f"port timed on the same cfg-1 step in the build container ({rc['host']['threads']} threads of "
+                                                   f"{rc['host']['cpu_model']}): reference {rc['full_step_cfg1']['reference_median_s']} s, port "
+                                                   f"{rc['full_step_cfg1']['port_median_s']} s per step; the reference cannot travel to the GPU box")})
+            except Exception:
+                pass
             if not out["step_loss_parity"]["pass"]:
                 print(json.dumps(out), flush=True)
                 raise SystemExit("step_loss_parity FAILED: " + ", ".join(out["step_loss_parity"]["failed"]))
