@@ -260,6 +260,26 @@ int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* 
                        int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, const float* rope_cos, const float* rope_sin,
                        int64_t rope_period, rpo_stream_t stream);
 
+/* One-query-per-sequence attention (rankpo_amd/csrc/lastq_attention.hip): the attention of the LAST block of a last-token-pooled
+ * encoder.  The reference pools `last_hidden_state[n, last real token]` (modeling.py:224-230, rankpo_trainer.py:409-413), so the
+ * last block's attention output is read for ONE query per sequence -- its last token, which sees every key of its sequence (no
+ * mask).  Stands where the packed encoder path called PyTorch's flash-attention op (an AOTriton kernel) with one-row queries.
+ *   q: [num_seqs, num_heads, hd] bf16 (sequence stride q_stride elements, heads contiguous) -- already rotated;
+ *   k / v: [T, num_kv_heads, hd] packed tokens (token strides k_stride / v_stride; k rotated), cu_seqlens: int32 [num_seqs + 1];
+ *   out: [num_seqs, num_heads * hd] bf16; lse: f32 [num_seqs][num_heads] = log sum_j exp(scale <q, k_j>).
+ * HBM-bound: K / V are read exactly once (one block per (sequence, kv head) serves the whole query-head group); f32 online
+ * softmax, deterministic (fixed merge order, no atomics).  head_dim 64 or 128, num_heads / num_kv_heads in {1, 2, 4}; anything
+ * else is RPO_ERR_UNSUPPORTED.
+ * Backward: one pass over K / V; writes EVERY row of dk / dv ([T, num_kv_heads, hd], token strides given: e.g. the two halves of
+ * one fused d(k|v) buffer) and dq [num_seqs, num_heads, hd]; out / dout / lse as produced / received by the forward. */
+int rpo_lastq_attn_fwd(const void* q, int64_t q_stride, const void* k, const void* v, int64_t k_stride, int64_t v_stride,
+                       const int* cu_seqlens, int64_t num_seqs, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim,
+                       float scale, void* out, int64_t out_stride, float* lse, rpo_stream_t stream);
+int rpo_lastq_attn_bwd(const void* q, int64_t q_stride, const void* k, const void* v, int64_t k_stride, int64_t v_stride,
+                       const int* cu_seqlens, int64_t num_seqs, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim,
+                       float scale, const void* out, int64_t out_stride, const void* dout, int64_t dout_stride, const float* lse,
+                       void* dq, int64_t dq_stride, void* dk, void* dv, int64_t dk_stride, int64_t dv_stride, rpo_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (8) exact top-k over score rows, merged chunk by chunk ("next" row f3: the k-selection of faiss.IndexFlatIP.search,
  * reference src/utils.py:58-80).  scores: [rows, cols] (row stride ld elements) of the chunk whose first column is corpus

@@ -374,8 +374,14 @@ class LlamaLayer(nn.Module):
         if _ops.fused_encoder_ops_ok(x, att.hd):
             q = _ops.rope_(q, rope_last.cos32, rope_last.sin32, att.nh, att.hd)
             kv = _ops.rope_(kv, rope.cos32, rope.sin32, att.nkv, att.hd, grad_inplace=True)   # rotates the k heads only
+            q = q.view(-1, att.nh, att.hd)
+            if ctx.tiles is not None and _ops.last_query_attn_ok(q, kv, att.nh, att.nkv, att.hd):
+                # hand-written one-query-per-sequence attention on the fused k|v buffer (ctx.tiles: hand_attention is on)
+                o = _ops.last_query_attn(q, kv, ctx.cu, att.nkv, att.hd, 1.0 / math.sqrt(att.hd))
+                xl = x[0].index_select(0, last_idx) + att.o_proj(o.reshape(-1, att.nh * att.hd))
+                return xl + self.mlp(self.post_attention_layernorm(xl))
             k, v = kv.split([nk, nk], dim=-1)
-            q, k = q.view(-1, att.nh, att.hd), k.view(T, att.nkv, att.hd)
+            k = k.view(T, att.nkv, att.hd)
         else:
             k, v = kv.split([nk, nk], dim=-1)
             q, k = q.view(-1, att.nh, att.hd), k.view(T, att.nkv, att.hd)
@@ -397,7 +403,12 @@ class LlamaEncoder(nn.Module):
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
         self.layers = nn.ModuleList(LlamaLayer(config) for _ in range(config.num_hidden_layers))
         self.norm = RMSNorm(config.hidden_size, config.rms_norm_eps)
-        self.register_buffer("inv_freq", _rope_inv_freq(config), persistent=False)
+        # The rotary frequencies are NOT a module buffer: `module.to(torch.bfloat16)` casts floating-point buffers too, and a
+        # frequency rounded to bf16 (8 significant bits) turns position 4096 by up to 2^-9 x 4096 = 8 rad the wrong way -- the
+        # pooled embeddings of 4096-token rows then sit 0.8 % (cosine) off the float32 reference arithmetic and the weight gradients 43 %
+        # (tests/test_gpu_fastpath.py::test_real_width_and_length_parity; short rows hide it: the error grows with the position).
+        # HF computes inv_freq in float32 whatever the model dtype; so does this: a float32 tensor per device, never cast.
+        self._inv_freq = {"cpu": _rope_inv_freq(config)}
         self.gradient_checkpointing = False
         self.checkpoint_layers = None      # None = all layers when gradient_checkpointing, else the first k
         self.pack_fill = True              # packed path: round the token count up to a multiple of 256 with a filler sequence
@@ -435,9 +446,18 @@ class LlamaEncoder(nn.Module):
         self.config.vocab_size = n
         return new
 
+    @property
+    def inv_freq(self) -> torch.Tensor:
+        """float32 rotary frequencies (host copy); see __init__ for why this is not a buffer."""
+        return self._inv_freq["cpu"]
+
     def _rope(self, pos):
         # same op order as HF LlamaRotaryEmbedding: f32 outer product of positions and inverse frequencies
-        return RopeTables(torch.outer(pos.to(torch.float32), self.inv_freq.to(device=pos.device, dtype=torch.float32)))
+        key = str(pos.device)
+        inv = self._inv_freq.get(key)
+        if inv is None:
+            inv = self._inv_freq[key] = self._inv_freq["cpu"].to(pos.device)
+        return RopeTables(torch.outer(pos.to(torch.float32), inv))
 
     def _mask(self, attention_mask, L, dtype):
         """None (pure causal attention, module docstring) when the MASK ITSELF is right-padded -- every row is ones followed
@@ -715,13 +735,12 @@ def load_encoder(path: str, torch_dtype=None) -> nn.Module:
         sd = {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in sd.items()}
     enc = enc.to_empty(device="cpu")
     missing, unexpected = enc.load_state_dict(sd, strict=False)
-    missing = [m for m in missing if "inv_freq" not in m]
     unexpected = [u for u in unexpected if not (u.startswith("pooler.") or u.startswith("lm_head.") or
-                                               "position_ids" in u or "token_type_ids" in u)]
+                                               "position_ids" in u or "token_type_ids" in u or "inv_freq" in u)]
     if missing or unexpected:
         raise RuntimeError(f"checkpoint {path} does not match the encoder: missing={missing} unexpected={unexpected}")
     if "Llama" in arch:
-        enc.inv_freq = _rope_inv_freq(cfg)
+        enc._inv_freq = {"cpu": _rope_inv_freq(cfg)}         # (built under the meta device above)
     return enc.to(torch_dtype) if torch_dtype is not None else enc
 
 

@@ -812,6 +812,66 @@ def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scal
 
 
 # ------------------------------------------------------------------------------------------------
+# (7) one-query-per-sequence attention of the last block (encoder side)
+# ------------------------------------------------------------------------------------------------
+def last_query_attn_ok(q, kv, num_heads: int, num_kv_heads: int, head_dim: int) -> bool:
+    return (q.is_cuda and q.dtype == torch.bfloat16 and kv.dtype == torch.bfloat16 and head_dim in (64, 128)
+            and num_heads % num_kv_heads == 0 and num_heads // num_kv_heads in (1, 2, 4))
+
+
+class _LastQueryAttn(torch.autograd.Function):
+    """out[n] = softmax(scale q_n K_n^T) V_n for ONE query per sequence (its last token: no mask) on packed K / V that are the
+    two column halves of the fused k|v projection output `kv` [T, 2 nkv hd] (k rotated in place already).  The backward writes
+    ONE d(k|v) buffer of the same layout (no split / cat copies) and dq."""
+
+    @staticmethod
+    def forward(ctx, q, kv, cu, nkv, hd, scale):
+        lib = _lib.load()
+        N, nh = q.shape[0], q.shape[1]
+        kv2 = kv.view(-1, kv.shape[-1])
+        if q.stride(2) != 1 or q.stride(1) != hd or kv2.stride(1) != 1 or kv2.shape[1] != 2 * nkv * hd:
+            raise ValueError("last_query_attn: q [N, nh, hd] with contiguous heads, kv [T, 2 nkv hd] with contiguous rows")
+        out = torch.empty((N, nh, hd), dtype=q.dtype, device=q.device)
+        lse = torch.empty((N, nh), dtype=torch.float32, device=q.device)
+        es = kv2.element_size()
+        with torch.cuda.device(q.device):
+            check(lib.rpo_lastq_attn_fwd(q.data_ptr(), q.stride(0), kv2.data_ptr(), kv2.data_ptr() + nkv * hd * es, kv2.stride(0),
+                                         kv2.stride(0), cu.data_ptr(), N, nh, nkv, hd, scale, out.data_ptr(), nh * hd,
+                                         lse.data_ptr(), _stream(q)), "rpo_lastq_attn_fwd")
+        ctx.save_for_backward(q, kv, cu, out, lse)
+        ctx.meta = (nkv, hd, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, go):
+        q, kv, cu, out, lse = ctx.saved_tensors
+        nkv, hd, scale = ctx.meta
+        lib = _lib.load()
+        N, nh = q.shape[0], q.shape[1]
+        go = go.contiguous()
+        kv2 = kv.view(-1, kv.shape[-1])
+        dq = torch.empty((N, nh, hd), dtype=q.dtype, device=q.device)
+        dkv = torch.empty_like(kv)                              # every row of both halves is written by the kernel
+        d2 = dkv.view(-1, kv.shape[-1])
+        es = kv2.element_size()
+        with torch.cuda.device(q.device):
+            check(lib.rpo_lastq_attn_bwd(q.data_ptr(), q.stride(0), kv2.data_ptr(), kv2.data_ptr() + nkv * hd * es, kv2.stride(0),
+                                         kv2.stride(0), cu.data_ptr(), N, nh, nkv, hd, scale, out.data_ptr(), nh * hd,
+                                         go.data_ptr(), nh * hd, lse.data_ptr(), dq.data_ptr(), nh * hd, d2.data_ptr(),
+                                         d2.data_ptr() + nkv * hd * es, d2.stride(0), d2.stride(0), _stream(q)),
+                  "rpo_lastq_attn_bwd")
+        return dq, dkv, None, None, None, None
+
+
+def last_query_attn(q, kv, cu, num_kv_heads: int, head_dim: int, scale: float):
+    """q [N, nh, hd] (rotated), kv [..., T, 2 nkv hd] = the fused k|v projection output with k rotated; cu int32 [N + 1]
+    -> [N, nh, hd].  Sequence n's query attends to ALL keys of sequence n."""
+    if not kv.is_contiguous() or cu.numel() != q.shape[0] + 1:
+        raise ValueError("last_query_attn: kv must be contiguous and cu_seqlens must have one entry per query + 1")
+    return _LastQueryAttn.apply(q, kv, cu, num_kv_heads, head_dim, float(scale))
+
+
+# ------------------------------------------------------------------------------------------------
 # (8) exact top-k over score chunks (retrieval, "next" row f3)
 # ------------------------------------------------------------------------------------------------
 TOPK_MAX_K = 1024
@@ -843,5 +903,5 @@ def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
 
 __all__ = ["pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
-           "flash_attn_varlen", "flash_attn_varlen_qkv", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
+           "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
            "attn_key_tile_table"]

@@ -427,3 +427,103 @@ def test_flash_attn_fwd128_speed_report():
     a = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, scale)[0]
     b = torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False)[0]
     assert (a.float() - b.float()).abs().max() < 2.5e-2
+
+
+def _ref_last_query(q, k, v, lens, scale):
+    """f32 reference of the one-query-per-sequence attention: q [N, nh, hd] (the last token of each sequence), packed k / v."""
+    outs, lses, o0 = [], [], 0
+    nh, nkv = q.shape[1], k.shape[1]
+    for i, n in enumerate(lens):
+        kk = k[o0:o0 + n].float().transpose(0, 1).repeat_interleave(nh // nkv, 0)      # [nh, n, hd]
+        vv = v[o0:o0 + n].float().transpose(0, 1).repeat_interleave(nh // nkv, 0)
+        s = torch.einsum("hd,hnd->hn", q[i].float(), kk) * scale
+        lses.append(torch.logsumexp(s, -1))
+        outs.append(torch.einsum("hn,hnd->hd", torch.softmax(s, -1), vv))
+        o0 += n
+    return torch.stack(outs), torch.stack(lses)
+
+
+@pytest.mark.parametrize("hd,nh,nkv,lens", [
+    (64, 32, 8, [4096, 2049, 1, 7, 31, 32, 33, 300, 1280]), (64, 4, 4, [5, 64, 129]), (64, 8, 4, [1000, 17]),
+    (128, 32, 8, [4096, 1, 15, 16, 17, 513, 2050]), (128, 4, 2, [3, 300])])
+def test_last_query_attention_matches_reference(hd, nh, nkv, lens):
+    """rpo_lastq_attn_fwd / _bwd (the last block's attention: ONE query per sequence, all keys visible; reference: the encoder
+    forward behind modeling.py:219 + the pooling of :224-230) on the fused k|v buffer the encoder hands it, against an f32
+    reference on the same bf16 inputs and against PyTorch's flash-attention op, which this kernel replaced."""
+    from rankpo_amd import ops
+    torch.manual_seed(sum(lens) + hd)
+    T, N = sum(lens), len(lens)
+    scale = 1.0 / math.sqrt(hd)
+    kv = torch.randn(1, T, 2 * nkv * hd, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    q = torch.randn(N, nh, hd, device=DEV).to(torch.bfloat16).requires_grad_(True)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    assert ops.last_query_attn_ok(q, kv, nh, nkv, hd)
+    out = ops.last_query_attn(q, kv, cu, nkv, hd, scale)
+    go = torch.randn_like(out)
+    out.backward(go)
+    k, v = kv.detach()[0].split([nkv * hd, nkv * hd], -1)
+    k, v = k.reshape(T, nkv, hd), v.reshape(T, nkv, hd)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    ro, rl = _ref_last_query(qr, kr, vr, lens, scale)
+    ro.backward(go.float())
+    assert (out.float() - ro).abs().max() < 1e-2                       # f32 softmax and P.V: only the bf16 output rounding
+    dkv_ref = torch.cat([kr.grad.reshape(T, -1), vr.grad.reshape(T, -1)], -1)
+    for name, a, b in (("dq", q.grad, qr.grad), ("dkv", kv.grad[0], dkv_ref)):
+        err = (a.float() - b).abs().max().item()
+        rel = ((a.float() - b).norm() / b.norm().clamp_min(1e-30)).item()
+        assert err < 0.02 * max(1.0, b.abs().max().item()) and rel < 6e-3, (name, err, rel)
+    # PyTorch's op on the same inputs (what ran here before): no further from the f32 reference than that op
+    cu_q = torch.arange(N + 1, device=DEV, dtype=torch.int32)
+    po = torch.ops.aten._flash_attention_forward(q.detach(), k.contiguous(), v.contiguous(), cu_q, cu, 1, max(lens), 0.0, False,
+                                                 False, scale=scale)[0]
+    e_ours, e_theirs = (out.float() - ro).norm().item(), (po.float() - ro).norm().item()
+    assert e_ours <= 1.5 * e_theirs + 1e-6, (e_ours, e_theirs)
+    # deterministic: a second run is bit-identical (fixed merge order, no atomics)
+    q2, kv2 = q.detach().clone().requires_grad_(True), kv.detach().clone().requires_grad_(True)
+    out2 = ops.last_query_attn(q2, kv2, cu, nkv, hd, scale)
+    out2.backward(go)
+    assert torch.equal(out2, out) and torch.equal(q2.grad, q.grad) and torch.equal(kv2.grad, kv.grad)
+
+
+def test_last_query_attention_lse_and_speed_report():
+    """lse through the C call; prints the rate next to the PyTorch op on the cfg-2 shape (56 sequences, 32 / 8 heads)."""
+    from rankpo_amd import ops, _lib
+    torch.manual_seed(0)
+    nh, nkv, hd, N, L = 32, 8, 64, 56, 4096
+    lens = torch.randint(L // 2, L + 1, (N,)); lens[0] = L
+    lens = lens.tolist(); T = sum(lens)
+    kv = torch.randn(T, 2 * nkv * hd, device=DEV).to(torch.bfloat16)
+    q = torch.randn(N, nh, hd, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    lib = _lib.load()
+    out = torch.empty(N, nh, hd, device=DEV, dtype=torch.bfloat16)
+    lse = torch.empty(N, nh, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    call = lambda: lib.rpo_lastq_attn_fwd(q.data_ptr(), nh * hd, kv.data_ptr(), kv.data_ptr() + nkv * hd * 2, 2 * nkv * hd, 2 * nkv * hd,
+                                          cu.data_ptr(), N, nh, nkv, hd, 0.125, out.data_ptr(), nh * hd, lse.data_ptr(), st)
+    assert call() == 0
+    k, v = kv.split([nkv * hd, nkv * hd], -1)
+    ro, rl = _ref_last_query(q, k.reshape(T, nkv, hd), v.reshape(T, nkv, hd), lens, 0.125)
+    assert (lse - rl).abs().max() < 1e-4 and (out.float() - ro).abs().max() < 1e-2
+    # unsupported group size: refused, not mis-computed
+    assert lib.rpo_lastq_attn_fwd(q.data_ptr(), nh * hd, kv.data_ptr(), kv.data_ptr(), 2 * nkv * hd, 2 * nkv * hd, cu.data_ptr(), N, 32, 4,
+                                  hd, 0.125, out.data_ptr(), nh * hd, lse.data_ptr(), st) == -2
+
+    def bench(fn, n=20):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e6
+    kc, vc = k.reshape(T, nkv, hd).contiguous(), v.reshape(T, nkv, hd).contiguous()
+    cu_q = torch.arange(N + 1, device=DEV, dtype=torch.int32)
+    ours = bench(call)
+    theirs = bench(lambda: torch.ops.aten._flash_attention_forward(q, kc, vc, cu_q, cu, 1, max(lens), 0.0, False, False))
+    qg, kvg = q.clone().requires_grad_(True), kv.clone().requires_grad_(True)
+    o = ops.last_query_attn(qg, kvg, cu, nkv, hd, 0.125)
+    go = torch.randn_like(o)
+    ours_b = bench(lambda: torch.autograd.grad(o, (qg, kvg), go, retain_graph=True), 10)
+    nbytes = 2 * T * nkv * hd * 2
+    print(f"\nlast-query attention, cfg-2 shape (T = {T}): forward HIP {ours:.0f} us = {nbytes / ours / 1e3:.0f} GB/s of K|V; PyTorch op "
+          f"{theirs:.0f} us; backward HIP {ours_b:.0f} us = {2 * nbytes / ours_b / 1e3:.0f} GB/s (K|V read + dK|dV written)")

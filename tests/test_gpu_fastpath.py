@@ -71,8 +71,14 @@ def test_bench_path_parity_bf16_packed_filler(hd, ckpt):
     batch, tot = _batch()
 
     # spies: the branches under test must be the ones that run
-    seen = {"qkv_T": [], "last_rows": 0, "multi": 0}
+    seen = {"qkv_T": [], "last_rows": 0, "multi": 0, "lastq": 0}
     real_qkv, real_last, real_multi = ops.rope_flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows, enc.pooled_last_token_multi
+    real_lq = ops.last_query_attn
+
+    def spy_lq(*a, **kw):
+        seen["lastq"] += 1
+        return real_lq(*a, **kw)
+    ops.last_query_attn = spy_lq
 
     def spy_qkv(qkv, *a, **kw):
         seen["qkv_T"].append(qkv.shape[-2])
@@ -93,9 +99,11 @@ def test_bench_path_parity_bf16_packed_filler(hd, ckpt):
     finally:
         ops.rope_flash_attn_varlen_qkv, PE.LlamaLayer.forward_last_rows = real_qkv, real_last
         enc.pooled_last_token_multi = real_multi
+        ops.last_query_attn = real_lq
     print("\nfast path parity:", rep)
     padded_T = (tot + 255) // 256 * 256
     assert seen["multi"] == 2 and seen["last_rows"] == (2 if ckpt else 1)      # the checkpointed last block is recomputed too
+    assert seen["lastq"] == seen["last_rows"]                                  # the last block's attention is the HIP kernel's
     # filler fired, every full block ran the fused attention (a checkpointed block runs it again in its recomputation)
     assert seen["qkv_T"] == [padded_T] * ((cfg.num_hidden_layers - 1) * (2 if ckpt else 1)), (seen, tot)
     assert rep["pass"], rep

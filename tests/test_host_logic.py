@@ -490,3 +490,22 @@ def test_query_tile_table_properties():
                 assert q0s == sorted(q0s, reverse=True)
     legacy = ops.attn_tile_table([300, 5], "cpu").numpy()
     assert legacy.shape == (4, 2) and legacy[0, 1] == 256
+
+
+def test_rotary_frequencies_survive_a_dtype_cast():
+    """`encoder.to(torch.bfloat16)` must not round the rotary frequencies (HF keeps inv_freq in float32 whatever the model dtype;
+    modeling.py:175-178 loads the encoder through it): rounded to bf16 they turn position 4096 by radians, not ulps.  Round 3
+    found the product doing exactly that (inv_freq was a module buffer) through the parity test at real sequence length."""
+    from rankpo_amd import encoder as PE
+    cfg = PE.llama_3_2_1b_config(vocab_size=64, num_hidden_layers=1, hidden_size=128, num_attention_heads=2, num_key_value_heads=1,
+                                 intermediate_size=64)
+    enc = PE.LlamaEncoder(cfg)
+    want = PE._rope_inv_freq(cfg)
+    for e in (enc, enc.to(torch.bfloat16), enc.to(torch.float32)):
+        assert e.inv_freq.dtype == torch.float32 and torch.equal(e.inv_freq, want)
+        t = e._rope(torch.tensor([4095]))
+        assert torch.equal(t.cos32, torch.outer(torch.tensor([4095.0]), want).cos())
+    assert "inv_freq" not in dict(enc.named_buffers()) and not any("inv_freq" in k for k in enc.state_dict())
+    # what the rounding would have cost at the end of a 4096-token row: > 1 rad on the fastest frequencies
+    err = (want.to(torch.bfloat16).float() - want).abs() * 4095
+    assert err.max() > 1.0
