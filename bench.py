@@ -832,7 +832,9 @@ def main():
                        "grad_checkpointing": "all blocks" if ckpt < 0 else f"first {ckpt} blocks",
                        "padding": "padded batches" if args.padded else "pad tokens skipped (packed varlen encoder)",
                        "tokens_per_step_per_gpu": {"padded": tok_pad, "real_mean": int(sum(tok_real) / len(tok_real))},
-                       "weights": "random init (seed 0)"},
+                       "weights": "random init (seed 0)",
+                       "dropout": {"hidden": float(getattr(cfg, "hidden_dropout_prob", 0.0) or 0.0),
+                                   "attention": float(getattr(cfg, "attention_probs_dropout_prob", getattr(cfg, "attention_dropout", 0.0)) or 0.0)}},
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
             "peak_mem_GiB": round(peak_mem, 2),
         }
@@ -875,6 +877,9 @@ def main():
             note("cpu baseline (oracle on host cores) ...")
             dt, times, toks, (cores, cores_how), sample_batch, ref = cpu_baseline(model, cfg, temperature, note=note)
             note("step parity: fast path and stock-eager control vs the float32 oracle ...")
+            # the timed steps ran with the configuration's dropout (BERT family: HF's 0.1, as the reference trains it); the
+            # oracle has none, so the parity leg -- outside the timed region -- compares with every nn.Dropout at p = 0
+            rankpo_amd.encoder.disable_dropout_in_model(model.model)
             out["step_loss_parity"] = step_parity(model, cfg, temperature, sample_batch, ref, device, dtype)
             toks_per_pair = Lp + Lq / (1 + K)
             nq_s, np_s = sample_batch["query"]["input_ids"].shape, sample_batch["passage"]["input_ids"].shape

@@ -46,7 +46,7 @@ def llama_config(**kw) -> EncoderConfig:
              intermediate_size=8192, num_hidden_layers=16, num_attention_heads=32, num_key_value_heads=8,
              head_dim=None, rms_norm_eps=1e-5, rope_theta=500000.0, rope_scaling=None,
              max_position_embeddings=131072, pad_token_id=None, attention_bias=False, mlp_bias=False,
-             initializer_range=0.02, hidden_act="silu", padding_side="right")
+             initializer_range=0.02, hidden_act="silu", padding_side="right", attention_dropout=0.0)
     d.update(kw)
     if d["head_dim"] is None:
         d["head_dim"] = d["hidden_size"] // d["num_attention_heads"]
@@ -78,7 +78,8 @@ def bert_config(**kw) -> EncoderConfig:
     d = dict(architectures=["BertModel"], model_type="bert", vocab_size=30522, hidden_size=384,
              intermediate_size=1536, num_hidden_layers=12, num_attention_heads=12, max_position_embeddings=512,
              type_vocab_size=2, layer_norm_eps=1e-12, pad_token_id=0, hidden_act="gelu", initializer_range=0.02,
-             hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0)
+             hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)     # HF BertConfig's defaults (the reference trains
+    #          BGE / BGE-M3 with them: modeling.py:175-178 loads the checkpoint's config as it is, arguments.py has no override)
     d.update(kw)
     return EncoderConfig(**d)
 
@@ -399,6 +400,10 @@ class LlamaEncoder(nn.Module):
 
     def __init__(self, config: EncoderConfig):
         super().__init__()
+        if float(getattr(config, "attention_dropout", 0.0) or 0.0) != 0.0:
+            # HF LlamaModel's only dropout; every Llama checkpoint the reference names ships 0.0.  Not implemented in the
+            # attention kernels: refuse loudly rather than train without a regularisation the config asks for.
+            raise ValueError(f"attention_dropout={config.attention_dropout} is not supported by LlamaEncoder (only 0.0)")
         self.config = config
         self.embed_tokens = nn.Embedding(config.vocab_size, config.hidden_size)
         self.layers = nn.ModuleList(LlamaLayer(config) for _ in range(config.num_hidden_layers))
@@ -590,6 +595,7 @@ class BertEmbeddings(nn.Module):
         self.position_embeddings = nn.Embedding(cfg.max_position_embeddings, cfg.hidden_size)
         self.token_type_embeddings = nn.Embedding(cfg.type_vocab_size, cfg.hidden_size)
         self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.dropout = nn.Dropout(cfg.hidden_dropout_prob)
         # RoBERTa family (XLM-R / BGE-M3): position ids count the NON-PAD tokens and start at padding_idx + 1; pad tokens
         # sit on padding_idx (HF create_position_ids_from_input_ids).  BERT: plain arange.
         self.roberta_positions = "Roberta" in cfg.architectures[0]
@@ -603,7 +609,7 @@ class BertEmbeddings(nn.Module):
         else:
             pos_emb = self.position_embeddings(torch.arange(L, device=input_ids.device))[None]
         tt = self.token_type_embeddings.weight[0] if token_type_ids is None else self.token_type_embeddings(token_type_ids)
-        return self.LayerNorm(self.word_embeddings(input_ids) + tt + pos_emb)
+        return self.dropout(self.LayerNorm(self.word_embeddings(input_ids) + tt + pos_emb))
 
 
 class _BertSelf(nn.Module):
@@ -613,6 +619,7 @@ class _BertSelf(nn.Module):
         self.query = nn.Linear(cfg.hidden_size, cfg.hidden_size)
         self.key = nn.Linear(cfg.hidden_size, cfg.hidden_size)
         self.value = nn.Linear(cfg.hidden_size, cfg.hidden_size)
+        self.dropout = nn.Dropout(cfg.attention_probs_dropout_prob)      # on the attention probabilities (HF BertSelfAttention)
 
 
 class _BertSelfOutput(nn.Module):
@@ -620,6 +627,7 @@ class _BertSelfOutput(nn.Module):
         super().__init__()
         self.dense = nn.Linear(cfg.hidden_size, cfg.hidden_size)
         self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.dropout = nn.Dropout(cfg.hidden_dropout_prob)
 
 
 class BertAttention(nn.Module):
@@ -634,8 +642,10 @@ class BertAttention(nn.Module):
         q = self.self.query(x).view(N, L, nh, D // nh).transpose(1, 2)
         k = self.self.key(x).view(N, L, nh, D // nh).transpose(1, 2)
         v = self.self.value(x).view(N, L, nh, D // nh).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask).transpose(1, 2).reshape(N, L, D)
-        return self.output.LayerNorm(self.output.dense(o) + x)
+        # attention-probability dropout inside the fused attention op (HF's sdpa path: dropout_p = p if training else 0)
+        pdrop = self.self.dropout.p if self.training else 0.0
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=pdrop).transpose(1, 2).reshape(N, L, D)
+        return self.output.LayerNorm(self.output.dropout(self.output.dense(o)) + x)
 
 
 class _Dense(nn.Module):
@@ -649,6 +659,7 @@ class _BertOutput(nn.Module):
         super().__init__()
         self.dense = nn.Linear(cfg.intermediate_size, cfg.hidden_size)
         self.LayerNorm = nn.LayerNorm(cfg.hidden_size, eps=cfg.layer_norm_eps)
+        self.dropout = nn.Dropout(cfg.hidden_dropout_prob)
 
 
 class BertLayer(nn.Module):
@@ -661,7 +672,7 @@ class BertLayer(nn.Module):
     def forward(self, x, mask):
         x = self.attention(x, mask)
         h = F.gelu(self.intermediate.dense(x))
-        return self.output.LayerNorm(self.output.dense(h) + x)
+        return self.output.LayerNorm(self.output.dropout(self.output.dense(h)) + x)
 
 
 class _BertStack(nn.Module):
@@ -704,6 +715,14 @@ class BertEncoder(nn.Module):
         for layer in self.encoder.layer:
             x = checkpoint(layer, x, mask, use_reentrant=False) if ck else layer(x, mask)
         return EncoderOutput(last_hidden_state=x) if return_dict else (x,)
+
+
+def disable_dropout_in_model(model: nn.Module) -> None:
+    """trl.trainer.utils.disable_dropout_in_model, which the reference calls when `disable_dropout` is set
+    (rankpo_trainer.py:209-213, arguments.py:778-779): every nn.Dropout of the model gets p = 0."""
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
 
 
 # ----------------------------------------------------------------------------------------------------

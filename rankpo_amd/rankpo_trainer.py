@@ -37,12 +37,14 @@ class RankPOTrainer:
         loss_type: str = "sigmoid",         # :762
         label_smoothing: float = 0.0,       # :766
         reference_free: bool = False,       # :692
+        disable_dropout: bool = True,       # :778
         args: Any = None,
     ):
         if args is not None:    # accept a RankPOArguments-like object
             beta, temperature = args.beta, args.temperature
             gamma_beta_ratio, sft_weight, rankpo_weight = args.gamma_beta_ratio, args.sft_weight, args.rankpo_weight
             loss_type, label_smoothing, reference_free = args.loss_type, args.label_smoothing, args.reference_free
+            disable_dropout = getattr(args, "disable_dropout", disable_dropout)
         self.model = model
         self.ref_model = ref_model
         self.beta = beta
@@ -53,6 +55,12 @@ class RankPOTrainer:
         self.loss_type = loss_type
         self.label_smoothing = label_smoothing
         self.reference_free = reference_free
+        if disable_dropout:                 # rankpo_trainer.py:209-213
+            from .encoder import disable_dropout_in_model
+            if self.model is not None:
+                disable_dropout_in_model(self.model)
+            if self.ref_model is not None:
+                disable_dropout_in_model(self.ref_model)
         if self.ref_model is not None:
             self.ref_model.eval()
             for p in self.ref_model.parameters():
@@ -163,10 +171,16 @@ class RankPOTrainer:
 
     # -- rankpo_trainer.py:570-587 --------------------------------------------------------------------
     def compute_loss(self, model, inputs: Dict[str, Any], return_outputs=False):
-        loss, metrics = self.get_batch_loss_metrics(model, inputs, train_eval="train")
-        self.store_metrics(metrics, train_eval="train")
+        """The reference resolves the 9 metrics to Python floats here, every micro-step (9 gathers + 9 `.item()` syncs,
+        rankpo_trainer.py:496-520).  Nobody reads them before `log`, so unless the caller asks for them (`return_outputs`)
+        the metric vector stays on the device and `log` resolves everything stored since the last log with ONE all-reduce and
+        ONE host copy: the training step has no host sync on this path."""
         if return_outputs:
+            loss, metrics = self.get_batch_loss_metrics(model, inputs, train_eval="train")
+            self.store_metrics(metrics, train_eval="train")
             return (loss, metrics)
+        loss, handle = self.get_batch_loss_metrics(model, inputs, train_eval="train", sync_metrics=False)
+        self._pending_metrics.append(handle)
         return loss
 
     # -- rankpo_trainer.py:626-645 --------------------------------------------------------------------
@@ -174,8 +188,23 @@ class RankPOTrainer:
         for key, value in metrics.items():
             self._stored_metrics[train_eval][key].append(value)
 
+    def _flush_pending(self):
+        """Resolve the device-side metric vectors of the micro-steps since the last log: the mean over the steps is taken on
+        the device first (the mean over ranks and over steps commute), then ONE all-reduce + ONE host copy."""
+        if not self._pending_metrics:
+            return
+        n = len(self._pending_metrics)
+        prefix = self._pending_metrics[0][0]
+        mean = torch.stack([m.detach() for _, m in self._pending_metrics]).mean(0)
+        self._pending_metrics = []
+        vals = self.resolve_metrics((prefix, mean))
+        for key, value in vals.items():                       # `log` averages the stored values: n copies of the mean
+            self._stored_metrics["train"][key].extend([value] * n)
+
     def log(self, logs: Dict[str, float]) -> Dict[str, float]:
         train_eval = "train" if "loss" in logs else "eval"
+        if train_eval == "train":
+            self._flush_pending()
         for key, metrics in self._stored_metrics[train_eval].items():
             logs[key] = torch.tensor(metrics).mean().item()
         del self._stored_metrics[train_eval]

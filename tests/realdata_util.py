@@ -12,7 +12,7 @@ def realdata_encoders():
     import torch
     from rankpo_amd import encoder as PE
     torch.manual_seed(4321)
-    bert = PE.BertEncoder(PE.bert_config(vocab_size=VOCAB, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+    bert = PE.BertEncoder(PE.bert_config(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=VOCAB, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
                                          num_attention_heads=4, max_position_embeddings=256, pad_token_id=0))
     torch.manual_seed(4322)
     llama = PE.LlamaEncoder(PE.llama_config(vocab_size=VOCAB, hidden_size=64, intermediate_size=128, num_hidden_layers=2,

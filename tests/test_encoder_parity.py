@@ -136,7 +136,7 @@ def test_product_llama_vs_oracle(ci, side):
 
 def test_product_bert_vs_oracle_and_grads():
     torch.manual_seed(3)
-    cfg = PE.bert_config(vocab_size=96, hidden_size=48, intermediate_size=96, num_hidden_layers=2,
+    cfg = PE.bert_config(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=96, hidden_size=48, intermediate_size=96, num_hidden_layers=2,
                          num_attention_heads=4, max_position_embeddings=64)
     enc = PE.BertEncoder(cfg).eval()
     ids, m = _batch(np.random.RandomState(2), 4, 20, 96)

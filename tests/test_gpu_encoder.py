@@ -201,7 +201,7 @@ def test_bert_cls_model_step_vs_oracle_cfg1_arch():
     import rankpo_amd
     from rankpo_amd import encoder as PE
     torch.manual_seed(9)
-    cfg = PE.bert_config(vocab_size=300, hidden_size=96, intermediate_size=192, num_hidden_layers=2,
+    cfg = PE.bert_config(hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0, vocab_size=300, hidden_size=96, intermediate_size=192, num_hidden_layers=2,
                          num_attention_heads=4, max_position_embeddings=64)
     enc = PE.BertEncoder(cfg)
     w = E.state_dict_to_f32(enc)

@@ -509,3 +509,65 @@ def test_rotary_frequencies_survive_a_dtype_cast():
     # what the rounding would have cost at the end of a 4096-token row: > 1 rad on the fastest frequencies
     err = (want.to(torch.bfloat16).float() - want).abs() * 4095
     assert err.max() > 1.0
+
+
+def test_bert_dropout_follows_the_config_and_disable_dropout():
+    """HF BertModel trains with hidden / attention-probability dropout 0.1 by default and the reference loads the checkpoint's
+    config as it is (modeling.py:175-178); RankPOTrainer switches every dropout off when `disable_dropout` is set, its default
+    (arguments.py:778-779, rankpo_trainer.py:209-213).  Here: eval mode ignores p; train mode with p > 0 is reproducible under a
+    seed and differs from p = 0; a checkpoint's non-zero rates survive load_encoder; disable_dropout zeroes them; a Llama config
+    that asks for attention dropout is refused."""
+    import tempfile
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    torch.manual_seed(0)
+    kw = dict(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=2, num_attention_heads=4, max_position_embeddings=32)
+    enc = PE.BertEncoder(PE.bert_config(**kw))
+    assert PE.bert_config().hidden_dropout_prob == 0.1 and PE.bert_config().attention_probs_dropout_prob == 0.1      # HF defaults
+    drops = [m for m in enc.modules() if isinstance(m, torch.nn.Dropout)]
+    assert len(drops) == 1 + 3 * 2 and all(m.p == 0.1 for m in drops)
+    ids = torch.randint(1, 64, (3, 10))
+    mask = torch.ones(3, 10, dtype=torch.long)
+    run = lambda: enc(input_ids=ids, attention_mask=mask).last_hidden_state
+    enc.eval()
+    e1, e2 = run(), run()
+    assert torch.equal(e1, e2)
+    enc.train()
+    torch.manual_seed(7); t1 = run()
+    torch.manual_seed(7); t2 = run()
+    torch.manual_seed(8); t3 = run()
+    assert torch.equal(t1, t2) and not torch.equal(t1, t3) and not torch.allclose(t1, e1, atol=1e-3)
+    with tempfile.TemporaryDirectory() as d:
+        PE.save_encoder(enc, d)
+        back = PE.load_encoder(d)
+        assert back.config.hidden_dropout_prob == 0.1 and back.embeddings.dropout.p == 0.1
+    tr = rankpo_amd.RankPOTrainer(enc, None, reference_free=True)                     # disable_dropout defaults to True
+    assert all(m.p == 0.0 for m in drops)
+    assert torch.equal(run(), e1)                                                     # train mode, p = 0: the eval result
+    del tr
+    enc2 = PE.BertEncoder(PE.bert_config(**kw))
+    rankpo_amd.RankPOTrainer(enc2, None, reference_free=True, disable_dropout=False)
+    assert all(m.p == 0.1 for m in enc2.modules() if isinstance(m, torch.nn.Dropout))
+    with pytest.raises(ValueError, match="attention_dropout"):
+        PE.LlamaEncoder(PE.llama_config(vocab_size=16, hidden_size=8, intermediate_size=8, num_hidden_layers=1,
+                                        num_attention_heads=2, num_key_value_heads=1, attention_dropout=0.1))
+
+
+def test_compute_loss_defers_metrics_to_log():
+    """compute_loss without return_outputs keeps the metric vector on the device; `log` resolves everything stored since the last
+    log (mean over the steps) with one copy and reports what the reference's per-step `.item()` path reports
+    (rankpo_trainer.py:570-587, 626-645)."""
+    import rankpo_amd
+    from rankpo_amd.rankpo_trainer import METRIC_KEYS
+    tr = rankpo_amd.RankPOTrainer(None, None, reference_free=True, rankpo_weight=1.0, sft_weight=0.5)
+    vecs = [torch.arange(len(METRIC_KEYS), dtype=torch.float32) + s for s in (0.0, 2.0, 4.0)]
+    it = iter(vecs)
+    tr.get_batch_loss_metrics = lambda model, batch, train_eval="train", sync_metrics=True: (
+        torch.tensor(1.0), ("", next(it)) if not sync_metrics else None)
+    for _ in vecs:
+        assert float(tr.compute_loss(None, {})) == 1.0
+    assert len(tr._pending_metrics) == 3 and not tr._stored_metrics["train"]
+    logs = tr.log({"loss": 1.0})
+    assert tr._pending_metrics == []
+    for i, k in enumerate(METRIC_KEYS):
+        assert abs(logs[k] - (i + 2.0)) < 1e-6
