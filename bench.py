@@ -476,7 +476,7 @@ class _StdoutToStderr:
 
 COMM_KEYS = ("backend", "ranks_seen", "world_size", "collectives_per_step", "allgather_calls_per_step", "allgather_bytes_per_rank",
              "allgather_wait_us", "allgather_wait_us_max", "allreduce_bytes", "allreduce_buckets", "allreduce_exposed_ms",
-             "allreduce_exposed_ms_max", "late_buckets", "loss_min_over_ranks", "loss_max_over_ranks", "loss_equal_over_ranks",
+             "allreduce_exposed_ms_max", "late_buckets", "optimizer_state_partitioned", "param_allgather_exposed_ms", "loss_min_over_ranks", "loss_max_over_ranks", "loss_equal_over_ranks",
              "params_in_sync", "ms_per_step_min_over_ranks", "ms_per_step_max_over_ranks", "timer")
 
 
@@ -489,7 +489,7 @@ class CommProbe:
     def __init__(self, use_events: bool):
         self.use_events = use_events
         self.enabled = False
-        self.gather, self.reduce = [], []          # (start, end) pairs
+        self.gather, self.reduce, self.param_gather = [], [], []          # (start, end) pairs
         self.gather_bytes = 0
         self.collectives = 0
 
@@ -503,7 +503,17 @@ class CommProbe:
     def install(self):
         from rankpo_amd import distributed as D
         probe = self
+        from rankpo_amd import train_step as TS
         g_init, g_wait, r_finish = D.EmbeddingGather.__init__, D.EmbeddingGather.wait, D.FlatGradAllReducer.finish
+        o_wait = TS.FlatAdamW._wait_gathers
+
+        def wait_gathers(o, works):
+            if not probe.enabled:
+                return o_wait(o, works)
+            a = probe._stamp()
+            o_wait(o, works)
+            probe.param_gather.append((a, probe._stamp()))
+        TS.FlatAdamW._wait_gathers = wait_gathers
         real_ar, real_ag, real_agt = dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor
 
         def count(fn):
@@ -513,6 +523,7 @@ class CommProbe:
                 return fn(*a, **k)
             return counted
         dist.all_reduce, dist.all_gather, dist.all_gather_into_tensor = count(real_ar), count(real_ag), count(real_agt)
+        dist.reduce_scatter_tensor = count(dist.reduce_scatter_tensor)
 
         def init(g, x):
             g_init(g, x)
@@ -554,6 +565,7 @@ def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=Non
     dist.all_reduce(ones)                                              # what the backend's communicator spans
     g_us = [1e3 * m for m in probe._ms(probe.gather)]
     r_ms = probe._ms(probe.reduce)
+    p_ms = probe._ms(probe.param_gather)
     loss = float(last_loss)
     lmin, lmax = red(loss, dist.ReduceOp.MIN), red(loss, dist.ReduceOp.MAX)
     in_sync = None
@@ -573,7 +585,8 @@ def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=Non
         "allgather_wait_us": rnd(mean(g_us), 1), "allgather_wait_us_max": rnd(max(g_us) if g_us else None, 1),
         "allreduce_bytes": reducer.flat.numel() * reducer.flat.element_size(), "allreduce_buckets": len(reducer.buckets),
         "allreduce_exposed_ms": rnd(mean(r_ms)), "allreduce_exposed_ms_max": rnd(max(r_ms) if r_ms else None),
-        "late_buckets": reducer.late_buckets,
+        "late_buckets": reducer.late_buckets, "optimizer_state_partitioned": bool(getattr(reducer, "shard", False)),
+        "param_allgather_exposed_ms": rnd(mean(p_ms)) if p_ms else 0.0,
         "loss_min_over_ranks": lmin, "loss_max_over_ranks": lmax, "loss_equal_over_ranks": bool(lmin == lmax),
         "params_in_sync": in_sync,
         "ms_per_step_min_over_ranks": rnd(red(ms, dist.ReduceOp.MIN)), "ms_per_step_max_over_ranks": rnd(red(ms, dist.ReduceOp.MAX)),
@@ -671,6 +684,10 @@ def main():
     ap.add_argument("--gas", type=int, default=1,
                     help="micro-batches per optimizer step (the reference's scripts use 4; negatives are per micro-batch). "
                          "A timed step is then `gas` micro-steps + one gradient all-reduce + one AdamW launch")
+    ap.add_argument("--partition-optimizer", default="auto", choices=("auto", "on", "off"),
+                    help="N > 1: optimizer state partitioned over the ranks (reduce-scatter + AdamW shard + parameter all-gather, "
+                         "the reference's ZeRO-1) instead of replicated (all-reduce); auto = on when the replicated state would "
+                         "force blocks to be checkpointed")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="CPU rehearsal of the N-rank launch only: gloo process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
@@ -728,19 +745,27 @@ def main():
     tok_real = [int(b["query"]["attention_mask"].sum()) + int(b["passage"]["attention_mask"].sum()) for b in batches]
     tok_pad = B * Lq + B * (1 + K) * Lp
     ckpt = args.ckpt_layers
-    if ckpt == -2:
+    partition = multi and args.partition_optimizer == "on"
+    es = 2 if dtype == torch.bfloat16 else 4
+    nl = cfg.num_hidden_layers
+    nparam = sum(p.numel() for p in enc.parameters())
+
+    def free_blocks(part):
         # activation bytes kept per token per un-checkpointed block: x, norm(x), q, k, v, attn out, x', norm(x'),
         # gate, up (the SwiGLU product is recomputed) = s (6.5 d + 2 ff) upper bound; measured 44 KB for
-        # Llama-3.2-1B bf16 (0.75 of the bound).  States: 16 B/param.
-        es = 2 if dtype == torch.bfloat16 else 4
-        nl = cfg.num_hidden_layers
+        # Llama-3.2-1B bf16 (0.75 of the bound).  States: parameters + gradients (2 s B/param) + f32 master / m / v
+        # (12 B/param, or 12 / W with the optimizer state partitioned over W ranks, + the s / W reduced-gradient shard).
         per_tok = int(0.8 * es * (6.5 * cfg.hidden_size + 2 * cfg.intermediate_size))
         toks = tok_pad     # budget for the worst case (every row at full length), also in packed mode
         per_layer = toks * per_tok
-        nparam = sum(p.numel() for p in enc.parameters())
         total = torch.cuda.get_device_properties(device).total_memory
-        budget = 0.72 * total - nparam * (es * 2 + 12) - toks * cfg.hidden_size * es * nl - 2 * per_layer
-        free_layers = max(0, min(nl, int(budget // per_layer)))
+        state = nparam * (es * 2 + ((12 + es) / max(1, world) if part else 12))
+        budget = 0.72 * total - state - toks * cfg.hidden_size * es * nl - 2 * per_layer
+        return max(0, min(nl, int(budget // per_layer)))
+    if multi and args.partition_optimizer == "auto":
+        partition = world > 1 and free_blocks(False) < nl
+    if ckpt == -2:
+        free_layers = free_blocks(partition)
         ckpt = nl - free_layers
         if not hasattr(enc, "layers"):          # encoders without per-block control: all blocks or none
             ckpt = 0 if free_layers == nl else -1
@@ -766,7 +791,7 @@ def main():
         loss_fn = lambda b: model(**b)["loss"]
     ts = TrainStep(model.parameters(), loss_fn, lr=1e-5, max_grad_norm=1.0,
                    gradient_accumulation_steps=gas, total_steps=max(10, args.steps + args.warmup), warmup_ratio=0.1,
-                   force_collectives=args.force_dist)
+                   force_collectives=args.force_dist, partition_optimizer=partition)
     micro = lambda i: batches[i] if gas == 1 else batches[i * gas:(i + 1) * gas]
 
     def note(msg):
@@ -829,6 +854,8 @@ def main():
                                     f"T={temperature}, in-batch negs" + (", cross-device negs" if multi else "")),
                        "global_batch": world * B, "pairs_per_step": world * B * (1 + K) * gas,
                        "parallelism": f"dp{world}", "optimizer": f"AdamW(flat, HIP) + clip 1.0, GAS={gas}", "micro_steps_per_step": gas,
+                       "optimizer_state": (f"partitioned over {world} ranks (reduce-scatter, AdamW on 1/{world}, parameter all-gather)"
+                                           if ts.opt.partition else "replicated (bucketed all-reduce)"),
                        "grad_checkpointing": "all blocks" if ckpt < 0 else f"first {ckpt} blocks",
                        "padding": "padded batches" if args.padded else "pad tokens skipped (packed varlen encoder)",
                        "tokens_per_step_per_gpu": {"padded": tok_pad, "real_mean": int(sum(tok_real) / len(tok_real))},

@@ -90,9 +90,14 @@ class FlatGradAllReducer:
     all-reduced (mean) on RCCL's stream as soon as every gradient inside has been accumulated."""
 
     def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 512.0, world_size: Optional[int] = None,
-                 force_collectives: bool = False):
+                 force_collectives: bool = False, shard: bool = False, rank: Optional[int] = None):
+        """shard=True (optimizer-state partition, `train_step.FlatAdamW(partition=True)`): every bucket is cut into `world` equal
+        shards and REDUCE-SCATTERED instead of all-reduced -- rank r receives the summed gradient of shard r of every bucket
+        (`grad_shards[b]`), the only part its optimizer slice needs; bucket sizes are padded to a multiple of 8 x world elements."""
         self.params = [p for p in params if p.requires_grad]
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
+        self.rank = rank if rank is not None else (dist.get_rank() if dist.is_initialized() else 0)
+        self.shard = bool(shard)
         assert self.params, "no trainable parameters"
         dtype, device = self.params[0].dtype, self.params[0].device
         assert all(p.dtype == dtype and p.device == device for p in self.params), "one dtype/device per reducer"
@@ -109,24 +114,35 @@ class FlatGradAllReducer:
                     j += 1
                 order[i:j] = sorted(order[i:j], key=lambda p: p._rpo_fuse_group[1])
             i = j
+        # layout: parameters back to back (every view 16-byte aligned), cut into buckets of >= `per` elements at parameter
+        # boundaries; with shard=True a bucket's length is padded up to a multiple of 8 x world so that its `world` shards are
+        # equal and 16-byte aligned (the padding elements belong to no parameter and stay zero)
+        es = torch.empty((), dtype=dtype).element_size()
+        per = max(1, int(bucket_mb * 2 ** 20 / es))
+        quantum = 8 * self.world if self.shard else 8
         offs, n = [], 0
-        for p in order:
+        self.buckets = []                              # (start, end, [param indices])
+        start, idxs = 0, []
+        for i, p in enumerate(order):
             offs.append(n)
-            n += (p.numel() + 7) // 8 * 8            # keep every view 16-byte aligned
+            n += (p.numel() + 7) // 8 * 8
+            idxs.append(i)
+            if n - start >= per or i == len(order) - 1:
+                n = start + (n - start + quantum - 1) // quantum * quantum
+                self.buckets.append((start, n, idxs))
+                start, idxs = n, []
         self.numel = n
         self.flat = torch.zeros(n, dtype=dtype, device=device)
         self.order, self.offsets = order, offs
         for p, o in zip(order, offs):
             p.grad = self.flat[o:o + p.numel()].view_as(p)
-        per = max(1, int(bucket_mb * 2 ** 20 / self.flat.element_size()))
-        self.buckets = []                              # (start, end, [param indices])
-        start, idxs = 0, []
-        for i, (p, o) in enumerate(zip(order, offs)):
-            idxs.append(i)
-            end = o + (p.numel() + 7) // 8 * 8
-            if end - start >= per or i == len(order) - 1:
-                self.buckets.append((start, end, idxs))
-                start, idxs = end, []
+        # shard=True: this rank's reduced gradient shards, one contiguous buffer, bucket b at shard_offsets[b]
+        self.shard_offsets, self.shard_numel, self.grad_shards = [], 0, None
+        if self.shard:
+            for s_, e_, _ in self.buckets:
+                self.shard_offsets.append(self.shard_numel)
+                self.shard_numel += (e_ - s_) // self.world
+            self.grad_shards = torch.zeros(self.shard_numel, dtype=dtype, device=device)
         self._bucket_of = {}
         for b, (_, _, ids) in enumerate(self.buckets):
             for i in ids:
@@ -153,9 +169,28 @@ class FlatGradAllReducer:
             b = self._bucket_of[i]
             self._pending[b] -= 1
             if self._pending[b] == 0:
-                s, e, _ = self.buckets[b]
-                self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                self._works.append(self._reduce_bucket(b))
         return hook
+
+    def shard_view(self, b: int) -> torch.Tensor:
+        """This rank's reduced-gradient shard of bucket b (shard=True)."""
+        s, e, _ = self.buckets[b]
+        o = self.shard_offsets[b]
+        return self.grad_shards[o:o + (e - s) // self.world]
+
+    def _reduce_bucket(self, b: int):
+        """Asynchronous sum over ranks of bucket b: all-reduce in place, or (shard=True) reduce-scatter into this rank's shard."""
+        s, e, _ = self.buckets[b]
+        if not self.shard:
+            return dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True)
+        out = self.shard_view(b)
+        if dist.get_backend() == "nccl":
+            return dist.reduce_scatter_tensor(out, self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True)
+        # gloo (the CPU tests) has no reduce-scatter: all-reduce, then keep the own shard -- the same values
+        n = (e - s) // self.world
+        dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM)
+        out.copy_(self.flat[s + self.rank * n:s + (self.rank + 1) * n])
+        return None
 
     def arm(self):
         """Call before the LAST backward of an accumulation window: buckets then reduce as they complete."""
@@ -174,12 +209,12 @@ class FlatGradAllReducer:
         if self._armed:
             for b, left in enumerate(self._pending):
                 if left > 0:
-                    s, e, _ = self.buckets[b]
-                    self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
+                    self._works.append(self._reduce_bucket(b))
                     self._pending[b] = 0
                     self.late_buckets += 1
         for w in self._works:
-            w.wait()
+            if w is not None:
+                w.wait()
         self._works = []
         self._armed = False
         return 1.0 / self.world

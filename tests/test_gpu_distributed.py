@@ -39,20 +39,23 @@ def test_cross_device_path_world1_equals_local(nccl_world1):
     rs = np.random.RandomState(0)
     batches = [{"query": _batch(rs, 4, 24, 256), "passage": _batch(rs, 12, 48, 256)} for _ in range(3)]
     results = []
-    for xdev in (False, True):
+    # local; cross-device path with replicated optimizer state (bucketed all-reduce); the same with the optimizer state
+    # partitioned (RCCL reduce-scatter per bucket, AdamW per shard, in-place parameter all-gather): at one rank all three agree
+    for xdev, part in ((False, False), (True, False), (True, True)):
         torch.manual_seed(0)
         enc = PE.LlamaEncoder(cfg).to(DEV).to(torch.bfloat16)
         model = rankpo_amd.ModelForTraining(encoder=enc, temperature=0.02, negatives_cross_device=xdev).train()
         ts = TrainStep(model.parameters(), lambda b: model(**b)["loss"], lr=1e-3, total_steps=10, warmup_ratio=0.0,
-                       bucket_mb=0.05, force_collectives=xdev)
+                       bucket_mb=0.05, force_collectives=xdev, partition_optimizer=part)
         assert len(ts.opt.reducer.buckets) > 1
         assert ts.opt.reducer._reduce == xdev            # the bucketed async all-reduce hooks are live in the xdev run
+        assert ts.opt.partition == part and ts.opt.reducer.shard == part
         losses = [ts.step(b).item() for b in batches]
         out = model(**batches[0])
         assert out.q_reps.shape[0] == 4 and out.p_reps.shape[0] == 12
         results.append((losses, enc.layers[1].mlp.down_proj.weight.detach().float().clone()))
-    assert results[0][0] == results[1][0]
-    assert torch.equal(results[0][1], results[1][1])
+    assert results[0][0] == results[1][0] == results[2][0]
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][1], results[2][1])
     assert results[0][0][0] != results[0][0][2]      # parameters really moved
 
 
