@@ -373,7 +373,7 @@ def cpu_baseline(model, cfg, temperature, sample=(20, 42, 8, 3), repeats=3, note
     return sorted(times)[len(times) // 2], times, Q_s * (Lq_s + G_s * Lp_s), (cores, how), batch, ref
 
 
-PARITY_GRADS = ("embed_tokens.weight", "layers.0.self_attn.q_proj.weight")
+PARITY_GRADS = ("embed_tokens.weight", "layers.0.self_attn.q_proj.weight", "layers.0.self_attn.k_proj.weight")
 
 
 def oracle_step(w, cd, batch, temperature):

@@ -137,7 +137,7 @@ __device__ __forceinline__ FaTile fa_tile(const int* __restrict__ tiles, int tco
 }
 
 __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
+    const bf16_t* q /* no __restrict__: q_rw below aliases it when the rotary fold writes q back */, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
     int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
     float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
     int64_t lse_head_stride, int lse_packed, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod,
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 constexpr int kFa128HD = 128, kFa128BN = 32, kFa128Row = 256;
 
 __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
+    const bf16_t* q /* no __restrict__: q_rw below aliases it when the rotary fold writes q back */, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
     int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
     float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
     int64_t lse_head_stride, int lse_packed, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod,

@@ -288,11 +288,21 @@ class ModelForInference(nn.Module):
             inputs = self.tokenizer(batch_sentences, padding=True, truncation=True, max_length=max_length,
                                     return_tensors="pt")
             inputs = {k: v.to(self.device) for k, v in inputs.items()}
-            h = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
-                           return_dict=True).last_hidden_state
-            if h.dtype == torch.float16:        # the HIP kernels take f32 / bf16
-                h = h.float()
-            emb = ops.pool_normalize(h, inputs["attention_mask"], mode, self.normalize_embeddings)
+            pooled = None
+            if mode == "last" and hasattr(self.model, "pooled_last_token"):
+                # right-padded batches (the tokenizer's default): packed tokens, no pad token is ever computed, the last block
+                # runs for the pooled rows only; ONE host sync per batch (the lengths); None for any other mask
+                pooled = self.model.pooled_last_token(inputs["input_ids"], inputs["attention_mask"])
+            if pooled is not None:
+                if pooled.dtype == torch.float16:
+                    pooled = pooled.float()
+                emb = ops.pool_normalize(pooled[:, None, :], None, "cls", self.normalize_embeddings)
+            else:
+                h = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                               return_dict=True).last_hidden_state
+                if h.dtype == torch.float16:        # the HIP kernels take f32 / bf16
+                    h = h.float()
+                emb = ops.pool_normalize(h, inputs["attention_mask"], mode, self.normalize_embeddings)
             all_embeddings.append(emb)
         out = torch.cat(all_embeddings, dim=0)
         if convert_to_numpy:

@@ -432,21 +432,25 @@ def test_head_dim_128_packed_training_step_vs_oracle():
     qi, qm = _batch(rs, 4, 70, 512)
     pi, pm = _batch(rs, 12, 150, 512)
     cb = {"query": {"input_ids": qi, "attention_mask": qm}, "passage": {"input_ids": pi, "attention_mask": pm}}
-    ref_loss, ref_s, _, _ = E.contrastive_step(w, cfg.to_dict(), cb, 0.02)
-    ref_loss.backward()
+    import importlib
+    bench = importlib.import_module("bench")
+    ref = bench.oracle_step(w, cfg.to_dict(), cb, 0.02)
+    assert {"layers.0.self_attn.q_proj.weight", "layers.0.self_attn.k_proj.weight"} <= set(ref["grads"])   # where the rotary-fold epilogues show
     calls, bcalls = [], []
     real, real_b = ops.flash_attn_varlen_fwd, ops.flash_attn_varlen_bwd
     ops.flash_attn_varlen_fwd = lambda q, *a, **kw: (calls.append(q.shape[-1]), real(q, *a, **kw))[1]
     ops.flash_attn_varlen_bwd = lambda q, *a, **kw: (bcalls.append((q.shape[-1], kw.get("key_block"))), real_b(q, *a, **kw))[1]
     try:
-        model = rankpo_amd.ModelForTraining(encoder=enc.to(DEV).to(torch.bfloat16), temperature=0.02).train()
-        out = model(**{k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in cb.items()})
-        out.loss.backward()
+        enc_dev = enc.to(DEV).to(torch.bfloat16)
+        model = rankpo_amd.ModelForTraining(encoder=enc_dev, temperature=0.02).train()
+        # the control-relative rule of bench.step_parity (fast path <= 1.5 x the stock-bf16 controls' error on cosines, loss and the
+        # embedding / q-projection / k-projection gradients; the controls agree with each other), not a guessed constant
+        rep = bench.step_parity(model, cfg, 0.02, cb, ref, DEV, torch.bfloat16)
     finally:
         ops.flash_attn_varlen_fwd, ops.flash_attn_varlen_bwd = real, real_b
-    assert calls and all(c == 128 for c in calls)                        # the head_dim-128 HIP forward ran in every full block
-    assert len(bcalls) == cfg.num_hidden_layers - 1 and all(c == (128, 128) for c in bcalls)   # ... and the HIP backward
-    assert (out.scores.float().cpu() * 0.02 - ref_s.detach() * 0.02).abs().max() < 2e-2      # cosines
-    assert abs(out.loss.item() - ref_loss.item()) < 0.25 * max(1.0, abs(ref_loss.item()))
-    g, gr = model.model.embed_tokens.weight.grad.float().cpu(), w["embed_tokens.weight"].grad
-    assert torch.isfinite(g).all() and (g - gr).norm() / gr.norm() < 0.1
+    print("\nhead_dim 128 packed step:", rep)
+    hand = [c for c in calls if c == 128]
+    assert hand and len(hand) == len(calls)                               # every hand-written forward call ran at head_dim 128
+    assert bcalls and all(c == (128, 128) for c in bcalls)                # ... and the HIP backward (key_block 128)
+    assert rep["pass"], rep
+    assert rep["fast_path"]["cos_max_err"] < 2e-2
