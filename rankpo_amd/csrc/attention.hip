@@ -2698,14 +2698,25 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
 constexpr int kD128Sl = 32;                                        // query rows per slice
 constexpr int kD128Img = 2 * kD128Sl * kFa128Row + 256;            // Q | dO | 32 x -lse / scale | 32 x -delta = 16640 B
 constexpr int kD128Keys = 128;                                     // keys per block (4 waves x 32)
+constexpr int kD128Ring = 4, kD128Ahead = 3;                       // slice images: ring of 4, 3 slices ahead of the one consumed
+constexpr int kD128Lds = kD128Ring * kD128Img;                     // 66560 B (dynamic)
 
+#include "attention_dkdv128_gen.inc"
+
+// Round 3: the slice body is ONE hand-placed instruction stream (tools/gen/gen_dkdv128_body.py -> attention_dkdv128_gen.inc), as
+// at head_dim 64: M1 (S', dP' chains, key-tile major) -> the exp2 / dS arithmetic and bf16 packing of key tile n in the issue
+// gaps of the MFMAs that follow its chains -> M2 (dV^T, dK^T) with the LDS reads of the NEXT slice's row operands under it.
+// Register split: v[0:63] hipcc (addresses, loop state), v[64:255] the stream's; a[0:127] dV^T / dK^T accumulators, a[128:191]
+// the wave's K / V fragments (they were 64 VGPRs in round 2's hipcc-scheduled kernel).  Masked slices (diagonal, sequence end)
+// run the same steps as separate statements around hipcc's code for the masked arithmetic.  hipcc must not spill (it does not
+// know a[0:191] to be occupied): its resource line must show 0 scratch and no v_accvgpr_* outside ASMSTART / ASMEND.
 __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
     const int* __restrict__ ktiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ nl,
     const float* __restrict__ nd, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
     int64_t sdv, int n_ktiles, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod) {
-    __shared__ __attribute__((aligned(16))) char smem[3 * kD128Img];
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, fr = lane & 15;
@@ -2722,16 +2733,20 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
     const int nsl = (len - qt0 + kD128Sl - 1) / kD128Sl;
     const int niter = nsl * group;
 
-    short8_t bk[2][4], bv[2][4];
+    {
+        short8_t bk[2][4], bv[2][4];
 #pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int key = k0 + 16 * n + fr;
+        for (int n = 0; n < 2; ++n) {
+            const int key = k0 + 16 * n + fr;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const short8_t z = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
-            bk[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(k + (t0 + key) * sk + hk * kFa128HD + 32 * ks + 8 * g) : z;
-            bv[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(v + (t0 + key) * sv + hk * kFa128HD + 32 * ks + 8 * g) : z;
+            for (int ks = 0; ks < 4; ++ks) {
+                const short8_t z = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
+                bk[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(k + (t0 + key) * sk + hk * kFa128HD + 32 * ks + 8 * g) : z;
+                bv[n][ks] = key < len ? *reinterpret_cast<const short8_t*>(v + (t0 + key) * sv + hk * kFa128HD + 32 * ks + 8 * g) : z;
+            }
         }
+        // the K / V fragments move to a[128:191] (this also places hipcc's wait for their loads in front of the DMA ring)
+        RPO_D128_KV_TO_ACC(bk, bv);
     }
     // staging: wave w moves rows 8w .. 8w + 7 of the Q and of the dO slice (two 1-KiB pieces of 4 rows each); wave 0 also the 64
     // row constants (lanes 0..31: -lse / scale, lanes 32..63: -delta)
@@ -2764,56 +2779,13 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
         stage(st_h, qt0 + st_s * kD128Sl, st_buf);
         if (++st_s == nsl) { st_s = 0; ++st_h; }
         ++st_n;
-        st_buf = st_buf == 2 ? 0 : st_buf + 1;
+        st_buf = (st_buf + 1) & (kD128Ring - 1);
     };
-    stage_next();
-    if (niter > 1) stage_next();
-    // touching the fragments here puts hipcc's wait for their loads in front of the loop
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(bk[n][ks]), "+v"(bv[n][ks]));
-    // dV^T / dK^T accumulators [hd tile c][key tile n] (rows = hd 16c + 4g + r, col = key 16n + fr) live in LITERAL accumulator
-    // registers for the whole kernel: dV^T[c][n] = a[8c + 4n : + 3], dK^T[c][n] = a[64 + 8c + 4n : + 3].  As C++ variables (MFMA builtin, or
-    // asm with "+a" operands) hipcc carries them through the loop in VGPRs and copies all 128 to the accumulator file and back in
-    // every iteration (830 v_accvgpr_* per slice).  hipcc does not know a[0:127] to be occupied: its resource line must show no
-    // scratch, and no v_accvgpr_* outside ASMSTART / ASMEND may name them (checked in the ISA; the kernel needs ~200 of 256 VGPRs).
-    asm volatile(
-        "v_accvgpr_write_b32 a0, 0\n\tv_accvgpr_write_b32 a1, 0\n\tv_accvgpr_write_b32 a2, 0\n\tv_accvgpr_write_b32 a3, 0\n\t"
-        "v_accvgpr_write_b32 a4, 0\n\tv_accvgpr_write_b32 a5, 0\n\tv_accvgpr_write_b32 a6, 0\n\tv_accvgpr_write_b32 a7, 0\n\t"
-        "v_accvgpr_write_b32 a8, 0\n\tv_accvgpr_write_b32 a9, 0\n\tv_accvgpr_write_b32 a10, 0\n\tv_accvgpr_write_b32 a11, 0\n\t"
-        "v_accvgpr_write_b32 a12, 0\n\tv_accvgpr_write_b32 a13, 0\n\tv_accvgpr_write_b32 a14, 0\n\tv_accvgpr_write_b32 a15, 0\n\t"
-        "v_accvgpr_write_b32 a16, 0\n\tv_accvgpr_write_b32 a17, 0\n\tv_accvgpr_write_b32 a18, 0\n\tv_accvgpr_write_b32 a19, 0\n\t"
-        "v_accvgpr_write_b32 a20, 0\n\tv_accvgpr_write_b32 a21, 0\n\tv_accvgpr_write_b32 a22, 0\n\tv_accvgpr_write_b32 a23, 0\n\t"
-        "v_accvgpr_write_b32 a24, 0\n\tv_accvgpr_write_b32 a25, 0\n\tv_accvgpr_write_b32 a26, 0\n\tv_accvgpr_write_b32 a27, 0\n\t"
-        "v_accvgpr_write_b32 a28, 0\n\tv_accvgpr_write_b32 a29, 0\n\tv_accvgpr_write_b32 a30, 0\n\tv_accvgpr_write_b32 a31, 0\n\t"
-        "v_accvgpr_write_b32 a32, 0\n\tv_accvgpr_write_b32 a33, 0\n\tv_accvgpr_write_b32 a34, 0\n\tv_accvgpr_write_b32 a35, 0\n\t"
-        "v_accvgpr_write_b32 a36, 0\n\tv_accvgpr_write_b32 a37, 0\n\tv_accvgpr_write_b32 a38, 0\n\tv_accvgpr_write_b32 a39, 0\n\t"
-        "v_accvgpr_write_b32 a40, 0\n\tv_accvgpr_write_b32 a41, 0\n\tv_accvgpr_write_b32 a42, 0\n\tv_accvgpr_write_b32 a43, 0\n\t"
-        "v_accvgpr_write_b32 a44, 0\n\tv_accvgpr_write_b32 a45, 0\n\tv_accvgpr_write_b32 a46, 0\n\tv_accvgpr_write_b32 a47, 0\n\t"
-        "v_accvgpr_write_b32 a48, 0\n\tv_accvgpr_write_b32 a49, 0\n\tv_accvgpr_write_b32 a50, 0\n\tv_accvgpr_write_b32 a51, 0\n\t"
-        "v_accvgpr_write_b32 a52, 0\n\tv_accvgpr_write_b32 a53, 0\n\tv_accvgpr_write_b32 a54, 0\n\tv_accvgpr_write_b32 a55, 0\n\t"
-        "v_accvgpr_write_b32 a56, 0\n\tv_accvgpr_write_b32 a57, 0\n\tv_accvgpr_write_b32 a58, 0\n\tv_accvgpr_write_b32 a59, 0\n\t"
-        "v_accvgpr_write_b32 a60, 0\n\tv_accvgpr_write_b32 a61, 0\n\tv_accvgpr_write_b32 a62, 0\n\tv_accvgpr_write_b32 a63, 0\n\t"
-        "v_accvgpr_write_b32 a64, 0\n\tv_accvgpr_write_b32 a65, 0\n\tv_accvgpr_write_b32 a66, 0\n\tv_accvgpr_write_b32 a67, 0\n\t"
-        "v_accvgpr_write_b32 a68, 0\n\tv_accvgpr_write_b32 a69, 0\n\tv_accvgpr_write_b32 a70, 0\n\tv_accvgpr_write_b32 a71, 0\n\t"
-        "v_accvgpr_write_b32 a72, 0\n\tv_accvgpr_write_b32 a73, 0\n\tv_accvgpr_write_b32 a74, 0\n\tv_accvgpr_write_b32 a75, 0\n\t"
-        "v_accvgpr_write_b32 a76, 0\n\tv_accvgpr_write_b32 a77, 0\n\tv_accvgpr_write_b32 a78, 0\n\tv_accvgpr_write_b32 a79, 0\n\t"
-        "v_accvgpr_write_b32 a80, 0\n\tv_accvgpr_write_b32 a81, 0\n\tv_accvgpr_write_b32 a82, 0\n\tv_accvgpr_write_b32 a83, 0\n\t"
-        "v_accvgpr_write_b32 a84, 0\n\tv_accvgpr_write_b32 a85, 0\n\tv_accvgpr_write_b32 a86, 0\n\tv_accvgpr_write_b32 a87, 0\n\t"
-        "v_accvgpr_write_b32 a88, 0\n\tv_accvgpr_write_b32 a89, 0\n\tv_accvgpr_write_b32 a90, 0\n\tv_accvgpr_write_b32 a91, 0\n\t"
-        "v_accvgpr_write_b32 a92, 0\n\tv_accvgpr_write_b32 a93, 0\n\tv_accvgpr_write_b32 a94, 0\n\tv_accvgpr_write_b32 a95, 0\n\t"
-        "v_accvgpr_write_b32 a96, 0\n\tv_accvgpr_write_b32 a97, 0\n\tv_accvgpr_write_b32 a98, 0\n\tv_accvgpr_write_b32 a99, 0\n\t"
-        "v_accvgpr_write_b32 a100, 0\n\tv_accvgpr_write_b32 a101, 0\n\tv_accvgpr_write_b32 a102, 0\n\tv_accvgpr_write_b32 a103, 0\n\t"
-        "v_accvgpr_write_b32 a104, 0\n\tv_accvgpr_write_b32 a105, 0\n\tv_accvgpr_write_b32 a106, 0\n\tv_accvgpr_write_b32 a107, 0\n\t"
-        "v_accvgpr_write_b32 a108, 0\n\tv_accvgpr_write_b32 a109, 0\n\tv_accvgpr_write_b32 a110, 0\n\tv_accvgpr_write_b32 a111, 0\n\t"
-        "v_accvgpr_write_b32 a112, 0\n\tv_accvgpr_write_b32 a113, 0\n\tv_accvgpr_write_b32 a114, 0\n\tv_accvgpr_write_b32 a115, 0\n\t"
-        "v_accvgpr_write_b32 a116, 0\n\tv_accvgpr_write_b32 a117, 0\n\tv_accvgpr_write_b32 a118, 0\n\tv_accvgpr_write_b32 a119, 0\n\t"
-        "v_accvgpr_write_b32 a120, 0\n\tv_accvgpr_write_b32 a121, 0\n\tv_accvgpr_write_b32 a122, 0\n\tv_accvgpr_write_b32 a123, 0\n\t"
-        "v_accvgpr_write_b32 a124, 0\n\tv_accvgpr_write_b32 a125, 0\n\tv_accvgpr_write_b32 a126, 0\n\tv_accvgpr_write_b32 a127, 0"
-        :
-        :
-        : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+#pragma unroll 1
+    for (int i = 0; i < kD128Ahead && i < niter; ++i) stage_next();
+    // dV^T / dK^T accumulators [hd tile c][key tile n] (rows = hd 16c + 4g + r, col = key 16n + fr): LITERAL accumulator
+    // registers for the whole kernel, dV^T[c][n] = a[8c + 4n : + 3], dK^T[c][n] = a[64 + 8c + 4n : + 3]
+    RPO_D128_ZERO_ACC();
     const int qq = fr >> 2, pp = fr & 3;
     const int vsw = 2 * (4 * (g & 1) + qq);
     unsigned tr_off[8];
@@ -2824,38 +2796,77 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) row_off[ks] = fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned rc_off = 2 * kD128Sl * kFa128Row + 16 * g;   // row constants of the lane's 4 rows (tile m at + 64, -delta at + 128)
+    const int per_stage = wave == 0 ? 5 : 4;                   // DMA instructions this wave issues per slice
 
+#define RPO_TR2H(OUT0, OUT1, ADDR)                                                                              \
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=&v"(OUT0), "=&v"(OUT1) : "v"(ADDR) : "memory")
+    auto wait_landed = [&](int upto) {                        // every stage <= upto of THIS wave has landed
+        const int later = (st_n - 1 - upto) * per_stage;     // DMA instructions issued after it: 0, 4 / 5, 8 / 10
+        if (later >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (later == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (later == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else if (later == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    bool hot = false;      // v[96:175] hold the row fragments / row constants of slice `it` (prefetched by the previous body)
     int cur = 0, sl = 0;
     for (int it = 0; it < niter; ++it) {
-        // slice `it` has landed; the stage behind it may still fly (wave 0 issues 5 DMA instructions per stage, the others 4)
-        if (it + 1 < niter) {
+        // slices <= it + 1 have landed (the body prefetches from the next image).  Steady state (slices still being staged):
+        // exactly one later stage (it + 2) is in flight
+        if (st_n < niter) {
             if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wait_landed(it + 1 < niter ? it + 1 : it);
         }
         __builtin_amdgcn_s_barrier();
-        if (st_n < niter) stage_next();                      // slice it + 2 -> the image read in iteration it - 1
+        if (st_n < niter) stage_next();                      // slice it + 3 -> the image of slice it - 1
         const int qb = qt0 + sl * kD128Sl;
         const bool active = (qb + kD128Sl - 1 >= k0) && (k0 < len);
-        if (active) {
+        // three kinds of active slices: plain (every key of the wave visible to every query of the slice), the DIAGONAL one (the
+        // causal boundary crosses it: one per wave and q head, at a different slice for each wave -- the same hand-placed stream
+        // with the mask folded into the S' chains' initial accumulators, so that the block does not wait at the next barrier for
+        // one wave on a slow path), and the tail (sequence end inside the slice or inside the wave's keys: hipcc's select-based
+        // code below; the last slice of a head for all four waves at once)
+        const bool tail = (qb + kD128Sl > len) || (k0 + 32 > len);
+        const bool diag = qb < k0 + 31;
+        const unsigned img = smem_base + cur * kD128Img;
+        const unsigned next_img = smem_base + ((cur + 1) & (kD128Ring - 1)) * kD128Img;
+        if (active && !tail) {
+            if (!diag) {
+                if (hot)
+                    RPO_D128_SLICE_BODY_HOT(img + row_off[0], img + row_off[1], img + row_off[2], img + row_off[3], img + rc_off,
+                                            img + tr_off[0], img + tr_off[1], img + tr_off[2], img + tr_off[3], img + tr_off[4],
+                                            img + tr_off[5], img + tr_off[6], img + tr_off[7], scale_log2e, next_img + row_off[0],
+                                            next_img + row_off[1], next_img + row_off[2], next_img + row_off[3], next_img + rc_off);
+                else
+                    RPO_D128_SLICE_BODY_LOAD(img + row_off[0], img + row_off[1], img + row_off[2], img + row_off[3], img + rc_off,
+                                             img + tr_off[0], img + tr_off[1], img + tr_off[2], img + tr_off[3], img + tr_off[4],
+                                             img + tr_off[5], img + tr_off[6], img + tr_off[7], scale_log2e, next_img + row_off[0],
+                                             next_img + row_off[1], next_img + row_off[2], next_img + row_off[3], next_img + rc_off);
+            } else {
+                const int dlane = (k0 + fr) - (qb + 4 * g);      // the lane's key (tile 0) minus its first query row
+                if (hot)
+                    RPO_D128_DIAG_BODY_HOT(img + row_off[0], img + row_off[1], img + row_off[2], img + row_off[3], img + rc_off,
+                                           img + tr_off[0], img + tr_off[1], img + tr_off[2], img + tr_off[3], img + tr_off[4],
+                                           img + tr_off[5], img + tr_off[6], img + tr_off[7], scale_log2e, next_img + row_off[0],
+                                           next_img + row_off[1], next_img + row_off[2], next_img + row_off[3], next_img + rc_off,
+                                           dlane);
+                else
+                    RPO_D128_DIAG_BODY_LOAD(img + row_off[0], img + row_off[1], img + row_off[2], img + row_off[3], img + rc_off,
+                                            img + tr_off[0], img + tr_off[1], img + tr_off[2], img + tr_off[3], img + tr_off[4],
+                                            img + tr_off[5], img + tr_off[6], img + tr_off[7], scale_log2e, next_img + row_off[0],
+                                            next_img + row_off[1], next_img + row_off[2], next_img + row_off[3], next_img + rc_off,
+                                            dlane);
+            }
+            hot = true;
+        } else if (active) {
+            hot = false;
             const char* Qs = smem + cur * kD128Img;
             const char* Ds = Qs + kD128Sl * kFa128Row;
             const float* Ls = reinterpret_cast<const float*>(Qs + 2 * kD128Sl * kFa128Row);
-            const unsigned tb = smem_base + cur * kD128Img;
-            // dO^T fragments (A operands of dV^T += dO^T P): d[c] = queries 4g .. 4g + 3 of rows 0-15, dd[c] = of rows 16-31
-            u32x2 d0, d1, d2, d3, d4, d5, d6, d7, dd0, dd1, dd2, dd3, dd4, dd5, dd6, dd7;
-            {
-                const unsigned db = tb + kD128Sl * kFa128Row;
-                RPO_TR2H(d0, dd0, db + tr_off[0]);
-                RPO_TR2H(d1, dd1, db + tr_off[1]);
-                RPO_TR2H(d2, dd2, db + tr_off[2]);
-                RPO_TR2H(d3, dd3, db + tr_off[3]);
-                RPO_TR2H(d4, dd4, db + tr_off[4]);
-                RPO_TR2H(d5, dd5, db + tr_off[5]);
-                RPO_TR2H(d6, dd6, db + tr_off[6]);
-                RPO_TR2H(d7, dd7, db + tr_off[7]);
-            }
+            const unsigned tb = img;
             float4_t s[2][2], dp[2][2];                       // [query tile m][key tile n]; rows = queries 16m + 4g + r, col = key 16n + fr
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
@@ -2867,63 +2878,39 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
                     dp[m][n] = dr;
                 }
             }
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const short8_t aq = *reinterpret_cast<const short8_t*>(Qs + row_off[ks] + m * 16 * kFa128Row);
-                    const short8_t ad = *reinterpret_cast<const short8_t*>(Ds + row_off[ks] + m * 16 * kFa128Row);
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        // asm with VGPR accumulators: the builtin takes its accumulators from the accumulator file, i.e. from a[0:31]
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(s[m][n]) : "v"(aq), "v"(bk[n][ks]));
-                        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(dp[m][n]) : "v"(ad), "v"(bv[n][ks]));
-                    }
-                }
+#define RPO_D128_M1_STEP(KS)                                                                                        \
+            {                                                                                                       \
+                const short8_t aq0_ = *reinterpret_cast<const short8_t*>(Qs + row_off[KS]);                          \
+                const short8_t ad0_ = *reinterpret_cast<const short8_t*>(Ds + row_off[KS]);                          \
+                const short8_t aq1_ = *reinterpret_cast<const short8_t*>(Qs + row_off[KS] + 16 * kFa128Row);         \
+                const short8_t ad1_ = *reinterpret_cast<const short8_t*>(Ds + row_off[KS] + 16 * kFa128Row);         \
+                RPO_D128_M1_KS##KS(0, aq0_, ad0_);                                                                   \
+                RPO_D128_M1_KS##KS(1, aq1_, ad1_);                                                                   \
             }
+            RPO_D128_M1_STEP(0)
+            RPO_D128_M1_STEP(1)
+            RPO_D128_M1_STEP(2)
+            RPO_D128_M1_STEP(3)
+#undef RPO_D128_M1_STEP
             // 8-pass MFMA result -> VALU read: 11 wait states, which hipcc cannot count for asm; the operands pin the statement
             // between the chains and their first use
             asm volatile("s_nop 15"
                          : "+v"(s[0][0]), "+v"(s[0][1]), "+v"(s[1][0]), "+v"(s[1][1]), "+v"(dp[0][0]), "+v"(dp[0][1]),
                            "+v"(dp[1][0]), "+v"(dp[1][1]));
-            // Q^T fragments (A operands of dK^T += Q^T dS): land under the arithmetic below
-            u32x2 e0, e1, e2, e3, e4, e5, e6, e7, ee0, ee1, ee2, ee3, ee4, ee5, ee6, ee7;
-            RPO_TR2H(e0, ee0, tb + tr_off[0]);
-            RPO_TR2H(e1, ee1, tb + tr_off[1]);
-            RPO_TR2H(e2, ee2, tb + tr_off[2]);
-            RPO_TR2H(e3, ee3, tb + tr_off[3]);
-            RPO_TR2H(e4, ee4, tb + tr_off[4]);
-            RPO_TR2H(e5, ee5, tb + tr_off[5]);
-            RPO_TR2H(e6, ee6, tb + tr_off[6]);
-            RPO_TR2H(e7, ee7, tb + tr_off[7]);
-            const bool need_mask = (qb < k0 + 31) || (qb + kD128Sl > len) || (k0 + 32 > len);
-            if (need_mask) {
 #pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    const int qr0 = qb + 16 * m + 4 * g;
+            for (int m = 0; m < 2; ++m) {
+                const int qr0 = qb + 16 * m + 4 * g;
 #pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        const int key = k0 + 16 * n + fr;
+                for (int n = 0; n < 2; ++n) {
+                    const int key = k0 + 16 * n + fr;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
-                            pv = (key > qr0 + r || key >= len || qr0 + r >= len) ? 0.f : pv;
-                            s[m][n][r] = pv;
-                            dp[m][n][r] = pv * dp[m][n][r];
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
+                        pv = (key > qr0 + r || key >= len || qr0 + r >= len) ? 0.f : pv;
+                        s[m][n][r] = pv;
+                        dp[m][n][r] = pv * dp[m][n][r];
                     }
                 }
-            } else {
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const float pv = __builtin_amdgcn_exp2f(s[m][n][r] * scale_log2e);
-                            s[m][n][r] = pv;
-                            dp[m][n][r] = pv * dp[m][n][r];
-                        }
             }
             short8_t pf[2], dsf[2];                         // k-slots = queries {4g + j, 16 + 4g + (j - 4)} of the slice
 #pragma unroll
@@ -2931,88 +2918,29 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
                 pf[n] = pack_frag(s[0][n], s[1][n]);
                 dsf[n] = pack_frag(dp[0][n], dp[1][n]);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7), "+v"(dd0),
-                           "+v"(dd1), "+v"(dd2), "+v"(dd3), "+v"(dd4), "+v"(dd5), "+v"(dd6), "+v"(dd7)
-                         :
-                         : "memory");
-            asm volatile(""
-                         : "+v"(e0), "+v"(e1), "+v"(e2), "+v"(e3), "+v"(e4), "+v"(e5), "+v"(e6), "+v"(e7), "+v"(ee0),
-                           "+v"(ee1), "+v"(ee2), "+v"(ee3), "+v"(ee4), "+v"(ee5), "+v"(ee6), "+v"(ee7)
-                         :
-                         : "memory");
-            const short8_t atd[8] = {join_tr(d0, dd0), join_tr(d1, dd1), join_tr(d2, dd2), join_tr(d3, dd3),
-                                     join_tr(d4, dd4), join_tr(d5, dd5), join_tr(d6, dd6), join_tr(d7, dd7)};
-            const short8_t atq[8] = {join_tr(e0, ee0), join_tr(e1, ee1), join_tr(e2, ee2), join_tr(e3, ee3),
-                                     join_tr(e4, ee4), join_tr(e5, ee5), join_tr(e6, ee6), join_tr(e7, ee7)};
-            // dV^T += dO^T P, dK^T += Q^T dS on the literal accumulators.  hipcc does not see inside the statements: the s_nop covers
-            // a VALU-written operand (packing, fragment assembly) in front of an MFMA.
-            asm volatile("s_nop 1\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[0:3], %0, %2, a[0:3]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[64:67], %1, %4, a[64:67]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[4:7], %0, %3, a[4:7]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[68:71], %1, %5, a[68:71]"
-                         :
-                         : "v"(atd[0]), "v"(atq[0]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
-                         : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71");
-            asm volatile("s_nop 1\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[8:11], %0, %2, a[8:11]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[72:75], %1, %4, a[72:75]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[12:15], %0, %3, a[12:15]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[76:79], %1, %5, a[76:79]"
-                         :
-                         : "v"(atd[1]), "v"(atq[1]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
-                         : "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79");
-            asm volatile("s_nop 1\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[16:19], %0, %2, a[16:19]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[80:83], %1, %4, a[80:83]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[20:23], %0, %3, a[20:23]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[84:87], %1, %5, a[84:87]"
-                         :
-                         : "v"(atd[2]), "v"(atq[2]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
-                         : "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87");
-            asm volatile("s_nop 1\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[24:27], %0, %2, a[24:27]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[88:91], %1, %4, a[88:91]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[28:31], %0, %3, a[28:31]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[92:95], %1, %5, a[92:95]"
-                         :
-                         : "v"(atd[3]), "v"(atq[3]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
-                         : "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95");
-            asm volatile("s_nop 1\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[32:35], %0, %2, a[32:35]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[96:99], %1, %4, a[96:99]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[36:39], %0, %3, a[36:39]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[100:103], %1, %5, a[100:103]"
-                         :
-                         : "v"(atd[4]), "v"(atq[4]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
-                         : "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103");
-            asm volatile("s_nop 1\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[40:43], %0, %2, a[40:43]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[104:107], %1, %4, a[104:107]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[44:47], %0, %3, a[44:47]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[108:111], %1, %5, a[108:111]"
-                         :
-                         : "v"(atd[5]), "v"(atq[5]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
-                         : "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111");
-            asm volatile("s_nop 1\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[48:51], %0, %2, a[48:51]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[112:115], %1, %4, a[112:115]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[52:55], %0, %3, a[52:55]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[116:119], %1, %5, a[116:119]"
-                         :
-                         : "v"(atd[6]), "v"(atq[6]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
-                         : "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119");
-            asm volatile("s_nop 1\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[56:59], %0, %2, a[56:59]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[120:123], %1, %4, a[120:123]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[60:63], %0, %3, a[60:63]\n\t"
-                         "v_mfma_f32_16x16x32_bf16 a[124:127], %1, %5, a[124:127]"
-                         :
-                         : "v"(atd[7]), "v"(atq[7]), "v"(pf[0]), "v"(pf[1]), "v"(dsf[0]), "v"(dsf[1])
-                         : "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127");
+            // M2 one hd tile at a time: dO^T / Q^T fragments by transposed reads (d = queries 4g .. 4g + 3 of rows 0-15, dd = of 16-31)
+#define RPO_D128_M2_STEP(C)                                                                                         \
+            {                                                                                                       \
+                u32x2 d_, dd_, e_, ee_;                                                                              \
+                RPO_TR2H(d_, dd_, tb + kD128Sl * kFa128Row + tr_off[C]);                                             \
+                RPO_TR2H(e_, ee_, tb + tr_off[C]);                                                                   \
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d_), "+v"(dd_), "+v"(e_), "+v"(ee_) : : "memory");        \
+                const short8_t atd_ = join_tr(d_, dd_), atq_ = join_tr(e_, ee_);                                     \
+                RPO_D128_M2_C##C(atd_, atq_, pf, dsf);                                                               \
+            }
+            RPO_D128_M2_STEP(0)
+            RPO_D128_M2_STEP(1)
+            RPO_D128_M2_STEP(2)
+            RPO_D128_M2_STEP(3)
+            RPO_D128_M2_STEP(4)
+            RPO_D128_M2_STEP(5)
+            RPO_D128_M2_STEP(6)
+            RPO_D128_M2_STEP(7)
+#undef RPO_D128_M2_STEP
+        } else {
+            hot = false;
         }
-        cur = cur == 2 ? 0 : cur + 1;
+        cur = (cur + 1) & (kD128Ring - 1);
         sl = sl + 1 == nsl ? 0 : sl + 1;
     }
 #undef RPO_TR2H
@@ -3198,7 +3126,12 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
                    lse, (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride, rope_cos, rope_sin, rope_period);
         const int rc128 = rpo_launch_status();
         if (rc128 != RPO_OK) return rc128;
-        RPO_LAUNCH(fa_bwd_dkdv128_kernel, dim3((unsigned)(((n_k_tiles + 7) / 8) * 8)), dim3(256), 0, st, (const bf16_t*)q,
+        static const bool attr128_set = [] {
+            (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kD128Lds);
+            return true;
+        }();
+        (void)attr128_set;
+        RPO_LAUNCH(fa_bwd_dkdv128_kernel, dim3((unsigned)(((n_k_tiles + 7) / 8) * 8)), dim3(256), kD128Lds, st, (const bf16_t*)q,
                    (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens,
                    k_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
                    (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles, rope_cos, rope_sin, rope_period);

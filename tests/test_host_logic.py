@@ -652,3 +652,15 @@ def test_gloo_optimizer_state_partition(world):
     ret = mgr.dict()
     mp.spawn(_partition_worker, args=(world, 29741 + world, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def test_generated_dkdv128_bodies_are_in_sync():
+    """rankpo_amd/csrc/attention_dkdv128_gen.inc (the hand-placed slice bodies of fa_bwd_dkdv128_kernel and its literal-register
+    statements) is generated text: it must be what tools/gen/gen_dkdv128_body.py emits today (edit the generator, not the file)."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GEN_")}
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_dkdv128_body.py")], capture_output=True,
+                         text=True, check=True, env=env).stdout
+    assert gen == open(os.path.join(root, "rankpo_amd", "csrc", "attention_dkdv128_gen.inc")).read()

@@ -12,14 +12,17 @@ for path in sys.argv[1:]:
         getattr(l, name).restype, getattr(l, name).argtypes = _lib.SIGNATURES[name]
     libs[os.path.basename(path)] = l
 DEV = "cuda"; torch.manual_seed(0)
-nh, nkv, hd, N, L = 32, 8, 64, 48, 4096
+hd = int(os.environ.get("HD", "64"))                    # HD=128: cfg 5's shape (24 sequences), key blocks of 128
+nh, nkv, N, L = 32, 8, (48 if hd == 64 else 24), 4096
+KB = 256 if hd == 64 else 128
+SC = 1.0 / hd ** 0.5
 lens = torch.randint(L // 2, L + 1, (N,)); lens[0] = L
 lens = lens.tolist(); T = sum(lens)
 q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
 k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
 v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
 cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
-tiles = ops.attn_tile_table(lens, DEV, nh, nkv); kt = ops.attn_key_tile_table(lens, DEV, nkv)
+tiles = ops.attn_tile_table(lens, DEV, nh, nkv); kt = ops.attn_key_tile_table(lens, DEV, nkv, KB)
 fl = sum(4 * nh * hd * n * (n + 1) / 2 for n in lens)
 st = torch.cuda.current_stream().cuda_stream
 out = {n: torch.empty(T, nh, hd, device=DEV, dtype=torch.bfloat16) for n in libs}
@@ -29,12 +32,12 @@ delta = torch.empty(2, nh, T, device=DEV)
 dq = {n: torch.empty_like(q) for n in libs}; dk = {n: torch.empty_like(k) for n in libs}; dv = {n: torch.empty_like(v) for n in libs}
 def fwd(n):
     return libs[n].rpo_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0), cu.data_ptr(),
-                                      tiles.data_ptr(), tiles.shape[0], tiles.shape[1], T, nh, nkv, hd, 0.125, out[n].data_ptr(), nh * hd,
+                                      tiles.data_ptr(), tiles.shape[0], tiles.shape[1], T, nh, nkv, hd, SC, out[n].data_ptr(), nh * hd,
                                       lse[n].data_ptr(), 0, None, None, 0, st)
 def bwd(n):
     return libs[n].rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out[n].data_ptr(), go.data_ptr(), q.stride(0), k.stride(0),
                                       v.stride(0), out[n].stride(0), go.stride(0), cu.data_ptr(), tiles.data_ptr(), tiles.shape[0],
-                                      tiles.shape[1], kt.data_ptr(), kt.shape[0], 256, 0, T, nh, nkv, hd, 0.125, lse[n].data_ptr(),
+                                      tiles.shape[1], kt.data_ptr(), kt.shape[0], KB, 0, T, nh, nkv, hd, SC, lse[n].data_ptr(),
                                       delta.data_ptr(), dq[n].data_ptr(), dk[n].data_ptr(), dv[n].data_ptr(), q.stride(0), k.stride(0),
                                       v.stride(0), None, None, 0, st)
 def t(fn, n=5):
