@@ -2698,8 +2698,16 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
 constexpr int kD128Sl = 32;                                        // query rows per slice
 constexpr int kD128Img = 2 * kD128Sl * kFa128Row + 256;            // Q | dO | 32 x -lse / scale | 32 x -delta = 16640 B
 constexpr int kD128Keys = 128;                                     // keys per block (4 waves x 32)
-constexpr int kD128Ring = 4, kD128Ahead = 3;                       // slice images: ring of 4, 3 slices ahead of the one consumed
+#ifndef RPO_D128_AHEAD
+#define RPO_D128_AHEAD 3
+#endif
+// slice images: ring of 4, 3 slices ahead of the one consumed.  Deeper does not pay (measured in one process, backward entry
+// point on cfg 5's shape: 3 / 4 / 6 / 7 ahead in a ring of 8 = 7.727 / 7.725 / 7.724 / 7.723 ms): the ring hides the latency
+// already; what the Q / dO stream still costs (1.0 ms of the kernel's 4.3: 0.2 for issuing the DMA instructions, 0.8 that
+// vanish when every stage re-reads the SAME slice) is throughput of the L2 -> L1 -> LDS path, which no queue depth buys back.
+constexpr int kD128Ring = 4, kD128Ahead = RPO_D128_AHEAD;
 constexpr int kD128Lds = kD128Ring * kD128Img;                     // 66560 B (dynamic)
+static_assert(kD128Ahead >= 2 && kD128Ahead < kD128Ring, "the image of stage it + Ahead must not be one of the two being read");
 
 #include "attention_dkdv128_gen.inc"
 
@@ -2776,7 +2784,11 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
     };
     int st_h = hk * group, st_s = 0, st_buf = 0, st_n = 0;     // (q head, slice) of the next stage, head-major, slices ascending
     auto stage_next = [&]() {
+#if defined(RPO_D128_EXP) && RPO_D128_EXP == 3                    // (timing experiment: every stage re-reads the SAME slice: L2 hits)
+        stage(hk * group, qt0, st_buf);
+#else
         stage(st_h, qt0 + st_s * kD128Sl, st_buf);
+#endif
         if (++st_s == nsl) { st_s = 0; ++st_h; }
         ++st_n;
         st_buf = (st_buf + 1) & (kD128Ring - 1);
@@ -2797,31 +2809,43 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
     for (int ks = 0; ks < 4; ++ks) row_off[ks] = fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
     const unsigned rc_off = 2 * kD128Sl * kFa128Row + 16 * g;   // row constants of the lane's 4 rows (tile m at + 64, -delta at + 128)
-    const int per_stage = wave == 0 ? 5 : 4;                   // DMA instructions this wave issues per slice
 
 #define RPO_TR2H(OUT0, OUT1, ADDR)                                                                              \
     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=&v"(OUT0), "=&v"(OUT1) : "v"(ADDR) : "memory")
+    // s_waitcnt takes an immediate: one statement per (number of later stages in flight, DMA instructions per stage)
+#define RPO_D128_WAIT(N)                                                                                            \
+    do {                                                                                                            \
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (N)) : "memory");                               \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (N)) : "memory");                                         \
+    } while (0)
     auto wait_landed = [&](int upto) {                        // every stage <= upto of THIS wave has landed
-        const int later = (st_n - 1 - upto) * per_stage;     // DMA instructions issued after it: 0, 4 / 5, 8 / 10
-        if (later >= 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-        else if (later == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (later == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-        else if (later == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int later = st_n - 1 - upto;                   // stages issued after it: 0 .. Ahead - 1
+        if (later >= 6) RPO_D128_WAIT(6);
+        else if (later == 5) RPO_D128_WAIT(5);
+        else if (later == 4) RPO_D128_WAIT(4);
+        else if (later == 3) RPO_D128_WAIT(3);
+        else if (later == 2) RPO_D128_WAIT(2);
+        else if (later == 1) RPO_D128_WAIT(1);
+        else RPO_D128_WAIT(0);
     };
     bool hot = false;      // v[96:175] hold the row fragments / row constants of slice `it` (prefetched by the previous body)
     int cur = 0, sl = 0;
     for (int it = 0; it < niter; ++it) {
         // slices <= it + 1 have landed (the body prefetches from the next image).  Steady state (slices still being staged):
-        // exactly one later stage (it + 2) is in flight
+        // stages it + 2 .. it + Ahead - 1 are in flight
         if (st_n < niter) {
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            RPO_D128_WAIT(kD128Ahead - 2);
         } else {
             wait_landed(it + 1 < niter ? it + 1 : it);
         }
+#if !defined(RPO_D128_EXP) || RPO_D128_EXP != 1               // (timing experiments: tools/exp/build_d128_variant.sh)
         __builtin_amdgcn_s_barrier();
-        if (st_n < niter) stage_next();                      // slice it + 3 -> the image of slice it - 1
+#endif
+#if !defined(RPO_D128_EXP) || RPO_D128_EXP != 2
+        if (st_n < niter) stage_next();                      // slice it + Ahead -> an image whose slice (<= it - 2) is done
+#else
+        if (st_n < niter) ++st_n;
+#endif
         const int qb = qt0 + sl * kD128Sl;
         const bool active = (qb + kD128Sl - 1 >= k0) && (k0 < len);
         // three kinds of active slices: plain (every key of the wave visible to every query of the slice), the DIAGONAL one (the

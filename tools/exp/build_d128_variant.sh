@@ -10,7 +10,7 @@ mkdir -p "$tmp/../include_dummy"
 env "$@" python tools/gen/gen_dkdv128_body.py > "$tmp/attention_dkdv128_gen.inc"
 sed -i "s|-I../../include|-I$(pwd)/include|; s|../../include/rankpo_hip.h|$(pwd)/include/rankpo_hip.h|" "$tmp/Makefile"
 sed -i "s|#include \"../../include/rankpo_hip.h\"|#include \"$(pwd)/include/rankpo_hip.h\"|" "$tmp/common.hpp"
-make -C "$tmp" -j8 > /dev/null
+make -C "$tmp" -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -I$(pwd)/include $CXXEXTRA" > /dev/null
 cp "$tmp/librankpo_hip.so" "tools/exp/librankpo_hip_$name.so"
 rm -rf "$tmp"
 echo "built tools/exp/librankpo_hip_$name.so"

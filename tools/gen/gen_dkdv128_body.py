@@ -127,6 +127,7 @@ READY = lambda n: 16 * (n + 1) + 2     # two MFMAs of the next group have issued
 RATE = int(os.environ.get("GEN_RATE", "3"))     # VALU instructions per MFMA gap
 NO_VALU = os.environ.get("GEN_NO_VALU") == "1"      # timing experiments only (results are wrong)
 NO_PREFETCH = os.environ.get("GEN_NO_PREFETCH") == "1"
+NO_TR = os.environ.get("GEN_NO_TR") == "1"
 ALL_V = ", ".join('"v%d"' % i for i in range(64, 256))
 ALL_A = ", ".join('"a%d"' % i for i in range(0, 192))
 
@@ -145,7 +146,7 @@ def build(hot, diag=False):
     if not hot:
         out += loads
     out.append("s_waitcnt lgkmcnt(0)")             # row fragments / row constants of this slice are in v[96:175]
-    lds = list(tr)
+    lds = [] if NO_TR else list(tr)
     if TR_RATE == 0:
         out += lds
         lds = []
