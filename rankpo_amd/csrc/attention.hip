@@ -1264,483 +1264,1093 @@ constexpr int kDkdv4Lds = kSlRing * kSlImg;                  // 67584 B
           "v"(PF[3]), "v"(DS[3])                                                                            \
         : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
 // generated by tools/gen/gen_dkdv4_body.py (register map and operand list there); 238 instructions
-#define RPO_D4_SLICE_BODY_LOAD(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD) \
-    asm volatile( \
-        "ds_read_b128 v[160:163], %2\n\t" \
-        "ds_read_b128 v[168:171], %2 offset:128\n\t" \
-        "ds_read_b128 v[128:131], %0\n\t" \
-        "ds_read_b128 v[132:135], %0 offset:4096\n\t" \
-        "ds_read_b128 v[164:167], %2 offset:64\n\t" \
-        "ds_read_b128 v[172:175], %2 offset:192\n\t" \
-        "ds_read_b128 v[136:139], %0 offset:2048\n\t" \
-        "ds_read_b128 v[140:143], %0 offset:6144\n\t" \
-        "ds_read_b128 v[144:147], %1\n\t" \
-        "ds_read_b128 v[148:151], %1 offset:4096\n\t" \
-        "ds_read_b128 v[152:155], %1 offset:2048\n\t" \
-        "ds_read_b128 v[156:159], %1 offset:6144\n\t" \
-        "s_waitcnt lgkmcnt(0)\n\t" \
-        "ds_read_b64_tr_b16 v[176:177], %3 offset:4096\n\t" \
-        "ds_read_b64_tr_b16 v[178:179], %3 offset:6144\n\t" \
-        "ds_read_b64_tr_b16 v[192:193], %3\n\t" \
-        "ds_read_b64_tr_b16 v[194:195], %3 offset:2048\n\t" \
-        "ds_read_b64_tr_b16 v[180:181], %4 offset:4096\n\t" \
-        "ds_read_b64_tr_b16 v[182:183], %4 offset:6144\n\t" \
-        "ds_read_b64_tr_b16 v[196:197], %4\n\t" \
-        "ds_read_b64_tr_b16 v[198:199], %4 offset:2048\n\t" \
-        "ds_read_b64_tr_b16 v[184:185], %5 offset:4096\n\t" \
-        "ds_read_b64_tr_b16 v[186:187], %5 offset:6144\n\t" \
-        "ds_read_b64_tr_b16 v[200:201], %5\n\t" \
-        "ds_read_b64_tr_b16 v[202:203], %5 offset:2048\n\t" \
-        "ds_read_b64_tr_b16 v[188:189], %6 offset:4096\n\t" \
-        "ds_read_b64_tr_b16 v[190:191], %6 offset:6144\n\t" \
-        "ds_read_b64_tr_b16 v[204:205], %6\n\t" \
-        "ds_read_b64_tr_b16 v[206:207], %6 offset:2048\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[64:67], v[128:131], a[128:131], v[160:163]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[80:83], v[136:139], a[128:131], v[164:167]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[96:99], v[132:135], a[160:163], v[168:171]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[112:115], v[140:143], a[160:163], v[172:175]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[64:67], v[144:147], a[132:135], v[64:67]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[80:83], v[152:155], a[132:135], v[80:83]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[96:99], v[148:151], a[164:167], v[96:99]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[112:115], v[156:159], a[164:167], v[112:115]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[68:71], v[128:131], a[136:139], v[160:163]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[84:87], v[136:139], a[136:139], v[164:167]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[100:103], v[132:135], a[168:171], v[168:171]\n\t" \
-        "v_mul_f32 v64, %7, v64\n\t" \
-        "v_mul_f32 v65, %7, v65\n\t" \
-        "v_mul_f32 v66, %7, v66\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[116:119], v[140:143], a[168:171], v[172:175]\n\t" \
-        "v_mul_f32 v67, %7, v67\n\t" \
-        "v_mul_f32 v80, %7, v80\n\t" \
-        "v_mul_f32 v81, %7, v81\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[68:71], v[144:147], a[140:143], v[68:71]\n\t" \
-        "v_mul_f32 v82, %7, v82\n\t" \
-        "v_mul_f32 v83, %7, v83\n\t" \
-        "v_exp_f32 v64, v64\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[84:87], v[152:155], a[140:143], v[84:87]\n\t" \
-        "v_exp_f32 v65, v65\n\t" \
-        "v_exp_f32 v66, v66\n\t" \
-        "v_exp_f32 v67, v67\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[100:103], v[148:151], a[172:175], v[100:103]\n\t" \
-        "v_exp_f32 v80, v80\n\t" \
-        "v_exp_f32 v81, v81\n\t" \
-        "v_exp_f32 v82, v82\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[116:119], v[156:159], a[172:175], v[116:119]\n\t" \
-        "v_exp_f32 v83, v83\n\t" \
-        "v_mul_f32 v96, v64, v96\n\t" \
-        "v_mul_f32 v97, v65, v97\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[72:75], v[128:131], a[144:147], v[160:163]\n\t" \
-        "v_mul_f32 v98, v66, v98\n\t" \
-        "v_mul_f32 v99, v67, v99\n\t" \
-        "v_mul_f32 v112, v80, v112\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[88:91], v[136:139], a[144:147], v[164:167]\n\t" \
-        "v_mul_f32 v113, v81, v113\n\t" \
-        "v_mul_f32 v114, v82, v114\n\t" \
-        "v_mul_f32 v115, v83, v115\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[104:107], v[132:135], a[176:179], v[168:171]\n\t" \
-        "v_cvt_pk_bf16_f32 v208, v64, v65\n\t" \
-        "v_cvt_pk_bf16_f32 v209, v66, v67\n\t" \
-        "v_cvt_pk_bf16_f32 v210, v80, v81\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[120:123], v[140:143], a[176:179], v[172:175]\n\t" \
-        "v_cvt_pk_bf16_f32 v211, v82, v83\n\t" \
-        "v_cvt_pk_bf16_f32 v224, v96, v97\n\t" \
-        "v_cvt_pk_bf16_f32 v225, v98, v99\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[72:75], v[144:147], a[148:151], v[72:75]\n\t" \
-        "v_cvt_pk_bf16_f32 v226, v112, v113\n\t" \
-        "v_cvt_pk_bf16_f32 v227, v114, v115\n\t" \
-        "v_mul_f32 v68, %7, v68\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[88:91], v[152:155], a[148:151], v[88:91]\n\t" \
-        "v_mul_f32 v69, %7, v69\n\t" \
-        "v_mul_f32 v70, %7, v70\n\t" \
-        "v_mul_f32 v71, %7, v71\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[104:107], v[148:151], a[180:183], v[104:107]\n\t" \
-        "v_mul_f32 v84, %7, v84\n\t" \
-        "v_mul_f32 v85, %7, v85\n\t" \
-        "v_mul_f32 v86, %7, v86\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[120:123], v[156:159], a[180:183], v[120:123]\n\t" \
-        "v_mul_f32 v87, %7, v87\n\t" \
-        "v_exp_f32 v68, v68\n\t" \
-        "v_exp_f32 v69, v69\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[76:79], v[128:131], a[152:155], v[160:163]\n\t" \
-        "v_exp_f32 v70, v70\n\t" \
-        "v_exp_f32 v71, v71\n\t" \
-        "v_exp_f32 v84, v84\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[92:95], v[136:139], a[152:155], v[164:167]\n\t" \
-        "v_exp_f32 v85, v85\n\t" \
-        "v_exp_f32 v86, v86\n\t" \
-        "v_exp_f32 v87, v87\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[108:111], v[132:135], a[184:187], v[168:171]\n\t" \
-        "v_mul_f32 v100, v68, v100\n\t" \
-        "v_mul_f32 v101, v69, v101\n\t" \
-        "v_mul_f32 v102, v70, v102\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[124:127], v[140:143], a[184:187], v[172:175]\n\t" \
-        "v_mul_f32 v103, v71, v103\n\t" \
-        "v_mul_f32 v116, v84, v116\n\t" \
-        "v_mul_f32 v117, v85, v117\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[76:79], v[144:147], a[156:159], v[76:79]\n\t" \
-        "v_mul_f32 v118, v86, v118\n\t" \
-        "v_mul_f32 v119, v87, v119\n\t" \
-        "v_cvt_pk_bf16_f32 v212, v68, v69\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[92:95], v[152:155], a[156:159], v[92:95]\n\t" \
-        "v_cvt_pk_bf16_f32 v213, v70, v71\n\t" \
-        "v_cvt_pk_bf16_f32 v214, v84, v85\n\t" \
-        "v_cvt_pk_bf16_f32 v215, v86, v87\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[108:111], v[148:151], a[188:191], v[108:111]\n\t" \
-        "v_cvt_pk_bf16_f32 v228, v100, v101\n\t" \
-        "v_cvt_pk_bf16_f32 v229, v102, v103\n\t" \
-        "v_cvt_pk_bf16_f32 v230, v116, v117\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[124:127], v[156:159], a[188:191], v[124:127]\n\t" \
-        "v_cvt_pk_bf16_f32 v231, v118, v119\n\t" \
-        "v_mul_f32 v72, %7, v72\n\t" \
-        "v_mul_f32 v73, %7, v73\n\t" \
-        "s_waitcnt lgkmcnt(0)\n\t" \
-        "ds_read_b128 v[160:163], %10\n\t" \
-        "ds_read_b128 v[168:171], %10 offset:128\n\t" \
-        "ds_read_b128 v[128:131], %8\n\t" \
-        "ds_read_b128 v[132:135], %8 offset:4096\n\t" \
-        "ds_read_b128 v[164:167], %10 offset:64\n\t" \
-        "ds_read_b128 v[172:175], %10 offset:192\n\t" \
-        "ds_read_b128 v[136:139], %8 offset:2048\n\t" \
-        "ds_read_b128 v[140:143], %8 offset:6144\n\t" \
-        "ds_read_b128 v[144:147], %9\n\t" \
-        "ds_read_b128 v[148:151], %9 offset:4096\n\t" \
-        "ds_read_b128 v[152:155], %9 offset:2048\n\t" \
-        "ds_read_b128 v[156:159], %9 offset:6144\n\t" \
-        "s_nop 1\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[0:3], v[176:179], v[208:211], a[0:3]\n\t" \
-        "v_mul_f32 v74, %7, v74\n\t" \
-        "v_mul_f32 v75, %7, v75\n\t" \
-        "v_mul_f32 v88, %7, v88\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[64:67], v[192:195], v[224:227], a[64:67]\n\t" \
-        "v_mul_f32 v89, %7, v89\n\t" \
-        "v_mul_f32 v90, %7, v90\n\t" \
-        "v_mul_f32 v91, %7, v91\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[16:19], v[180:183], v[208:211], a[16:19]\n\t" \
-        "v_exp_f32 v72, v72\n\t" \
-        "v_exp_f32 v73, v73\n\t" \
-        "v_exp_f32 v74, v74\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[80:83], v[196:199], v[224:227], a[80:83]\n\t" \
-        "v_exp_f32 v75, v75\n\t" \
-        "v_exp_f32 v88, v88\n\t" \
-        "v_exp_f32 v89, v89\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[32:35], v[184:187], v[208:211], a[32:35]\n\t" \
-        "v_exp_f32 v90, v90\n\t" \
-        "v_exp_f32 v91, v91\n\t" \
-        "v_mul_f32 v104, v72, v104\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[96:99], v[200:203], v[224:227], a[96:99]\n\t" \
-        "v_mul_f32 v105, v73, v105\n\t" \
-        "v_mul_f32 v106, v74, v106\n\t" \
-        "v_mul_f32 v107, v75, v107\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[48:51], v[188:191], v[208:211], a[48:51]\n\t" \
-        "v_mul_f32 v120, v88, v120\n\t" \
-        "v_mul_f32 v121, v89, v121\n\t" \
-        "v_mul_f32 v122, v90, v122\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[112:115], v[204:207], v[224:227], a[112:115]\n\t" \
-        "v_mul_f32 v123, v91, v123\n\t" \
-        "v_cvt_pk_bf16_f32 v216, v72, v73\n\t" \
-        "v_cvt_pk_bf16_f32 v217, v74, v75\n\t" \
-        "s_nop 1\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[4:7], v[176:179], v[212:215], a[4:7]\n\t" \
-        "v_cvt_pk_bf16_f32 v218, v88, v89\n\t" \
-        "v_cvt_pk_bf16_f32 v219, v90, v91\n\t" \
-        "v_cvt_pk_bf16_f32 v232, v104, v105\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[68:71], v[192:195], v[228:231], a[68:71]\n\t" \
-        "v_cvt_pk_bf16_f32 v233, v106, v107\n\t" \
-        "v_cvt_pk_bf16_f32 v234, v120, v121\n\t" \
-        "v_cvt_pk_bf16_f32 v235, v122, v123\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[20:23], v[180:183], v[212:215], a[20:23]\n\t" \
-        "v_mul_f32 v76, %7, v76\n\t" \
-        "v_mul_f32 v77, %7, v77\n\t" \
-        "v_mul_f32 v78, %7, v78\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[84:87], v[196:199], v[228:231], a[84:87]\n\t" \
-        "v_mul_f32 v79, %7, v79\n\t" \
-        "v_mul_f32 v92, %7, v92\n\t" \
-        "v_mul_f32 v93, %7, v93\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[36:39], v[184:187], v[212:215], a[36:39]\n\t" \
-        "v_mul_f32 v94, %7, v94\n\t" \
-        "v_mul_f32 v95, %7, v95\n\t" \
-        "v_exp_f32 v76, v76\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[100:103], v[200:203], v[228:231], a[100:103]\n\t" \
-        "v_exp_f32 v77, v77\n\t" \
-        "v_exp_f32 v78, v78\n\t" \
-        "v_exp_f32 v79, v79\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[52:55], v[188:191], v[212:215], a[52:55]\n\t" \
-        "v_exp_f32 v92, v92\n\t" \
-        "v_exp_f32 v93, v93\n\t" \
-        "v_exp_f32 v94, v94\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[116:119], v[204:207], v[228:231], a[116:119]\n\t" \
-        "v_exp_f32 v95, v95\n\t" \
-        "v_mul_f32 v108, v76, v108\n\t" \
-        "v_mul_f32 v109, v77, v109\n\t" \
-        "s_nop 1\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[8:11], v[176:179], v[216:219], a[8:11]\n\t" \
-        "v_mul_f32 v110, v78, v110\n\t" \
-        "v_mul_f32 v111, v79, v111\n\t" \
-        "v_mul_f32 v124, v92, v124\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[72:75], v[192:195], v[232:235], a[72:75]\n\t" \
-        "v_mul_f32 v125, v93, v125\n\t" \
-        "v_mul_f32 v126, v94, v126\n\t" \
-        "v_mul_f32 v127, v95, v127\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[24:27], v[180:183], v[216:219], a[24:27]\n\t" \
-        "v_cvt_pk_bf16_f32 v220, v76, v77\n\t" \
-        "v_cvt_pk_bf16_f32 v221, v78, v79\n\t" \
-        "v_cvt_pk_bf16_f32 v222, v92, v93\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[88:91], v[196:199], v[232:235], a[88:91]\n\t" \
-        "v_cvt_pk_bf16_f32 v223, v94, v95\n\t" \
-        "v_cvt_pk_bf16_f32 v236, v108, v109\n\t" \
-        "v_cvt_pk_bf16_f32 v237, v110, v111\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[40:43], v[184:187], v[216:219], a[40:43]\n\t" \
-        "v_cvt_pk_bf16_f32 v238, v124, v125\n\t" \
-        "v_cvt_pk_bf16_f32 v239, v126, v127\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[104:107], v[200:203], v[232:235], a[104:107]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[56:59], v[188:191], v[216:219], a[56:59]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[120:123], v[204:207], v[232:235], a[120:123]\n\t" \
-        "s_nop 1\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[12:15], v[176:179], v[220:223], a[12:15]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[76:79], v[192:195], v[236:239], a[76:79]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[28:31], v[180:183], v[220:223], a[28:31]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[92:95], v[196:199], v[236:239], a[92:95]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[44:47], v[184:187], v[220:223], a[44:47]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[108:111], v[200:203], v[236:239], a[108:111]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[60:63], v[188:191], v[220:223], a[60:63]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[124:127], v[204:207], v[236:239], a[124:127]" \
-        : \
-        : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1), \
-          "v"(NLRD) \
+#define RPO_D4_SLICE_BODY_LOAD(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD)                    \
+    asm volatile(                                                                                               \
+        "ds_read_b128 v[160:163], %2\n\t"                                                                             \
+        "ds_read_b128 v[168:171], %2 offset:128\n\t"                                                                  \
+        "ds_read_b128 v[128:131], %0\n\t"                                                                             \
+        "ds_read_b128 v[132:135], %0 offset:4096\n\t"                                                                 \
+        "ds_read_b128 v[164:167], %2 offset:64\n\t"                                                                   \
+        "ds_read_b128 v[172:175], %2 offset:192\n\t"                                                                  \
+        "ds_read_b128 v[136:139], %0 offset:2048\n\t"                                                                 \
+        "ds_read_b128 v[140:143], %0 offset:6144\n\t"                                                                 \
+        "ds_read_b128 v[144:147], %1\n\t"                                                                             \
+        "ds_read_b128 v[148:151], %1 offset:4096\n\t"                                                                 \
+        "ds_read_b128 v[152:155], %1 offset:2048\n\t"                                                                 \
+        "ds_read_b128 v[156:159], %1 offset:6144\n\t"                                                                 \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[128:131], a[128:131], v[160:163]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[176:177], %3 offset:4096\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[136:139], a[128:131], v[164:167]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[178:179], %3 offset:6144\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[132:135], a[160:163], v[168:171]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[192:193], %3\n\t"                                                                       \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[140:143], a[160:163], v[172:175]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[194:195], %3 offset:2048\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[144:147], a[132:135], v[64:67]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[180:181], %4 offset:4096\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[152:155], a[132:135], v[80:83]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[182:183], %4 offset:6144\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[148:151], a[164:167], v[96:99]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[196:197], %4\n\t"                                                                       \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[156:159], a[164:167], v[112:115]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[198:199], %4 offset:2048\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[128:131], a[136:139], v[160:163]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[184:185], %5 offset:4096\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[136:139], a[136:139], v[164:167]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[186:187], %5 offset:6144\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[132:135], a[168:171], v[168:171]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[200:201], %5\n\t"                                                                       \
+        "v_mul_f32 v64, %7, v64\n\t"                                                                                  \
+        "v_mul_f32 v65, %7, v65\n\t"                                                                                  \
+        "v_mul_f32 v66, %7, v66\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[140:143], a[168:171], v[172:175]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[202:203], %5 offset:2048\n\t"                                                           \
+        "v_mul_f32 v67, %7, v67\n\t"                                                                                  \
+        "v_mul_f32 v80, %7, v80\n\t"                                                                                  \
+        "v_mul_f32 v81, %7, v81\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[144:147], a[140:143], v[68:71]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[188:189], %6 offset:4096\n\t"                                                           \
+        "v_mul_f32 v82, %7, v82\n\t"                                                                                  \
+        "v_mul_f32 v83, %7, v83\n\t"                                                                                  \
+        "v_exp_f32 v64, v64\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[152:155], a[140:143], v[84:87]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[190:191], %6 offset:6144\n\t"                                                           \
+        "v_exp_f32 v65, v65\n\t"                                                                                      \
+        "v_exp_f32 v66, v66\n\t"                                                                                      \
+        "v_exp_f32 v67, v67\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[148:151], a[172:175], v[100:103]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[204:205], %6\n\t"                                                                       \
+        "v_exp_f32 v80, v80\n\t"                                                                                      \
+        "v_exp_f32 v81, v81\n\t"                                                                                      \
+        "v_exp_f32 v82, v82\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[156:159], a[172:175], v[116:119]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[206:207], %6 offset:2048\n\t"                                                           \
+        "v_exp_f32 v83, v83\n\t"                                                                                      \
+        "v_mul_f32 v96, v64, v96\n\t"                                                                                 \
+        "v_mul_f32 v97, v65, v97\n\t"                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[128:131], a[144:147], v[160:163]\n\t"                                   \
+        "v_mul_f32 v98, v66, v98\n\t"                                                                                 \
+        "v_mul_f32 v99, v67, v99\n\t"                                                                                 \
+        "v_mul_f32 v112, v80, v112\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[136:139], a[144:147], v[164:167]\n\t"                                   \
+        "v_mul_f32 v113, v81, v113\n\t"                                                                               \
+        "v_mul_f32 v114, v82, v114\n\t"                                                                               \
+        "v_mul_f32 v115, v83, v115\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[132:135], a[176:179], v[168:171]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v208, v64, v65\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v209, v66, v67\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v210, v80, v81\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[140:143], a[176:179], v[172:175]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v211, v82, v83\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v224, v96, v97\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v225, v98, v99\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[144:147], a[148:151], v[72:75]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v226, v112, v113\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v227, v114, v115\n\t"                                                                      \
+        "v_mul_f32 v68, %7, v68\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[152:155], a[148:151], v[88:91]\n\t"                                     \
+        "v_mul_f32 v69, %7, v69\n\t"                                                                                  \
+        "v_mul_f32 v70, %7, v70\n\t"                                                                                  \
+        "v_mul_f32 v71, %7, v71\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[148:151], a[180:183], v[104:107]\n\t"                                 \
+        "v_mul_f32 v84, %7, v84\n\t"                                                                                  \
+        "v_mul_f32 v85, %7, v85\n\t"                                                                                  \
+        "v_mul_f32 v86, %7, v86\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[156:159], a[180:183], v[120:123]\n\t"                                 \
+        "v_mul_f32 v87, %7, v87\n\t"                                                                                  \
+        "v_exp_f32 v68, v68\n\t"                                                                                      \
+        "v_exp_f32 v69, v69\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[128:131], a[152:155], v[160:163]\n\t"                                   \
+        "v_exp_f32 v70, v70\n\t"                                                                                      \
+        "v_exp_f32 v71, v71\n\t"                                                                                      \
+        "v_exp_f32 v84, v84\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[136:139], a[152:155], v[164:167]\n\t"                                   \
+        "v_exp_f32 v85, v85\n\t"                                                                                      \
+        "v_exp_f32 v86, v86\n\t"                                                                                      \
+        "v_exp_f32 v87, v87\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[132:135], a[184:187], v[168:171]\n\t"                                 \
+        "v_mul_f32 v100, v68, v100\n\t"                                                                               \
+        "v_mul_f32 v101, v69, v101\n\t"                                                                               \
+        "v_mul_f32 v102, v70, v102\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[140:143], a[184:187], v[172:175]\n\t"                                 \
+        "v_mul_f32 v103, v71, v103\n\t"                                                                               \
+        "v_mul_f32 v116, v84, v116\n\t"                                                                               \
+        "v_mul_f32 v117, v85, v117\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[144:147], a[156:159], v[76:79]\n\t"                                     \
+        "v_mul_f32 v118, v86, v118\n\t"                                                                               \
+        "v_mul_f32 v119, v87, v119\n\t"                                                                               \
+        "v_cvt_pk_bf16_f32 v212, v68, v69\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[152:155], a[156:159], v[92:95]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v213, v70, v71\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v214, v84, v85\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v215, v86, v87\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[148:151], a[188:191], v[108:111]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v228, v100, v101\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v229, v102, v103\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v230, v116, v117\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[156:159], a[188:191], v[124:127]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v231, v118, v119\n\t"                                                                      \
+        "v_mul_f32 v72, %7, v72\n\t"                                                                                  \
+        "v_mul_f32 v73, %7, v73\n\t"                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[0:3], v[176:179], v[208:211], a[0:3]\n\t"                                         \
+        "ds_read_b128 v[160:163], %10\n\t"                                                                            \
+        "v_mul_f32 v74, %7, v74\n\t"                                                                                  \
+        "v_mul_f32 v75, %7, v75\n\t"                                                                                  \
+        "v_mul_f32 v88, %7, v88\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[64:67], v[192:195], v[224:227], a[64:67]\n\t"                                     \
+        "ds_read_b128 v[168:171], %10 offset:128\n\t"                                                                 \
+        "v_mul_f32 v89, %7, v89\n\t"                                                                                  \
+        "v_mul_f32 v90, %7, v90\n\t"                                                                                  \
+        "v_mul_f32 v91, %7, v91\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[16:19], v[180:183], v[208:211], a[16:19]\n\t"                                     \
+        "ds_read_b128 v[128:131], %8\n\t"                                                                             \
+        "v_exp_f32 v72, v72\n\t"                                                                                      \
+        "v_exp_f32 v73, v73\n\t"                                                                                      \
+        "v_exp_f32 v74, v74\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[80:83], v[196:199], v[224:227], a[80:83]\n\t"                                     \
+        "ds_read_b128 v[132:135], %8 offset:4096\n\t"                                                                 \
+        "v_exp_f32 v75, v75\n\t"                                                                                      \
+        "v_exp_f32 v88, v88\n\t"                                                                                      \
+        "v_exp_f32 v89, v89\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[32:35], v[184:187], v[208:211], a[32:35]\n\t"                                     \
+        "ds_read_b128 v[164:167], %10 offset:64\n\t"                                                                  \
+        "v_exp_f32 v90, v90\n\t"                                                                                      \
+        "v_exp_f32 v91, v91\n\t"                                                                                      \
+        "v_mul_f32 v104, v72, v104\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[96:99], v[200:203], v[224:227], a[96:99]\n\t"                                     \
+        "ds_read_b128 v[172:175], %10 offset:192\n\t"                                                                 \
+        "v_mul_f32 v105, v73, v105\n\t"                                                                               \
+        "v_mul_f32 v106, v74, v106\n\t"                                                                               \
+        "v_mul_f32 v107, v75, v107\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[48:51], v[188:191], v[208:211], a[48:51]\n\t"                                     \
+        "ds_read_b128 v[136:139], %8 offset:2048\n\t"                                                                 \
+        "v_mul_f32 v120, v88, v120\n\t"                                                                               \
+        "v_mul_f32 v121, v89, v121\n\t"                                                                               \
+        "v_mul_f32 v122, v90, v122\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[112:115], v[204:207], v[224:227], a[112:115]\n\t"                                 \
+        "ds_read_b128 v[140:143], %8 offset:6144\n\t"                                                                 \
+        "v_mul_f32 v123, v91, v123\n\t"                                                                               \
+        "v_cvt_pk_bf16_f32 v216, v72, v73\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v217, v74, v75\n\t"                                                                        \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[4:7], v[176:179], v[212:215], a[4:7]\n\t"                                         \
+        "ds_read_b128 v[144:147], %9\n\t"                                                                             \
+        "v_cvt_pk_bf16_f32 v218, v88, v89\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v219, v90, v91\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v232, v104, v105\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[68:71], v[192:195], v[228:231], a[68:71]\n\t"                                     \
+        "ds_read_b128 v[148:151], %9 offset:4096\n\t"                                                                 \
+        "v_cvt_pk_bf16_f32 v233, v106, v107\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v234, v120, v121\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v235, v122, v123\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[20:23], v[180:183], v[212:215], a[20:23]\n\t"                                     \
+        "ds_read_b128 v[152:155], %9 offset:2048\n\t"                                                                 \
+        "v_mul_f32 v76, %7, v76\n\t"                                                                                  \
+        "v_mul_f32 v77, %7, v77\n\t"                                                                                  \
+        "v_mul_f32 v78, %7, v78\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[84:87], v[196:199], v[228:231], a[84:87]\n\t"                                     \
+        "ds_read_b128 v[156:159], %9 offset:6144\n\t"                                                                 \
+        "v_mul_f32 v79, %7, v79\n\t"                                                                                  \
+        "v_mul_f32 v92, %7, v92\n\t"                                                                                  \
+        "v_mul_f32 v93, %7, v93\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[36:39], v[184:187], v[212:215], a[36:39]\n\t"                                     \
+        "v_mul_f32 v94, %7, v94\n\t"                                                                                  \
+        "v_mul_f32 v95, %7, v95\n\t"                                                                                  \
+        "v_exp_f32 v76, v76\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[100:103], v[200:203], v[228:231], a[100:103]\n\t"                                 \
+        "v_exp_f32 v77, v77\n\t"                                                                                      \
+        "v_exp_f32 v78, v78\n\t"                                                                                      \
+        "v_exp_f32 v79, v79\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[52:55], v[188:191], v[212:215], a[52:55]\n\t"                                     \
+        "v_exp_f32 v92, v92\n\t"                                                                                      \
+        "v_exp_f32 v93, v93\n\t"                                                                                      \
+        "v_exp_f32 v94, v94\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[116:119], v[204:207], v[228:231], a[116:119]\n\t"                                 \
+        "v_exp_f32 v95, v95\n\t"                                                                                      \
+        "v_mul_f32 v108, v76, v108\n\t"                                                                               \
+        "v_mul_f32 v109, v77, v109\n\t"                                                                               \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[8:11], v[176:179], v[216:219], a[8:11]\n\t"                                       \
+        "v_mul_f32 v110, v78, v110\n\t"                                                                               \
+        "v_mul_f32 v111, v79, v111\n\t"                                                                               \
+        "v_mul_f32 v124, v92, v124\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[72:75], v[192:195], v[232:235], a[72:75]\n\t"                                     \
+        "v_mul_f32 v125, v93, v125\n\t"                                                                               \
+        "v_mul_f32 v126, v94, v126\n\t"                                                                               \
+        "v_mul_f32 v127, v95, v127\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[24:27], v[180:183], v[216:219], a[24:27]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v220, v76, v77\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v221, v78, v79\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v222, v92, v93\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 a[88:91], v[196:199], v[232:235], a[88:91]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v223, v94, v95\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v236, v108, v109\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v237, v110, v111\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[40:43], v[184:187], v[216:219], a[40:43]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v238, v124, v125\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v239, v126, v127\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[104:107], v[200:203], v[232:235], a[104:107]\n\t"                                 \
+        "v_mfma_f32_16x16x32_bf16 a[56:59], v[188:191], v[216:219], a[56:59]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[120:123], v[204:207], v[232:235], a[120:123]\n\t"                                 \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[12:15], v[176:179], v[220:223], a[12:15]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[76:79], v[192:195], v[236:239], a[76:79]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[28:31], v[180:183], v[220:223], a[28:31]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[92:95], v[196:199], v[236:239], a[92:95]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[44:47], v[184:187], v[220:223], a[44:47]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[108:111], v[200:203], v[236:239], a[108:111]\n\t"                                 \
+        "v_mfma_f32_16x16x32_bf16 a[60:63], v[188:191], v[220:223], a[60:63]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[124:127], v[204:207], v[236:239], a[124:127]"                                     \
+        :                                                                                                           \
+        : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1),   \
+          "v"(NLRD)                                                                                \
         : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "memory")
 // generated by tools/gen/gen_dkdv4_body.py (register map and operand list there); 226 instructions
-#define RPO_D4_SLICE_BODY_HOT(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD) \
-    asm volatile( \
-        "s_waitcnt lgkmcnt(0)\n\t" \
-        "ds_read_b64_tr_b16 v[176:177], %3 offset:4096\n\t" \
-        "ds_read_b64_tr_b16 v[178:179], %3 offset:6144\n\t" \
-        "ds_read_b64_tr_b16 v[192:193], %3\n\t" \
-        "ds_read_b64_tr_b16 v[194:195], %3 offset:2048\n\t" \
-        "ds_read_b64_tr_b16 v[180:181], %4 offset:4096\n\t" \
-        "ds_read_b64_tr_b16 v[182:183], %4 offset:6144\n\t" \
-        "ds_read_b64_tr_b16 v[196:197], %4\n\t" \
-        "ds_read_b64_tr_b16 v[198:199], %4 offset:2048\n\t" \
-        "ds_read_b64_tr_b16 v[184:185], %5 offset:4096\n\t" \
-        "ds_read_b64_tr_b16 v[186:187], %5 offset:6144\n\t" \
-        "ds_read_b64_tr_b16 v[200:201], %5\n\t" \
-        "ds_read_b64_tr_b16 v[202:203], %5 offset:2048\n\t" \
-        "ds_read_b64_tr_b16 v[188:189], %6 offset:4096\n\t" \
-        "ds_read_b64_tr_b16 v[190:191], %6 offset:6144\n\t" \
-        "ds_read_b64_tr_b16 v[204:205], %6\n\t" \
-        "ds_read_b64_tr_b16 v[206:207], %6 offset:2048\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[64:67], v[128:131], a[128:131], v[160:163]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[80:83], v[136:139], a[128:131], v[164:167]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[96:99], v[132:135], a[160:163], v[168:171]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[112:115], v[140:143], a[160:163], v[172:175]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[64:67], v[144:147], a[132:135], v[64:67]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[80:83], v[152:155], a[132:135], v[80:83]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[96:99], v[148:151], a[164:167], v[96:99]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[112:115], v[156:159], a[164:167], v[112:115]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[68:71], v[128:131], a[136:139], v[160:163]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[84:87], v[136:139], a[136:139], v[164:167]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[100:103], v[132:135], a[168:171], v[168:171]\n\t" \
-        "v_mul_f32 v64, %7, v64\n\t" \
-        "v_mul_f32 v65, %7, v65\n\t" \
-        "v_mul_f32 v66, %7, v66\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[116:119], v[140:143], a[168:171], v[172:175]\n\t" \
-        "v_mul_f32 v67, %7, v67\n\t" \
-        "v_mul_f32 v80, %7, v80\n\t" \
-        "v_mul_f32 v81, %7, v81\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[68:71], v[144:147], a[140:143], v[68:71]\n\t" \
-        "v_mul_f32 v82, %7, v82\n\t" \
-        "v_mul_f32 v83, %7, v83\n\t" \
-        "v_exp_f32 v64, v64\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[84:87], v[152:155], a[140:143], v[84:87]\n\t" \
-        "v_exp_f32 v65, v65\n\t" \
-        "v_exp_f32 v66, v66\n\t" \
-        "v_exp_f32 v67, v67\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[100:103], v[148:151], a[172:175], v[100:103]\n\t" \
-        "v_exp_f32 v80, v80\n\t" \
-        "v_exp_f32 v81, v81\n\t" \
-        "v_exp_f32 v82, v82\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[116:119], v[156:159], a[172:175], v[116:119]\n\t" \
-        "v_exp_f32 v83, v83\n\t" \
-        "v_mul_f32 v96, v64, v96\n\t" \
-        "v_mul_f32 v97, v65, v97\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[72:75], v[128:131], a[144:147], v[160:163]\n\t" \
-        "v_mul_f32 v98, v66, v98\n\t" \
-        "v_mul_f32 v99, v67, v99\n\t" \
-        "v_mul_f32 v112, v80, v112\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[88:91], v[136:139], a[144:147], v[164:167]\n\t" \
-        "v_mul_f32 v113, v81, v113\n\t" \
-        "v_mul_f32 v114, v82, v114\n\t" \
-        "v_mul_f32 v115, v83, v115\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[104:107], v[132:135], a[176:179], v[168:171]\n\t" \
-        "v_cvt_pk_bf16_f32 v208, v64, v65\n\t" \
-        "v_cvt_pk_bf16_f32 v209, v66, v67\n\t" \
-        "v_cvt_pk_bf16_f32 v210, v80, v81\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[120:123], v[140:143], a[176:179], v[172:175]\n\t" \
-        "v_cvt_pk_bf16_f32 v211, v82, v83\n\t" \
-        "v_cvt_pk_bf16_f32 v224, v96, v97\n\t" \
-        "v_cvt_pk_bf16_f32 v225, v98, v99\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[72:75], v[144:147], a[148:151], v[72:75]\n\t" \
-        "v_cvt_pk_bf16_f32 v226, v112, v113\n\t" \
-        "v_cvt_pk_bf16_f32 v227, v114, v115\n\t" \
-        "v_mul_f32 v68, %7, v68\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[88:91], v[152:155], a[148:151], v[88:91]\n\t" \
-        "v_mul_f32 v69, %7, v69\n\t" \
-        "v_mul_f32 v70, %7, v70\n\t" \
-        "v_mul_f32 v71, %7, v71\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[104:107], v[148:151], a[180:183], v[104:107]\n\t" \
-        "v_mul_f32 v84, %7, v84\n\t" \
-        "v_mul_f32 v85, %7, v85\n\t" \
-        "v_mul_f32 v86, %7, v86\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[120:123], v[156:159], a[180:183], v[120:123]\n\t" \
-        "v_mul_f32 v87, %7, v87\n\t" \
-        "v_exp_f32 v68, v68\n\t" \
-        "v_exp_f32 v69, v69\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[76:79], v[128:131], a[152:155], v[160:163]\n\t" \
-        "v_exp_f32 v70, v70\n\t" \
-        "v_exp_f32 v71, v71\n\t" \
-        "v_exp_f32 v84, v84\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[92:95], v[136:139], a[152:155], v[164:167]\n\t" \
-        "v_exp_f32 v85, v85\n\t" \
-        "v_exp_f32 v86, v86\n\t" \
-        "v_exp_f32 v87, v87\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[108:111], v[132:135], a[184:187], v[168:171]\n\t" \
-        "v_mul_f32 v100, v68, v100\n\t" \
-        "v_mul_f32 v101, v69, v101\n\t" \
-        "v_mul_f32 v102, v70, v102\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[124:127], v[140:143], a[184:187], v[172:175]\n\t" \
-        "v_mul_f32 v103, v71, v103\n\t" \
-        "v_mul_f32 v116, v84, v116\n\t" \
-        "v_mul_f32 v117, v85, v117\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[76:79], v[144:147], a[156:159], v[76:79]\n\t" \
-        "v_mul_f32 v118, v86, v118\n\t" \
-        "v_mul_f32 v119, v87, v119\n\t" \
-        "v_cvt_pk_bf16_f32 v212, v68, v69\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[92:95], v[152:155], a[156:159], v[92:95]\n\t" \
-        "v_cvt_pk_bf16_f32 v213, v70, v71\n\t" \
-        "v_cvt_pk_bf16_f32 v214, v84, v85\n\t" \
-        "v_cvt_pk_bf16_f32 v215, v86, v87\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[108:111], v[148:151], a[188:191], v[108:111]\n\t" \
-        "v_cvt_pk_bf16_f32 v228, v100, v101\n\t" \
-        "v_cvt_pk_bf16_f32 v229, v102, v103\n\t" \
-        "v_cvt_pk_bf16_f32 v230, v116, v117\n\t" \
-        "v_mfma_f32_16x16x32_bf16 v[124:127], v[156:159], a[188:191], v[124:127]\n\t" \
-        "v_cvt_pk_bf16_f32 v231, v118, v119\n\t" \
-        "v_mul_f32 v72, %7, v72\n\t" \
-        "v_mul_f32 v73, %7, v73\n\t" \
-        "s_waitcnt lgkmcnt(0)\n\t" \
-        "ds_read_b128 v[160:163], %10\n\t" \
-        "ds_read_b128 v[168:171], %10 offset:128\n\t" \
-        "ds_read_b128 v[128:131], %8\n\t" \
-        "ds_read_b128 v[132:135], %8 offset:4096\n\t" \
-        "ds_read_b128 v[164:167], %10 offset:64\n\t" \
-        "ds_read_b128 v[172:175], %10 offset:192\n\t" \
-        "ds_read_b128 v[136:139], %8 offset:2048\n\t" \
-        "ds_read_b128 v[140:143], %8 offset:6144\n\t" \
-        "ds_read_b128 v[144:147], %9\n\t" \
-        "ds_read_b128 v[148:151], %9 offset:4096\n\t" \
-        "ds_read_b128 v[152:155], %9 offset:2048\n\t" \
-        "ds_read_b128 v[156:159], %9 offset:6144\n\t" \
-        "s_nop 1\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[0:3], v[176:179], v[208:211], a[0:3]\n\t" \
-        "v_mul_f32 v74, %7, v74\n\t" \
-        "v_mul_f32 v75, %7, v75\n\t" \
-        "v_mul_f32 v88, %7, v88\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[64:67], v[192:195], v[224:227], a[64:67]\n\t" \
-        "v_mul_f32 v89, %7, v89\n\t" \
-        "v_mul_f32 v90, %7, v90\n\t" \
-        "v_mul_f32 v91, %7, v91\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[16:19], v[180:183], v[208:211], a[16:19]\n\t" \
-        "v_exp_f32 v72, v72\n\t" \
-        "v_exp_f32 v73, v73\n\t" \
-        "v_exp_f32 v74, v74\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[80:83], v[196:199], v[224:227], a[80:83]\n\t" \
-        "v_exp_f32 v75, v75\n\t" \
-        "v_exp_f32 v88, v88\n\t" \
-        "v_exp_f32 v89, v89\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[32:35], v[184:187], v[208:211], a[32:35]\n\t" \
-        "v_exp_f32 v90, v90\n\t" \
-        "v_exp_f32 v91, v91\n\t" \
-        "v_mul_f32 v104, v72, v104\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[96:99], v[200:203], v[224:227], a[96:99]\n\t" \
-        "v_mul_f32 v105, v73, v105\n\t" \
-        "v_mul_f32 v106, v74, v106\n\t" \
-        "v_mul_f32 v107, v75, v107\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[48:51], v[188:191], v[208:211], a[48:51]\n\t" \
-        "v_mul_f32 v120, v88, v120\n\t" \
-        "v_mul_f32 v121, v89, v121\n\t" \
-        "v_mul_f32 v122, v90, v122\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[112:115], v[204:207], v[224:227], a[112:115]\n\t" \
-        "v_mul_f32 v123, v91, v123\n\t" \
-        "v_cvt_pk_bf16_f32 v216, v72, v73\n\t" \
-        "v_cvt_pk_bf16_f32 v217, v74, v75\n\t" \
-        "s_nop 1\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[4:7], v[176:179], v[212:215], a[4:7]\n\t" \
-        "v_cvt_pk_bf16_f32 v218, v88, v89\n\t" \
-        "v_cvt_pk_bf16_f32 v219, v90, v91\n\t" \
-        "v_cvt_pk_bf16_f32 v232, v104, v105\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[68:71], v[192:195], v[228:231], a[68:71]\n\t" \
-        "v_cvt_pk_bf16_f32 v233, v106, v107\n\t" \
-        "v_cvt_pk_bf16_f32 v234, v120, v121\n\t" \
-        "v_cvt_pk_bf16_f32 v235, v122, v123\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[20:23], v[180:183], v[212:215], a[20:23]\n\t" \
-        "v_mul_f32 v76, %7, v76\n\t" \
-        "v_mul_f32 v77, %7, v77\n\t" \
-        "v_mul_f32 v78, %7, v78\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[84:87], v[196:199], v[228:231], a[84:87]\n\t" \
-        "v_mul_f32 v79, %7, v79\n\t" \
-        "v_mul_f32 v92, %7, v92\n\t" \
-        "v_mul_f32 v93, %7, v93\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[36:39], v[184:187], v[212:215], a[36:39]\n\t" \
-        "v_mul_f32 v94, %7, v94\n\t" \
-        "v_mul_f32 v95, %7, v95\n\t" \
-        "v_exp_f32 v76, v76\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[100:103], v[200:203], v[228:231], a[100:103]\n\t" \
-        "v_exp_f32 v77, v77\n\t" \
-        "v_exp_f32 v78, v78\n\t" \
-        "v_exp_f32 v79, v79\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[52:55], v[188:191], v[212:215], a[52:55]\n\t" \
-        "v_exp_f32 v92, v92\n\t" \
-        "v_exp_f32 v93, v93\n\t" \
-        "v_exp_f32 v94, v94\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[116:119], v[204:207], v[228:231], a[116:119]\n\t" \
-        "v_exp_f32 v95, v95\n\t" \
-        "v_mul_f32 v108, v76, v108\n\t" \
-        "v_mul_f32 v109, v77, v109\n\t" \
-        "s_nop 1\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[8:11], v[176:179], v[216:219], a[8:11]\n\t" \
-        "v_mul_f32 v110, v78, v110\n\t" \
-        "v_mul_f32 v111, v79, v111\n\t" \
-        "v_mul_f32 v124, v92, v124\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[72:75], v[192:195], v[232:235], a[72:75]\n\t" \
-        "v_mul_f32 v125, v93, v125\n\t" \
-        "v_mul_f32 v126, v94, v126\n\t" \
-        "v_mul_f32 v127, v95, v127\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[24:27], v[180:183], v[216:219], a[24:27]\n\t" \
-        "v_cvt_pk_bf16_f32 v220, v76, v77\n\t" \
-        "v_cvt_pk_bf16_f32 v221, v78, v79\n\t" \
-        "v_cvt_pk_bf16_f32 v222, v92, v93\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[88:91], v[196:199], v[232:235], a[88:91]\n\t" \
-        "v_cvt_pk_bf16_f32 v223, v94, v95\n\t" \
-        "v_cvt_pk_bf16_f32 v236, v108, v109\n\t" \
-        "v_cvt_pk_bf16_f32 v237, v110, v111\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[40:43], v[184:187], v[216:219], a[40:43]\n\t" \
-        "v_cvt_pk_bf16_f32 v238, v124, v125\n\t" \
-        "v_cvt_pk_bf16_f32 v239, v126, v127\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[104:107], v[200:203], v[232:235], a[104:107]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[56:59], v[188:191], v[216:219], a[56:59]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[120:123], v[204:207], v[232:235], a[120:123]\n\t" \
-        "s_nop 1\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[12:15], v[176:179], v[220:223], a[12:15]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[76:79], v[192:195], v[236:239], a[76:79]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[28:31], v[180:183], v[220:223], a[28:31]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[92:95], v[196:199], v[236:239], a[92:95]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[44:47], v[184:187], v[220:223], a[44:47]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[108:111], v[200:203], v[236:239], a[108:111]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[60:63], v[188:191], v[220:223], a[60:63]\n\t" \
-        "v_mfma_f32_16x16x32_bf16 a[124:127], v[204:207], v[236:239], a[124:127]" \
-        : \
-        : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1), \
-          "v"(NLRD) \
+#define RPO_D4_SLICE_BODY_HOT(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD)                    \
+    asm volatile(                                                                                               \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[128:131], a[128:131], v[160:163]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[176:177], %3 offset:4096\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[136:139], a[128:131], v[164:167]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[178:179], %3 offset:6144\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[132:135], a[160:163], v[168:171]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[192:193], %3\n\t"                                                                       \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[140:143], a[160:163], v[172:175]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[194:195], %3 offset:2048\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[144:147], a[132:135], v[64:67]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[180:181], %4 offset:4096\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[152:155], a[132:135], v[80:83]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[182:183], %4 offset:6144\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[148:151], a[164:167], v[96:99]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[196:197], %4\n\t"                                                                       \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[156:159], a[164:167], v[112:115]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[198:199], %4 offset:2048\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[128:131], a[136:139], v[160:163]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[184:185], %5 offset:4096\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[136:139], a[136:139], v[164:167]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[186:187], %5 offset:6144\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[132:135], a[168:171], v[168:171]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[200:201], %5\n\t"                                                                       \
+        "v_mul_f32 v64, %7, v64\n\t"                                                                                  \
+        "v_mul_f32 v65, %7, v65\n\t"                                                                                  \
+        "v_mul_f32 v66, %7, v66\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[140:143], a[168:171], v[172:175]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[202:203], %5 offset:2048\n\t"                                                           \
+        "v_mul_f32 v67, %7, v67\n\t"                                                                                  \
+        "v_mul_f32 v80, %7, v80\n\t"                                                                                  \
+        "v_mul_f32 v81, %7, v81\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[144:147], a[140:143], v[68:71]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[188:189], %6 offset:4096\n\t"                                                           \
+        "v_mul_f32 v82, %7, v82\n\t"                                                                                  \
+        "v_mul_f32 v83, %7, v83\n\t"                                                                                  \
+        "v_exp_f32 v64, v64\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[152:155], a[140:143], v[84:87]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[190:191], %6 offset:6144\n\t"                                                           \
+        "v_exp_f32 v65, v65\n\t"                                                                                      \
+        "v_exp_f32 v66, v66\n\t"                                                                                      \
+        "v_exp_f32 v67, v67\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[148:151], a[172:175], v[100:103]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[204:205], %6\n\t"                                                                       \
+        "v_exp_f32 v80, v80\n\t"                                                                                      \
+        "v_exp_f32 v81, v81\n\t"                                                                                      \
+        "v_exp_f32 v82, v82\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[156:159], a[172:175], v[116:119]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[206:207], %6 offset:2048\n\t"                                                           \
+        "v_exp_f32 v83, v83\n\t"                                                                                      \
+        "v_mul_f32 v96, v64, v96\n\t"                                                                                 \
+        "v_mul_f32 v97, v65, v97\n\t"                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[128:131], a[144:147], v[160:163]\n\t"                                   \
+        "v_mul_f32 v98, v66, v98\n\t"                                                                                 \
+        "v_mul_f32 v99, v67, v99\n\t"                                                                                 \
+        "v_mul_f32 v112, v80, v112\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[136:139], a[144:147], v[164:167]\n\t"                                   \
+        "v_mul_f32 v113, v81, v113\n\t"                                                                               \
+        "v_mul_f32 v114, v82, v114\n\t"                                                                               \
+        "v_mul_f32 v115, v83, v115\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[132:135], a[176:179], v[168:171]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v208, v64, v65\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v209, v66, v67\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v210, v80, v81\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[140:143], a[176:179], v[172:175]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v211, v82, v83\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v224, v96, v97\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v225, v98, v99\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[144:147], a[148:151], v[72:75]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v226, v112, v113\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v227, v114, v115\n\t"                                                                      \
+        "v_mul_f32 v68, %7, v68\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[152:155], a[148:151], v[88:91]\n\t"                                     \
+        "v_mul_f32 v69, %7, v69\n\t"                                                                                  \
+        "v_mul_f32 v70, %7, v70\n\t"                                                                                  \
+        "v_mul_f32 v71, %7, v71\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[148:151], a[180:183], v[104:107]\n\t"                                 \
+        "v_mul_f32 v84, %7, v84\n\t"                                                                                  \
+        "v_mul_f32 v85, %7, v85\n\t"                                                                                  \
+        "v_mul_f32 v86, %7, v86\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[156:159], a[180:183], v[120:123]\n\t"                                 \
+        "v_mul_f32 v87, %7, v87\n\t"                                                                                  \
+        "v_exp_f32 v68, v68\n\t"                                                                                      \
+        "v_exp_f32 v69, v69\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[128:131], a[152:155], v[160:163]\n\t"                                   \
+        "v_exp_f32 v70, v70\n\t"                                                                                      \
+        "v_exp_f32 v71, v71\n\t"                                                                                      \
+        "v_exp_f32 v84, v84\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[136:139], a[152:155], v[164:167]\n\t"                                   \
+        "v_exp_f32 v85, v85\n\t"                                                                                      \
+        "v_exp_f32 v86, v86\n\t"                                                                                      \
+        "v_exp_f32 v87, v87\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[132:135], a[184:187], v[168:171]\n\t"                                 \
+        "v_mul_f32 v100, v68, v100\n\t"                                                                               \
+        "v_mul_f32 v101, v69, v101\n\t"                                                                               \
+        "v_mul_f32 v102, v70, v102\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[140:143], a[184:187], v[172:175]\n\t"                                 \
+        "v_mul_f32 v103, v71, v103\n\t"                                                                               \
+        "v_mul_f32 v116, v84, v116\n\t"                                                                               \
+        "v_mul_f32 v117, v85, v117\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[144:147], a[156:159], v[76:79]\n\t"                                     \
+        "v_mul_f32 v118, v86, v118\n\t"                                                                               \
+        "v_mul_f32 v119, v87, v119\n\t"                                                                               \
+        "v_cvt_pk_bf16_f32 v212, v68, v69\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[152:155], a[156:159], v[92:95]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v213, v70, v71\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v214, v84, v85\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v215, v86, v87\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[148:151], a[188:191], v[108:111]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v228, v100, v101\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v229, v102, v103\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v230, v116, v117\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[156:159], a[188:191], v[124:127]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v231, v118, v119\n\t"                                                                      \
+        "v_mul_f32 v72, %7, v72\n\t"                                                                                  \
+        "v_mul_f32 v73, %7, v73\n\t"                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[0:3], v[176:179], v[208:211], a[0:3]\n\t"                                         \
+        "ds_read_b128 v[160:163], %10\n\t"                                                                            \
+        "v_mul_f32 v74, %7, v74\n\t"                                                                                  \
+        "v_mul_f32 v75, %7, v75\n\t"                                                                                  \
+        "v_mul_f32 v88, %7, v88\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[64:67], v[192:195], v[224:227], a[64:67]\n\t"                                     \
+        "ds_read_b128 v[168:171], %10 offset:128\n\t"                                                                 \
+        "v_mul_f32 v89, %7, v89\n\t"                                                                                  \
+        "v_mul_f32 v90, %7, v90\n\t"                                                                                  \
+        "v_mul_f32 v91, %7, v91\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[16:19], v[180:183], v[208:211], a[16:19]\n\t"                                     \
+        "ds_read_b128 v[128:131], %8\n\t"                                                                             \
+        "v_exp_f32 v72, v72\n\t"                                                                                      \
+        "v_exp_f32 v73, v73\n\t"                                                                                      \
+        "v_exp_f32 v74, v74\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[80:83], v[196:199], v[224:227], a[80:83]\n\t"                                     \
+        "ds_read_b128 v[132:135], %8 offset:4096\n\t"                                                                 \
+        "v_exp_f32 v75, v75\n\t"                                                                                      \
+        "v_exp_f32 v88, v88\n\t"                                                                                      \
+        "v_exp_f32 v89, v89\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[32:35], v[184:187], v[208:211], a[32:35]\n\t"                                     \
+        "ds_read_b128 v[164:167], %10 offset:64\n\t"                                                                  \
+        "v_exp_f32 v90, v90\n\t"                                                                                      \
+        "v_exp_f32 v91, v91\n\t"                                                                                      \
+        "v_mul_f32 v104, v72, v104\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[96:99], v[200:203], v[224:227], a[96:99]\n\t"                                     \
+        "ds_read_b128 v[172:175], %10 offset:192\n\t"                                                                 \
+        "v_mul_f32 v105, v73, v105\n\t"                                                                               \
+        "v_mul_f32 v106, v74, v106\n\t"                                                                               \
+        "v_mul_f32 v107, v75, v107\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[48:51], v[188:191], v[208:211], a[48:51]\n\t"                                     \
+        "ds_read_b128 v[136:139], %8 offset:2048\n\t"                                                                 \
+        "v_mul_f32 v120, v88, v120\n\t"                                                                               \
+        "v_mul_f32 v121, v89, v121\n\t"                                                                               \
+        "v_mul_f32 v122, v90, v122\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[112:115], v[204:207], v[224:227], a[112:115]\n\t"                                 \
+        "ds_read_b128 v[140:143], %8 offset:6144\n\t"                                                                 \
+        "v_mul_f32 v123, v91, v123\n\t"                                                                               \
+        "v_cvt_pk_bf16_f32 v216, v72, v73\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v217, v74, v75\n\t"                                                                        \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[4:7], v[176:179], v[212:215], a[4:7]\n\t"                                         \
+        "ds_read_b128 v[144:147], %9\n\t"                                                                             \
+        "v_cvt_pk_bf16_f32 v218, v88, v89\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v219, v90, v91\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v232, v104, v105\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[68:71], v[192:195], v[228:231], a[68:71]\n\t"                                     \
+        "ds_read_b128 v[148:151], %9 offset:4096\n\t"                                                                 \
+        "v_cvt_pk_bf16_f32 v233, v106, v107\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v234, v120, v121\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v235, v122, v123\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[20:23], v[180:183], v[212:215], a[20:23]\n\t"                                     \
+        "ds_read_b128 v[152:155], %9 offset:2048\n\t"                                                                 \
+        "v_mul_f32 v76, %7, v76\n\t"                                                                                  \
+        "v_mul_f32 v77, %7, v77\n\t"                                                                                  \
+        "v_mul_f32 v78, %7, v78\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[84:87], v[196:199], v[228:231], a[84:87]\n\t"                                     \
+        "ds_read_b128 v[156:159], %9 offset:6144\n\t"                                                                 \
+        "v_mul_f32 v79, %7, v79\n\t"                                                                                  \
+        "v_mul_f32 v92, %7, v92\n\t"                                                                                  \
+        "v_mul_f32 v93, %7, v93\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[36:39], v[184:187], v[212:215], a[36:39]\n\t"                                     \
+        "v_mul_f32 v94, %7, v94\n\t"                                                                                  \
+        "v_mul_f32 v95, %7, v95\n\t"                                                                                  \
+        "v_exp_f32 v76, v76\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[100:103], v[200:203], v[228:231], a[100:103]\n\t"                                 \
+        "v_exp_f32 v77, v77\n\t"                                                                                      \
+        "v_exp_f32 v78, v78\n\t"                                                                                      \
+        "v_exp_f32 v79, v79\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[52:55], v[188:191], v[212:215], a[52:55]\n\t"                                     \
+        "v_exp_f32 v92, v92\n\t"                                                                                      \
+        "v_exp_f32 v93, v93\n\t"                                                                                      \
+        "v_exp_f32 v94, v94\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[116:119], v[204:207], v[228:231], a[116:119]\n\t"                                 \
+        "v_exp_f32 v95, v95\n\t"                                                                                      \
+        "v_mul_f32 v108, v76, v108\n\t"                                                                               \
+        "v_mul_f32 v109, v77, v109\n\t"                                                                               \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[8:11], v[176:179], v[216:219], a[8:11]\n\t"                                       \
+        "v_mul_f32 v110, v78, v110\n\t"                                                                               \
+        "v_mul_f32 v111, v79, v111\n\t"                                                                               \
+        "v_mul_f32 v124, v92, v124\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[72:75], v[192:195], v[232:235], a[72:75]\n\t"                                     \
+        "v_mul_f32 v125, v93, v125\n\t"                                                                               \
+        "v_mul_f32 v126, v94, v126\n\t"                                                                               \
+        "v_mul_f32 v127, v95, v127\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[24:27], v[180:183], v[216:219], a[24:27]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v220, v76, v77\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v221, v78, v79\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v222, v92, v93\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 a[88:91], v[196:199], v[232:235], a[88:91]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v223, v94, v95\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v236, v108, v109\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v237, v110, v111\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[40:43], v[184:187], v[216:219], a[40:43]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v238, v124, v125\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v239, v126, v127\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[104:107], v[200:203], v[232:235], a[104:107]\n\t"                                 \
+        "v_mfma_f32_16x16x32_bf16 a[56:59], v[188:191], v[216:219], a[56:59]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[120:123], v[204:207], v[232:235], a[120:123]\n\t"                                 \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[12:15], v[176:179], v[220:223], a[12:15]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[76:79], v[192:195], v[236:239], a[76:79]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[28:31], v[180:183], v[220:223], a[28:31]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[92:95], v[196:199], v[236:239], a[92:95]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[44:47], v[184:187], v[220:223], a[44:47]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[108:111], v[200:203], v[236:239], a[108:111]\n\t"                                 \
+        "v_mfma_f32_16x16x32_bf16 a[60:63], v[188:191], v[220:223], a[60:63]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[124:127], v[204:207], v[236:239], a[124:127]"                                     \
+        :                                                                                                           \
+        : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1),   \
+          "v"(NLRD)                                                                                \
         : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "memory")
+// generated by tools/gen/gen_dkdv4_body.py (register map and operand list there); 304 instructions
+#define RPO_D4_DIAG_BODY_LOAD(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD, DLANE)                    \
+    asm volatile(                                                                                               \
+        "ds_read_b128 v[160:163], %2\n\t"                                                                             \
+        "ds_read_b128 v[168:171], %2 offset:128\n\t"                                                                  \
+        "ds_read_b128 v[128:131], %0\n\t"                                                                             \
+        "ds_read_b128 v[132:135], %0 offset:4096\n\t"                                                                 \
+        "ds_read_b128 v[164:167], %2 offset:64\n\t"                                                                   \
+        "ds_read_b128 v[172:175], %2 offset:192\n\t"                                                                  \
+        "ds_read_b128 v[136:139], %0 offset:2048\n\t"                                                                 \
+        "ds_read_b128 v[140:143], %0 offset:6144\n\t"                                                                 \
+        "ds_read_b128 v[144:147], %1\n\t"                                                                             \
+        "ds_read_b128 v[148:151], %1 offset:4096\n\t"                                                                 \
+        "ds_read_b128 v[152:155], %1 offset:2048\n\t"                                                                 \
+        "ds_read_b128 v[156:159], %1 offset:6144\n\t"                                                                 \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "v_mov_b32 v239, 0xf149f2ca\n\t"                                                                              \
+        "v_cmp_ge_i32 vcc, 0, %11\n\t"                                                                                \
+        "v_cndmask_b32 v64, v239, v160, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 1, %11\n\t"                                                                                \
+        "v_cndmask_b32 v65, v239, v161, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 2, %11\n\t"                                                                                \
+        "v_cndmask_b32 v66, v239, v162, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 3, %11\n\t"                                                                                \
+        "v_cndmask_b32 v67, v239, v163, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 16, %11\n\t"                                                                               \
+        "v_cndmask_b32 v80, v239, v164, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 17, %11\n\t"                                                                               \
+        "v_cndmask_b32 v81, v239, v165, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 18, %11\n\t"                                                                               \
+        "v_cndmask_b32 v82, v239, v166, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 19, %11\n\t"                                                                               \
+        "v_cndmask_b32 v83, v239, v167, vcc\n\t"                                                                      \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[128:131], a[128:131], v[64:67]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[176:177], %3 offset:4096\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -16, %11\n\t"                                                                              \
+        "v_cndmask_b32 v68, v239, v160, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -15, %11\n\t"                                                                              \
+        "v_cndmask_b32 v69, v239, v161, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[136:139], a[128:131], v[80:83]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[178:179], %3 offset:6144\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -14, %11\n\t"                                                                              \
+        "v_cndmask_b32 v70, v239, v162, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -13, %11\n\t"                                                                              \
+        "v_cndmask_b32 v71, v239, v163, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[132:135], a[160:163], v[168:171]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[192:193], %3\n\t"                                                                       \
+        "v_cmp_ge_i32 vcc, 0, %11\n\t"                                                                                \
+        "v_cndmask_b32 v84, v239, v164, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 1, %11\n\t"                                                                                \
+        "v_cndmask_b32 v85, v239, v165, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[140:143], a[160:163], v[172:175]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[194:195], %3 offset:2048\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, 2, %11\n\t"                                                                                \
+        "v_cndmask_b32 v86, v239, v166, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 3, %11\n\t"                                                                                \
+        "v_cndmask_b32 v87, v239, v167, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[144:147], a[132:135], v[64:67]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[180:181], %4 offset:4096\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[152:155], a[132:135], v[80:83]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[182:183], %4 offset:6144\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[148:151], a[164:167], v[96:99]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[196:197], %4\n\t"                                                                       \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[156:159], a[164:167], v[112:115]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[198:199], %4 offset:2048\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[128:131], a[136:139], v[68:71]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[184:185], %5 offset:4096\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -32, %11\n\t"                                                                              \
+        "v_cndmask_b32 v72, v239, v160, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -31, %11\n\t"                                                                              \
+        "v_cndmask_b32 v73, v239, v161, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[136:139], a[136:139], v[84:87]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[186:187], %5 offset:6144\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -30, %11\n\t"                                                                              \
+        "v_cndmask_b32 v74, v239, v162, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -29, %11\n\t"                                                                              \
+        "v_cndmask_b32 v75, v239, v163, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[132:135], a[168:171], v[168:171]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[200:201], %5\n\t"                                                                       \
+        "v_cmp_ge_i32 vcc, -16, %11\n\t"                                                                              \
+        "v_cndmask_b32 v88, v239, v164, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -15, %11\n\t"                                                                              \
+        "v_cndmask_b32 v89, v239, v165, vcc\n\t"                                                                      \
+        "v_mul_f32 v64, %7, v64\n\t"                                                                                  \
+        "v_mul_f32 v65, %7, v65\n\t"                                                                                  \
+        "v_mul_f32 v66, %7, v66\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[140:143], a[168:171], v[172:175]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[202:203], %5 offset:2048\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -14, %11\n\t"                                                                              \
+        "v_cndmask_b32 v90, v239, v166, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -13, %11\n\t"                                                                              \
+        "v_cndmask_b32 v91, v239, v167, vcc\n\t"                                                                      \
+        "v_mul_f32 v67, %7, v67\n\t"                                                                                  \
+        "v_mul_f32 v80, %7, v80\n\t"                                                                                  \
+        "v_mul_f32 v81, %7, v81\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[144:147], a[140:143], v[68:71]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[188:189], %6 offset:4096\n\t"                                                           \
+        "v_mul_f32 v82, %7, v82\n\t"                                                                                  \
+        "v_mul_f32 v83, %7, v83\n\t"                                                                                  \
+        "v_exp_f32 v64, v64\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[152:155], a[140:143], v[84:87]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[190:191], %6 offset:6144\n\t"                                                           \
+        "v_exp_f32 v65, v65\n\t"                                                                                      \
+        "v_exp_f32 v66, v66\n\t"                                                                                      \
+        "v_exp_f32 v67, v67\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[148:151], a[172:175], v[100:103]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[204:205], %6\n\t"                                                                       \
+        "v_exp_f32 v80, v80\n\t"                                                                                      \
+        "v_exp_f32 v81, v81\n\t"                                                                                      \
+        "v_exp_f32 v82, v82\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[156:159], a[172:175], v[116:119]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[206:207], %6 offset:2048\n\t"                                                           \
+        "v_exp_f32 v83, v83\n\t"                                                                                      \
+        "v_mul_f32 v96, v64, v96\n\t"                                                                                 \
+        "v_mul_f32 v97, v65, v97\n\t"                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[128:131], a[144:147], v[72:75]\n\t"                                     \
+        "v_cmp_ge_i32 vcc, -48, %11\n\t"                                                                              \
+        "v_cndmask_b32 v76, v239, v160, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -47, %11\n\t"                                                                              \
+        "v_cndmask_b32 v77, v239, v161, vcc\n\t"                                                                      \
+        "v_mul_f32 v98, v66, v98\n\t"                                                                                 \
+        "v_mul_f32 v99, v67, v99\n\t"                                                                                 \
+        "v_mul_f32 v112, v80, v112\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[136:139], a[144:147], v[88:91]\n\t"                                     \
+        "v_cmp_ge_i32 vcc, -46, %11\n\t"                                                                              \
+        "v_cndmask_b32 v78, v239, v162, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -45, %11\n\t"                                                                              \
+        "v_cndmask_b32 v79, v239, v163, vcc\n\t"                                                                      \
+        "v_mul_f32 v113, v81, v113\n\t"                                                                               \
+        "v_mul_f32 v114, v82, v114\n\t"                                                                               \
+        "v_mul_f32 v115, v83, v115\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[132:135], a[176:179], v[168:171]\n\t"                                 \
+        "v_cmp_ge_i32 vcc, -32, %11\n\t"                                                                              \
+        "v_cndmask_b32 v92, v239, v164, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -31, %11\n\t"                                                                              \
+        "v_cndmask_b32 v93, v239, v165, vcc\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v208, v64, v65\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v209, v66, v67\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v210, v80, v81\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[140:143], a[176:179], v[172:175]\n\t"                                 \
+        "v_cmp_ge_i32 vcc, -30, %11\n\t"                                                                              \
+        "v_cndmask_b32 v94, v239, v166, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -29, %11\n\t"                                                                              \
+        "v_cndmask_b32 v95, v239, v167, vcc\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v211, v82, v83\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v224, v96, v97\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v225, v98, v99\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[144:147], a[148:151], v[72:75]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v226, v112, v113\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v227, v114, v115\n\t"                                                                      \
+        "v_mul_f32 v68, %7, v68\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[152:155], a[148:151], v[88:91]\n\t"                                     \
+        "v_mul_f32 v69, %7, v69\n\t"                                                                                  \
+        "v_mul_f32 v70, %7, v70\n\t"                                                                                  \
+        "v_mul_f32 v71, %7, v71\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[148:151], a[180:183], v[104:107]\n\t"                                 \
+        "v_mul_f32 v84, %7, v84\n\t"                                                                                  \
+        "v_mul_f32 v85, %7, v85\n\t"                                                                                  \
+        "v_mul_f32 v86, %7, v86\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[156:159], a[180:183], v[120:123]\n\t"                                 \
+        "v_mul_f32 v87, %7, v87\n\t"                                                                                  \
+        "v_exp_f32 v68, v68\n\t"                                                                                      \
+        "v_exp_f32 v69, v69\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[128:131], a[152:155], v[76:79]\n\t"                                     \
+        "v_exp_f32 v70, v70\n\t"                                                                                      \
+        "v_exp_f32 v71, v71\n\t"                                                                                      \
+        "v_exp_f32 v84, v84\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[136:139], a[152:155], v[92:95]\n\t"                                     \
+        "v_exp_f32 v85, v85\n\t"                                                                                      \
+        "v_exp_f32 v86, v86\n\t"                                                                                      \
+        "v_exp_f32 v87, v87\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[132:135], a[184:187], v[168:171]\n\t"                                 \
+        "v_mul_f32 v100, v68, v100\n\t"                                                                               \
+        "v_mul_f32 v101, v69, v101\n\t"                                                                               \
+        "v_mul_f32 v102, v70, v102\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[140:143], a[184:187], v[172:175]\n\t"                                 \
+        "v_mul_f32 v103, v71, v103\n\t"                                                                               \
+        "v_mul_f32 v116, v84, v116\n\t"                                                                               \
+        "v_mul_f32 v117, v85, v117\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[144:147], a[156:159], v[76:79]\n\t"                                     \
+        "v_mul_f32 v118, v86, v118\n\t"                                                                               \
+        "v_mul_f32 v119, v87, v119\n\t"                                                                               \
+        "v_cvt_pk_bf16_f32 v212, v68, v69\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[152:155], a[156:159], v[92:95]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v213, v70, v71\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v214, v84, v85\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v215, v86, v87\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[148:151], a[188:191], v[108:111]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v228, v100, v101\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v229, v102, v103\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v230, v116, v117\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[156:159], a[188:191], v[124:127]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v231, v118, v119\n\t"                                                                      \
+        "v_mul_f32 v72, %7, v72\n\t"                                                                                  \
+        "v_mul_f32 v73, %7, v73\n\t"                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[0:3], v[176:179], v[208:211], a[0:3]\n\t"                                         \
+        "ds_read_b128 v[160:163], %10\n\t"                                                                            \
+        "v_mul_f32 v74, %7, v74\n\t"                                                                                  \
+        "v_mul_f32 v75, %7, v75\n\t"                                                                                  \
+        "v_mul_f32 v88, %7, v88\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[64:67], v[192:195], v[224:227], a[64:67]\n\t"                                     \
+        "ds_read_b128 v[168:171], %10 offset:128\n\t"                                                                 \
+        "v_mul_f32 v89, %7, v89\n\t"                                                                                  \
+        "v_mul_f32 v90, %7, v90\n\t"                                                                                  \
+        "v_mul_f32 v91, %7, v91\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[16:19], v[180:183], v[208:211], a[16:19]\n\t"                                     \
+        "ds_read_b128 v[128:131], %8\n\t"                                                                             \
+        "v_exp_f32 v72, v72\n\t"                                                                                      \
+        "v_exp_f32 v73, v73\n\t"                                                                                      \
+        "v_exp_f32 v74, v74\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[80:83], v[196:199], v[224:227], a[80:83]\n\t"                                     \
+        "ds_read_b128 v[132:135], %8 offset:4096\n\t"                                                                 \
+        "v_exp_f32 v75, v75\n\t"                                                                                      \
+        "v_exp_f32 v88, v88\n\t"                                                                                      \
+        "v_exp_f32 v89, v89\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[32:35], v[184:187], v[208:211], a[32:35]\n\t"                                     \
+        "ds_read_b128 v[164:167], %10 offset:64\n\t"                                                                  \
+        "v_exp_f32 v90, v90\n\t"                                                                                      \
+        "v_exp_f32 v91, v91\n\t"                                                                                      \
+        "v_mul_f32 v104, v72, v104\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[96:99], v[200:203], v[224:227], a[96:99]\n\t"                                     \
+        "ds_read_b128 v[172:175], %10 offset:192\n\t"                                                                 \
+        "v_mul_f32 v105, v73, v105\n\t"                                                                               \
+        "v_mul_f32 v106, v74, v106\n\t"                                                                               \
+        "v_mul_f32 v107, v75, v107\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[48:51], v[188:191], v[208:211], a[48:51]\n\t"                                     \
+        "ds_read_b128 v[136:139], %8 offset:2048\n\t"                                                                 \
+        "v_mul_f32 v120, v88, v120\n\t"                                                                               \
+        "v_mul_f32 v121, v89, v121\n\t"                                                                               \
+        "v_mul_f32 v122, v90, v122\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[112:115], v[204:207], v[224:227], a[112:115]\n\t"                                 \
+        "ds_read_b128 v[140:143], %8 offset:6144\n\t"                                                                 \
+        "v_mul_f32 v123, v91, v123\n\t"                                                                               \
+        "v_cvt_pk_bf16_f32 v216, v72, v73\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v217, v74, v75\n\t"                                                                        \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[4:7], v[176:179], v[212:215], a[4:7]\n\t"                                         \
+        "ds_read_b128 v[144:147], %9\n\t"                                                                             \
+        "v_cvt_pk_bf16_f32 v218, v88, v89\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v219, v90, v91\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v232, v104, v105\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[68:71], v[192:195], v[228:231], a[68:71]\n\t"                                     \
+        "ds_read_b128 v[148:151], %9 offset:4096\n\t"                                                                 \
+        "v_cvt_pk_bf16_f32 v233, v106, v107\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v234, v120, v121\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v235, v122, v123\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[20:23], v[180:183], v[212:215], a[20:23]\n\t"                                     \
+        "ds_read_b128 v[152:155], %9 offset:2048\n\t"                                                                 \
+        "v_mul_f32 v76, %7, v76\n\t"                                                                                  \
+        "v_mul_f32 v77, %7, v77\n\t"                                                                                  \
+        "v_mul_f32 v78, %7, v78\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[84:87], v[196:199], v[228:231], a[84:87]\n\t"                                     \
+        "ds_read_b128 v[156:159], %9 offset:6144\n\t"                                                                 \
+        "v_mul_f32 v79, %7, v79\n\t"                                                                                  \
+        "v_mul_f32 v92, %7, v92\n\t"                                                                                  \
+        "v_mul_f32 v93, %7, v93\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[36:39], v[184:187], v[212:215], a[36:39]\n\t"                                     \
+        "v_mul_f32 v94, %7, v94\n\t"                                                                                  \
+        "v_mul_f32 v95, %7, v95\n\t"                                                                                  \
+        "v_exp_f32 v76, v76\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[100:103], v[200:203], v[228:231], a[100:103]\n\t"                                 \
+        "v_exp_f32 v77, v77\n\t"                                                                                      \
+        "v_exp_f32 v78, v78\n\t"                                                                                      \
+        "v_exp_f32 v79, v79\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[52:55], v[188:191], v[212:215], a[52:55]\n\t"                                     \
+        "v_exp_f32 v92, v92\n\t"                                                                                      \
+        "v_exp_f32 v93, v93\n\t"                                                                                      \
+        "v_exp_f32 v94, v94\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[116:119], v[204:207], v[228:231], a[116:119]\n\t"                                 \
+        "v_exp_f32 v95, v95\n\t"                                                                                      \
+        "v_mul_f32 v108, v76, v108\n\t"                                                                               \
+        "v_mul_f32 v109, v77, v109\n\t"                                                                               \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[8:11], v[176:179], v[216:219], a[8:11]\n\t"                                       \
+        "v_mul_f32 v110, v78, v110\n\t"                                                                               \
+        "v_mul_f32 v111, v79, v111\n\t"                                                                               \
+        "v_mul_f32 v124, v92, v124\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[72:75], v[192:195], v[232:235], a[72:75]\n\t"                                     \
+        "v_mul_f32 v125, v93, v125\n\t"                                                                               \
+        "v_mul_f32 v126, v94, v126\n\t"                                                                               \
+        "v_mul_f32 v127, v95, v127\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[24:27], v[180:183], v[216:219], a[24:27]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v220, v76, v77\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v221, v78, v79\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v222, v92, v93\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 a[88:91], v[196:199], v[232:235], a[88:91]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v223, v94, v95\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v236, v108, v109\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v237, v110, v111\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[40:43], v[184:187], v[216:219], a[40:43]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v238, v124, v125\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v239, v126, v127\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[104:107], v[200:203], v[232:235], a[104:107]\n\t"                                 \
+        "v_mfma_f32_16x16x32_bf16 a[56:59], v[188:191], v[216:219], a[56:59]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[120:123], v[204:207], v[232:235], a[120:123]\n\t"                                 \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[12:15], v[176:179], v[220:223], a[12:15]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[76:79], v[192:195], v[236:239], a[76:79]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[28:31], v[180:183], v[220:223], a[28:31]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[92:95], v[196:199], v[236:239], a[92:95]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[44:47], v[184:187], v[220:223], a[44:47]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[108:111], v[200:203], v[236:239], a[108:111]\n\t"                                 \
+        "v_mfma_f32_16x16x32_bf16 a[60:63], v[188:191], v[220:223], a[60:63]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[124:127], v[204:207], v[236:239], a[124:127]"                                     \
+        :                                                                                                           \
+        : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1),   \
+          "v"(NLRD), "v"(DLANE)                                                                                \
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "vcc", "memory")
+// generated by tools/gen/gen_dkdv4_body.py (register map and operand list there); 292 instructions
+#define RPO_D4_DIAG_BODY_HOT(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD, DLANE)                    \
+    asm volatile(                                                                                               \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "v_mov_b32 v239, 0xf149f2ca\n\t"                                                                              \
+        "v_cmp_ge_i32 vcc, 0, %11\n\t"                                                                                \
+        "v_cndmask_b32 v64, v239, v160, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 1, %11\n\t"                                                                                \
+        "v_cndmask_b32 v65, v239, v161, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 2, %11\n\t"                                                                                \
+        "v_cndmask_b32 v66, v239, v162, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 3, %11\n\t"                                                                                \
+        "v_cndmask_b32 v67, v239, v163, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 16, %11\n\t"                                                                               \
+        "v_cndmask_b32 v80, v239, v164, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 17, %11\n\t"                                                                               \
+        "v_cndmask_b32 v81, v239, v165, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 18, %11\n\t"                                                                               \
+        "v_cndmask_b32 v82, v239, v166, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 19, %11\n\t"                                                                               \
+        "v_cndmask_b32 v83, v239, v167, vcc\n\t"                                                                      \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[128:131], a[128:131], v[64:67]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[176:177], %3 offset:4096\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -16, %11\n\t"                                                                              \
+        "v_cndmask_b32 v68, v239, v160, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -15, %11\n\t"                                                                              \
+        "v_cndmask_b32 v69, v239, v161, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[136:139], a[128:131], v[80:83]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[178:179], %3 offset:6144\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -14, %11\n\t"                                                                              \
+        "v_cndmask_b32 v70, v239, v162, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -13, %11\n\t"                                                                              \
+        "v_cndmask_b32 v71, v239, v163, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[132:135], a[160:163], v[168:171]\n\t"                                   \
+        "ds_read_b64_tr_b16 v[192:193], %3\n\t"                                                                       \
+        "v_cmp_ge_i32 vcc, 0, %11\n\t"                                                                                \
+        "v_cndmask_b32 v84, v239, v164, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 1, %11\n\t"                                                                                \
+        "v_cndmask_b32 v85, v239, v165, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[140:143], a[160:163], v[172:175]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[194:195], %3 offset:2048\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, 2, %11\n\t"                                                                                \
+        "v_cndmask_b32 v86, v239, v166, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, 3, %11\n\t"                                                                                \
+        "v_cndmask_b32 v87, v239, v167, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[64:67], v[144:147], a[132:135], v[64:67]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[180:181], %4 offset:4096\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[80:83], v[152:155], a[132:135], v[80:83]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[182:183], %4 offset:6144\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[96:99], v[148:151], a[164:167], v[96:99]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[196:197], %4\n\t"                                                                       \
+        "v_mfma_f32_16x16x32_bf16 v[112:115], v[156:159], a[164:167], v[112:115]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[198:199], %4 offset:2048\n\t"                                                           \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[128:131], a[136:139], v[68:71]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[184:185], %5 offset:4096\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -32, %11\n\t"                                                                              \
+        "v_cndmask_b32 v72, v239, v160, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -31, %11\n\t"                                                                              \
+        "v_cndmask_b32 v73, v239, v161, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[136:139], a[136:139], v[84:87]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[186:187], %5 offset:6144\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -30, %11\n\t"                                                                              \
+        "v_cndmask_b32 v74, v239, v162, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -29, %11\n\t"                                                                              \
+        "v_cndmask_b32 v75, v239, v163, vcc\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[132:135], a[168:171], v[168:171]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[200:201], %5\n\t"                                                                       \
+        "v_cmp_ge_i32 vcc, -16, %11\n\t"                                                                              \
+        "v_cndmask_b32 v88, v239, v164, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -15, %11\n\t"                                                                              \
+        "v_cndmask_b32 v89, v239, v165, vcc\n\t"                                                                      \
+        "v_mul_f32 v64, %7, v64\n\t"                                                                                  \
+        "v_mul_f32 v65, %7, v65\n\t"                                                                                  \
+        "v_mul_f32 v66, %7, v66\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[140:143], a[168:171], v[172:175]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[202:203], %5 offset:2048\n\t"                                                           \
+        "v_cmp_ge_i32 vcc, -14, %11\n\t"                                                                              \
+        "v_cndmask_b32 v90, v239, v166, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -13, %11\n\t"                                                                              \
+        "v_cndmask_b32 v91, v239, v167, vcc\n\t"                                                                      \
+        "v_mul_f32 v67, %7, v67\n\t"                                                                                  \
+        "v_mul_f32 v80, %7, v80\n\t"                                                                                  \
+        "v_mul_f32 v81, %7, v81\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[68:71], v[144:147], a[140:143], v[68:71]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[188:189], %6 offset:4096\n\t"                                                           \
+        "v_mul_f32 v82, %7, v82\n\t"                                                                                  \
+        "v_mul_f32 v83, %7, v83\n\t"                                                                                  \
+        "v_exp_f32 v64, v64\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[84:87], v[152:155], a[140:143], v[84:87]\n\t"                                     \
+        "ds_read_b64_tr_b16 v[190:191], %6 offset:6144\n\t"                                                           \
+        "v_exp_f32 v65, v65\n\t"                                                                                      \
+        "v_exp_f32 v66, v66\n\t"                                                                                      \
+        "v_exp_f32 v67, v67\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[100:103], v[148:151], a[172:175], v[100:103]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[204:205], %6\n\t"                                                                       \
+        "v_exp_f32 v80, v80\n\t"                                                                                      \
+        "v_exp_f32 v81, v81\n\t"                                                                                      \
+        "v_exp_f32 v82, v82\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[116:119], v[156:159], a[172:175], v[116:119]\n\t"                                 \
+        "ds_read_b64_tr_b16 v[206:207], %6 offset:2048\n\t"                                                           \
+        "v_exp_f32 v83, v83\n\t"                                                                                      \
+        "v_mul_f32 v96, v64, v96\n\t"                                                                                 \
+        "v_mul_f32 v97, v65, v97\n\t"                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[128:131], a[144:147], v[72:75]\n\t"                                     \
+        "v_cmp_ge_i32 vcc, -48, %11\n\t"                                                                              \
+        "v_cndmask_b32 v76, v239, v160, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -47, %11\n\t"                                                                              \
+        "v_cndmask_b32 v77, v239, v161, vcc\n\t"                                                                      \
+        "v_mul_f32 v98, v66, v98\n\t"                                                                                 \
+        "v_mul_f32 v99, v67, v99\n\t"                                                                                 \
+        "v_mul_f32 v112, v80, v112\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[136:139], a[144:147], v[88:91]\n\t"                                     \
+        "v_cmp_ge_i32 vcc, -46, %11\n\t"                                                                              \
+        "v_cndmask_b32 v78, v239, v162, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -45, %11\n\t"                                                                              \
+        "v_cndmask_b32 v79, v239, v163, vcc\n\t"                                                                      \
+        "v_mul_f32 v113, v81, v113\n\t"                                                                               \
+        "v_mul_f32 v114, v82, v114\n\t"                                                                               \
+        "v_mul_f32 v115, v83, v115\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[132:135], a[176:179], v[168:171]\n\t"                                 \
+        "v_cmp_ge_i32 vcc, -32, %11\n\t"                                                                              \
+        "v_cndmask_b32 v92, v239, v164, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -31, %11\n\t"                                                                              \
+        "v_cndmask_b32 v93, v239, v165, vcc\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v208, v64, v65\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v209, v66, v67\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v210, v80, v81\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[140:143], a[176:179], v[172:175]\n\t"                                 \
+        "v_cmp_ge_i32 vcc, -30, %11\n\t"                                                                              \
+        "v_cndmask_b32 v94, v239, v166, vcc\n\t"                                                                      \
+        "v_cmp_ge_i32 vcc, -29, %11\n\t"                                                                              \
+        "v_cndmask_b32 v95, v239, v167, vcc\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v211, v82, v83\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v224, v96, v97\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v225, v98, v99\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[72:75], v[144:147], a[148:151], v[72:75]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v226, v112, v113\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v227, v114, v115\n\t"                                                                      \
+        "v_mul_f32 v68, %7, v68\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[88:91], v[152:155], a[148:151], v[88:91]\n\t"                                     \
+        "v_mul_f32 v69, %7, v69\n\t"                                                                                  \
+        "v_mul_f32 v70, %7, v70\n\t"                                                                                  \
+        "v_mul_f32 v71, %7, v71\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[104:107], v[148:151], a[180:183], v[104:107]\n\t"                                 \
+        "v_mul_f32 v84, %7, v84\n\t"                                                                                  \
+        "v_mul_f32 v85, %7, v85\n\t"                                                                                  \
+        "v_mul_f32 v86, %7, v86\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 v[120:123], v[156:159], a[180:183], v[120:123]\n\t"                                 \
+        "v_mul_f32 v87, %7, v87\n\t"                                                                                  \
+        "v_exp_f32 v68, v68\n\t"                                                                                      \
+        "v_exp_f32 v69, v69\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[128:131], a[152:155], v[76:79]\n\t"                                     \
+        "v_exp_f32 v70, v70\n\t"                                                                                      \
+        "v_exp_f32 v71, v71\n\t"                                                                                      \
+        "v_exp_f32 v84, v84\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[136:139], a[152:155], v[92:95]\n\t"                                     \
+        "v_exp_f32 v85, v85\n\t"                                                                                      \
+        "v_exp_f32 v86, v86\n\t"                                                                                      \
+        "v_exp_f32 v87, v87\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[132:135], a[184:187], v[168:171]\n\t"                                 \
+        "v_mul_f32 v100, v68, v100\n\t"                                                                               \
+        "v_mul_f32 v101, v69, v101\n\t"                                                                               \
+        "v_mul_f32 v102, v70, v102\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[140:143], a[184:187], v[172:175]\n\t"                                 \
+        "v_mul_f32 v103, v71, v103\n\t"                                                                               \
+        "v_mul_f32 v116, v84, v116\n\t"                                                                               \
+        "v_mul_f32 v117, v85, v117\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 v[76:79], v[144:147], a[156:159], v[76:79]\n\t"                                     \
+        "v_mul_f32 v118, v86, v118\n\t"                                                                               \
+        "v_mul_f32 v119, v87, v119\n\t"                                                                               \
+        "v_cvt_pk_bf16_f32 v212, v68, v69\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[92:95], v[152:155], a[156:159], v[92:95]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v213, v70, v71\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v214, v84, v85\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v215, v86, v87\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 v[108:111], v[148:151], a[188:191], v[108:111]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v228, v100, v101\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v229, v102, v103\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v230, v116, v117\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 v[124:127], v[156:159], a[188:191], v[124:127]\n\t"                                 \
+        "v_cvt_pk_bf16_f32 v231, v118, v119\n\t"                                                                      \
+        "v_mul_f32 v72, %7, v72\n\t"                                                                                  \
+        "v_mul_f32 v73, %7, v73\n\t"                                                                                  \
+        "s_waitcnt lgkmcnt(0)\n\t"                                                                                    \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[0:3], v[176:179], v[208:211], a[0:3]\n\t"                                         \
+        "ds_read_b128 v[160:163], %10\n\t"                                                                            \
+        "v_mul_f32 v74, %7, v74\n\t"                                                                                  \
+        "v_mul_f32 v75, %7, v75\n\t"                                                                                  \
+        "v_mul_f32 v88, %7, v88\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[64:67], v[192:195], v[224:227], a[64:67]\n\t"                                     \
+        "ds_read_b128 v[168:171], %10 offset:128\n\t"                                                                 \
+        "v_mul_f32 v89, %7, v89\n\t"                                                                                  \
+        "v_mul_f32 v90, %7, v90\n\t"                                                                                  \
+        "v_mul_f32 v91, %7, v91\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[16:19], v[180:183], v[208:211], a[16:19]\n\t"                                     \
+        "ds_read_b128 v[128:131], %8\n\t"                                                                             \
+        "v_exp_f32 v72, v72\n\t"                                                                                      \
+        "v_exp_f32 v73, v73\n\t"                                                                                      \
+        "v_exp_f32 v74, v74\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[80:83], v[196:199], v[224:227], a[80:83]\n\t"                                     \
+        "ds_read_b128 v[132:135], %8 offset:4096\n\t"                                                                 \
+        "v_exp_f32 v75, v75\n\t"                                                                                      \
+        "v_exp_f32 v88, v88\n\t"                                                                                      \
+        "v_exp_f32 v89, v89\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[32:35], v[184:187], v[208:211], a[32:35]\n\t"                                     \
+        "ds_read_b128 v[164:167], %10 offset:64\n\t"                                                                  \
+        "v_exp_f32 v90, v90\n\t"                                                                                      \
+        "v_exp_f32 v91, v91\n\t"                                                                                      \
+        "v_mul_f32 v104, v72, v104\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[96:99], v[200:203], v[224:227], a[96:99]\n\t"                                     \
+        "ds_read_b128 v[172:175], %10 offset:192\n\t"                                                                 \
+        "v_mul_f32 v105, v73, v105\n\t"                                                                               \
+        "v_mul_f32 v106, v74, v106\n\t"                                                                               \
+        "v_mul_f32 v107, v75, v107\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[48:51], v[188:191], v[208:211], a[48:51]\n\t"                                     \
+        "ds_read_b128 v[136:139], %8 offset:2048\n\t"                                                                 \
+        "v_mul_f32 v120, v88, v120\n\t"                                                                               \
+        "v_mul_f32 v121, v89, v121\n\t"                                                                               \
+        "v_mul_f32 v122, v90, v122\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[112:115], v[204:207], v[224:227], a[112:115]\n\t"                                 \
+        "ds_read_b128 v[140:143], %8 offset:6144\n\t"                                                                 \
+        "v_mul_f32 v123, v91, v123\n\t"                                                                               \
+        "v_cvt_pk_bf16_f32 v216, v72, v73\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v217, v74, v75\n\t"                                                                        \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[4:7], v[176:179], v[212:215], a[4:7]\n\t"                                         \
+        "ds_read_b128 v[144:147], %9\n\t"                                                                             \
+        "v_cvt_pk_bf16_f32 v218, v88, v89\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v219, v90, v91\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v232, v104, v105\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[68:71], v[192:195], v[228:231], a[68:71]\n\t"                                     \
+        "ds_read_b128 v[148:151], %9 offset:4096\n\t"                                                                 \
+        "v_cvt_pk_bf16_f32 v233, v106, v107\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v234, v120, v121\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v235, v122, v123\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[20:23], v[180:183], v[212:215], a[20:23]\n\t"                                     \
+        "ds_read_b128 v[152:155], %9 offset:2048\n\t"                                                                 \
+        "v_mul_f32 v76, %7, v76\n\t"                                                                                  \
+        "v_mul_f32 v77, %7, v77\n\t"                                                                                  \
+        "v_mul_f32 v78, %7, v78\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[84:87], v[196:199], v[228:231], a[84:87]\n\t"                                     \
+        "ds_read_b128 v[156:159], %9 offset:6144\n\t"                                                                 \
+        "v_mul_f32 v79, %7, v79\n\t"                                                                                  \
+        "v_mul_f32 v92, %7, v92\n\t"                                                                                  \
+        "v_mul_f32 v93, %7, v93\n\t"                                                                                  \
+        "v_mfma_f32_16x16x32_bf16 a[36:39], v[184:187], v[212:215], a[36:39]\n\t"                                     \
+        "v_mul_f32 v94, %7, v94\n\t"                                                                                  \
+        "v_mul_f32 v95, %7, v95\n\t"                                                                                  \
+        "v_exp_f32 v76, v76\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[100:103], v[200:203], v[228:231], a[100:103]\n\t"                                 \
+        "v_exp_f32 v77, v77\n\t"                                                                                      \
+        "v_exp_f32 v78, v78\n\t"                                                                                      \
+        "v_exp_f32 v79, v79\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[52:55], v[188:191], v[212:215], a[52:55]\n\t"                                     \
+        "v_exp_f32 v92, v92\n\t"                                                                                      \
+        "v_exp_f32 v93, v93\n\t"                                                                                      \
+        "v_exp_f32 v94, v94\n\t"                                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[116:119], v[204:207], v[228:231], a[116:119]\n\t"                                 \
+        "v_exp_f32 v95, v95\n\t"                                                                                      \
+        "v_mul_f32 v108, v76, v108\n\t"                                                                               \
+        "v_mul_f32 v109, v77, v109\n\t"                                                                               \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[8:11], v[176:179], v[216:219], a[8:11]\n\t"                                       \
+        "v_mul_f32 v110, v78, v110\n\t"                                                                               \
+        "v_mul_f32 v111, v79, v111\n\t"                                                                               \
+        "v_mul_f32 v124, v92, v124\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[72:75], v[192:195], v[232:235], a[72:75]\n\t"                                     \
+        "v_mul_f32 v125, v93, v125\n\t"                                                                               \
+        "v_mul_f32 v126, v94, v126\n\t"                                                                               \
+        "v_mul_f32 v127, v95, v127\n\t"                                                                               \
+        "v_mfma_f32_16x16x32_bf16 a[24:27], v[180:183], v[216:219], a[24:27]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v220, v76, v77\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v221, v78, v79\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v222, v92, v93\n\t"                                                                        \
+        "v_mfma_f32_16x16x32_bf16 a[88:91], v[196:199], v[232:235], a[88:91]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v223, v94, v95\n\t"                                                                        \
+        "v_cvt_pk_bf16_f32 v236, v108, v109\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v237, v110, v111\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[40:43], v[184:187], v[216:219], a[40:43]\n\t"                                     \
+        "v_cvt_pk_bf16_f32 v238, v124, v125\n\t"                                                                      \
+        "v_cvt_pk_bf16_f32 v239, v126, v127\n\t"                                                                      \
+        "v_mfma_f32_16x16x32_bf16 a[104:107], v[200:203], v[232:235], a[104:107]\n\t"                                 \
+        "v_mfma_f32_16x16x32_bf16 a[56:59], v[188:191], v[216:219], a[56:59]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[120:123], v[204:207], v[232:235], a[120:123]\n\t"                                 \
+        "s_nop 1\n\t"                                                                                                 \
+        "v_mfma_f32_16x16x32_bf16 a[12:15], v[176:179], v[220:223], a[12:15]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[76:79], v[192:195], v[236:239], a[76:79]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[28:31], v[180:183], v[220:223], a[28:31]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[92:95], v[196:199], v[236:239], a[92:95]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[44:47], v[184:187], v[220:223], a[44:47]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[108:111], v[200:203], v[236:239], a[108:111]\n\t"                                 \
+        "v_mfma_f32_16x16x32_bf16 a[60:63], v[188:191], v[220:223], a[60:63]\n\t"                                     \
+        "v_mfma_f32_16x16x32_bf16 a[124:127], v[204:207], v[236:239], a[124:127]"                                     \
+        :                                                                                                           \
+        : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1),   \
+          "v"(NLRD), "v"(DLANE)                                                                                \
+        : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "vcc", "memory")
 
 template <bool DOWN>
 __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
@@ -2126,18 +2736,35 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
         if (st_n < niter) stage_next();                      // slice it + 4 -> the image of slice it - 4
         const int qb = qt0 + sl * kSl;
         const bool active = (qb + kSl - 1 >= k0) && (k0 < len);
-        const bool need_mask = (qb < k0 + 63) || (qb + kSl > len) || (k0 + 64 > len);
+        // three kinds of active slices (round 3): plain; the two DIAGONAL ones of the wave (the causal boundary crosses them, at
+        // different slices for each wave of the block: the same hand-placed stream with the mask folded into the S' chains'
+        // initial accumulators, so that the block does not wait at the next barrier for one wave on hipcc's slower path); the
+        // tail (sequence end inside the slice or inside the wave's keys: the select-based code below)
+        const bool tail = (qb + kSl > len) || (k0 + 64 > len);
+        const bool diag = qb < k0 + 63;
         const unsigned img = smem_base + cur * kSlImg;
         const unsigned next_img = smem_base + ((cur + 1) & (kSlRing - 1)) * kSlImg;
-        if (active && !need_mask) {
-            if (hot)
-                RPO_D4_SLICE_BODY_HOT(img + row_off[0], img + row_off[1], img + 2 * kSl * 128 + 16 * g, img + tr_off[0],
-                                      img + tr_off[1], img + tr_off[2], img + tr_off[3], scale_log2e,
-                                      next_img + row_off[0], next_img + row_off[1], next_img + 2 * kSl * 128 + 16 * g);
-            else
-                RPO_D4_SLICE_BODY_LOAD(img + row_off[0], img + row_off[1], img + 2 * kSl * 128 + 16 * g, img + tr_off[0],
-                                       img + tr_off[1], img + tr_off[2], img + tr_off[3], scale_log2e,
-                                       next_img + row_off[0], next_img + row_off[1], next_img + 2 * kSl * 128 + 16 * g);
+        if (active && !tail) {
+            if (!diag) {
+                if (hot)
+                    RPO_D4_SLICE_BODY_HOT(img + row_off[0], img + row_off[1], img + 2 * kSl * 128 + 16 * g, img + tr_off[0],
+                                          img + tr_off[1], img + tr_off[2], img + tr_off[3], scale_log2e,
+                                          next_img + row_off[0], next_img + row_off[1], next_img + 2 * kSl * 128 + 16 * g);
+                else
+                    RPO_D4_SLICE_BODY_LOAD(img + row_off[0], img + row_off[1], img + 2 * kSl * 128 + 16 * g, img + tr_off[0],
+                                           img + tr_off[1], img + tr_off[2], img + tr_off[3], scale_log2e,
+                                           next_img + row_off[0], next_img + row_off[1], next_img + 2 * kSl * 128 + 16 * g);
+            } else {
+                const int dlane = (k0 + fr) - (qb + 4 * g);      // the lane's key (tile 0) minus its first query row
+                if (hot)
+                    RPO_D4_DIAG_BODY_HOT(img + row_off[0], img + row_off[1], img + 2 * kSl * 128 + 16 * g, img + tr_off[0],
+                                         img + tr_off[1], img + tr_off[2], img + tr_off[3], scale_log2e,
+                                         next_img + row_off[0], next_img + row_off[1], next_img + 2 * kSl * 128 + 16 * g, dlane);
+                else
+                    RPO_D4_DIAG_BODY_LOAD(img + row_off[0], img + row_off[1], img + 2 * kSl * 128 + 16 * g, img + tr_off[0],
+                                          img + tr_off[1], img + tr_off[2], img + tr_off[3], scale_log2e,
+                                          next_img + row_off[0], next_img + row_off[1], next_img + 2 * kSl * 128 + 16 * g, dlane);
+            }
             hot = true;
         } else if (active) {
             hot = false;
