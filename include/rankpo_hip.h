@@ -246,7 +246,10 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
  * kernel that consumes the table.  head_dim 64: 256 (one wave per SIMD, entries dealt to the 8 XCDs in equal eighths, padded
  * with first key >= 2^30) or 64 (the 8-wave kernel; entries sorted by (sequence, head, key)); head_dim 128: 128 (one wave per
  * SIMD, 32 keys per wave; table dealt and padded like the 256 one).  Any other value is RPO_ERR_UNSUPPORTED: the meaning of
- * the table is an argument, never process-global state.  sweep_down: head_dim 64 / key_block 256 only (ignored elsewhere).
+ * the table is an argument, never process-global state.  sweep_down (key_block 256 and 128; ignored at 64, and when the q-head group
+ * is not a power of two): the dK/dV blocks sweep the query slices from the last one downwards, the group's q heads innermost (pairs
+ * with a work list that keeps a (sequence, kv head)'s key blocks next to each other: they then read each Q / dO slice at about the
+ * same time, once from HBM).  dk / dv differ from the ascending sweep by summation order only; either order is deterministic.
  * dq: [T, num_heads, hd], dk / dv: [T, num_kv_heads, hd] (token strides given), every valid row is written.
  * rope_cos / rope_sin (both NULL, or both f32 [rope_period][hd / 2], 16-byte aligned; token t uses row t % rope_period; the
  * tables rpo_rope rotated q and k with): dq and dk then leave as the gradients w.r.t. the PRE-rotary q / k -- the inverse

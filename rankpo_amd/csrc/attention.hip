@@ -3345,12 +3345,17 @@ static_assert(kD128Ahead >= 2 && kD128Ahead < kD128Ring, "the image of stage it 
 // the wave's K / V fragments (they were 64 VGPRs in round 2's hipcc-scheduled kernel).  Masked slices (diagonal, sequence end)
 // run the same steps as separate statements around hipcc's code for the masked arithmetic.  hipcc must not spill (it does not
 // know a[0:191] to be occupied): its resource line must show 0 scratch and no v_accvgpr_* outside ASMSTART / ASMEND.
+// DOWN (sweep_down of the C entry point, power-of-two group): slice-major from the LAST query slice downwards, the group's q
+// heads innermost -- every key block of a (sequence, kv head) then starts at the same slice and walks the same (slice, head)
+// sequence, so blocks launched side by side on one XCD (the group-ordered work list) read each Q / dO slice at about the same
+// time: once from HBM, the rest from L2.
+template <bool DOWN>
 __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
     const int* __restrict__ ktiles, int nh, int nkv, float scale_log2e, float scale, const float* __restrict__ nl,
     const float* __restrict__ nd, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
-    int64_t sdv, int n_ktiles, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod) {
+    int64_t sdv, int n_ktiles, int gshift, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -3414,9 +3419,13 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
 #if defined(RPO_D128_EXP) && RPO_D128_EXP == 3                    // (timing experiment: every stage re-reads the SAME slice: L2 hits)
         stage(hk * group, qt0, st_buf);
 #else
-        stage(st_h, qt0 + st_s * kD128Sl, st_buf);
+        if constexpr (DOWN) {
+            stage(hk * group + (st_n & (group - 1)), qt0 + (nsl - 1 - (st_n >> gshift)) * kD128Sl, st_buf);
+        } else {
+            stage(st_h, qt0 + st_s * kD128Sl, st_buf);
+            if (++st_s == nsl) { st_s = 0; ++st_h; }
+        }
 #endif
-        if (++st_s == nsl) { st_s = 0; ++st_h; }
         ++st_n;
         st_buf = (st_buf + 1) & (kD128Ring - 1);
     };
@@ -3458,6 +3467,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
     bool hot = false;      // v[96:175] hold the row fragments / row constants of slice `it` (prefetched by the previous body)
     int cur = 0, sl = 0;
     for (int it = 0; it < niter; ++it) {
+        if constexpr (DOWN) sl = nsl - 1 - (it >> gshift);
         // slices <= it + 1 have landed (the body prefetches from the next image).  Steady state (slices still being staged):
         // stages it + 2 .. it + Ahead - 1 are in flight
         if (st_n < niter) {
@@ -3592,7 +3602,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
             hot = false;
         }
         cur = (cur + 1) & (kD128Ring - 1);
-        sl = sl + 1 == nsl ? 0 : sl + 1;
+        if constexpr (!DOWN) sl = sl + 1 == nsl ? 0 : sl + 1;
     }
 #undef RPO_TR2H
     // the last MFMAs have to leave the pipe before their accumulators are read (hipcc cannot see the dependency)
@@ -3778,14 +3788,25 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
         const int rc128 = rpo_launch_status();
         if (rc128 != RPO_OK) return rc128;
         static const bool attr128_set = [] {
-            (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kD128Lds);
+            (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kD128Lds);
+            (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, kD128Lds);
             return true;
         }();
         (void)attr128_set;
-        RPO_LAUNCH(fa_bwd_dkdv128_kernel, dim3((unsigned)(((n_k_tiles + 7) / 8) * 8)), dim3(256), kD128Lds, st, (const bf16_t*)q,
-                   (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens,
-                   k_tiles, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk,
-                   (bf16_t*)dv, dk_stride, dv_stride, (int)n_k_tiles, rope_cos, rope_sin, rope_period);
+        const int group128 = (int)(num_heads / num_kv_heads);
+        int gshift128 = 0;
+        while ((1 << gshift128) < group128) ++gshift128;
+        const dim3 grid128((unsigned)(((n_k_tiles + 7) / 8) * 8));
+        if (sweep_down && (1 << gshift128) == group128)
+            RPO_LAUNCH(fa_bwd_dkdv128_kernel<true>, grid128, dim3(256), kD128Lds, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
+                       (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk, (bf16_t*)dv,
+                       dk_stride, dv_stride, (int)n_k_tiles, gshift128, rope_cos, rope_sin, rope_period);
+        else
+            RPO_LAUNCH(fa_bwd_dkdv128_kernel<false>, grid128, dim3(256), kD128Lds, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride, dout_stride, cu_seqlens, k_tiles,
+                       (int)num_heads, (int)num_kv_heads, scale * log2e, scale, nl, nd, total_tokens, (bf16_t*)dk, (bf16_t*)dv,
+                       dk_stride, dv_stride, (int)n_k_tiles, gshift128, rope_cos, rope_sin, rope_period);
         return rpo_launch_status();
     }
     RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0,

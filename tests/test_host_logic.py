@@ -439,7 +439,7 @@ def test_key_block_table_properties():
     rs = np.random.RandomState(0)
     for bn, nkv, lens in ((256, 8, rs.randint(1, 4097, size=37).tolist()), (256, 2, [5, 300, 257, 256, 1]), (256, 1, [1000]),
                           (128, 8, rs.randint(1, 4097, size=23).tolist()), (128, 2, [5, 300, 129, 128, 1])):   # 128: head_dim 128
-        t = ops.attn_key_tile_table(lens, "cpu", nkv, block_n=bn).numpy()
+        t = ops.attn_key_tile_table(lens, "cpu", nkv, block_n=bn, group_order=False).numpy()
         assert t.shape[0] % 8 == 0
         per = t.shape[0] // 8
         real = t[t[:, 2] < (1 << 30)]
@@ -453,6 +453,35 @@ def test_key_block_table_properties():
             assert (chunk[len(work):, 2] == (1 << 30)).all()
             for s, h, k in chunk[:len(work)].tolist():
                 assert owner.setdefault((s, h), x) == x
+
+
+def test_key_block_table_group_order():
+    """The group-ordered dK/dV work list (pairs with sweep_down; the default at head_dim 128): every (sequence, kv head, key block)
+    exactly once, a group on ONE XCD eighth and CONTIGUOUS there with its key blocks ascending (the heaviest first), eighths padded
+    with entries the kernel skips."""
+    from rankpo_amd import ops
+    rs = np.random.RandomState(2)
+    for bn, nkv, lens in ((128, 8, rs.randint(1, 4097, size=19).tolist()), (128, 2, [5, 300, 129, 128, 1]), (256, 4, [700, 256, 3])):
+        t = ops.attn_key_tile_table(lens, "cpu", nkv, block_n=bn, group_order=True if bn == 256 else None).numpy()   # 128: the default
+        assert t.shape[0] % 8 == 0
+        per = t.shape[0] // 8
+        real = t[t[:, 2] < (1 << 30)]
+        want = {(s, h, k) for s, n in enumerate(lens) for h in range(nkv) for k in range(0, n, bn)}
+        assert len(real) == len(want) and set(map(tuple, real.tolist())) == want
+        owner = {}
+        for x in range(8):
+            chunk = t[x * per:(x + 1) * per]
+            nreal = int((chunk[:, 2] < (1 << 30)).sum())
+            assert (chunk[nreal:, 2] == (1 << 30)).all()
+            seen, last, lastk = set(), None, -1
+            for s_, h_, k_ in chunk[:nreal].tolist():
+                assert owner.setdefault((s_, h_), x) == x
+                if (s_, h_) != last:
+                    assert (s_, h_) not in seen
+                    seen.add((s_, h_))
+                    last, lastk = (s_, h_), -1
+                assert k_ > lastk
+                lastk = k_
 
 
 def test_query_tile_table_properties():
