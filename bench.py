@@ -570,7 +570,9 @@ def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=Non
     lmin, lmax = red(loss, dist.ReduceOp.MIN), red(loss, dist.ReduceOp.MAX)
     in_sync = None
     if flat_param is not None:                                        # replicas still hold the same parameters after the steps
-        cs = flat_param.float().abs().sum().double().reshape(1) if flat_param.dtype != torch.float64 else flat_param.abs().sum().reshape(1)
+        # a checksum of the parameter BITS (no float temporary: the 8B model's flat buffer is 15 GB): integer sum of the words
+        bits = flat_param.view({1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[flat_param.element_size()])
+        cs = bits.sum(dtype=torch.int64).reshape(1)
         lo, hi = cs.clone(), cs.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
