@@ -71,13 +71,19 @@ __global__ __launch_bounds__(kEwThreads) void rope_kernel(const T* xin, T* x, in
     constexpr int V = Elem<T>::kVec;
     const int half = hd >> 1;
     const int vec_per_head = half / V;
-    const int total = H * vec_per_head;
-    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) {
+    const int total = H * vec_per_head;            // (low, high) vector pairs of one row
+    // A row with few pairs (round 3: the rotary fold leaves this kernel the K heads only, 8 heads x 4 pairs = 32 of the block's
+    // 256 threads) shares the block with its neighbours: rpb rows per block, thread -> (row tid / total, pair tid % total)
+    const int rpb = total <= kEwThreads / 2 ? kEwThreads / total : 1;
+    const int rin = rpb > 1 ? threadIdx.x / total : 0;
+    const int i0 = rpb > 1 ? threadIdx.x - rin * total : threadIdx.x;
+    if (rin >= rpb) return;                        // (threads beyond rpb * total when total does not divide the block)
+    for (int64_t r = (int64_t)blockIdx.x * rpb + rin; r < rows; r += (int64_t)gridDim.x * rpb) {
         T* xr = x + r * row_stride;
         const T* xi = xin + r * row_stride;
         const float* c = cs + (r % period) * half;
         const float* s = sn + (r % period) * half;
-        for (int i = threadIdx.x; i < total; i += kEwThreads) {
+        for (int i = i0; i < total; i += (rpb > 1 ? total : kEwThreads)) {
             const int h = i / vec_per_head, j = (i - h * vec_per_head) * V;
             T* lo = xr + h * hd + j;
             T* hi = lo + half;
@@ -226,7 +232,10 @@ extern "C" int rpo_rope(const void* x_in, void* x, int64_t row_stride, const flo
     const int V = dtype == RPO_DT_BF16 ? 8 : 4;
     if ((head_dim / 2) % V != 0 || head_dim % 2 != 0 || row_stride % V != 0 || !rpo_aligned16(x) || !rpo_aligned16(x_in))
         return RPO_ERR_UNSUPPORTED;
-    int64_t grid = rows < INT32_MAX ? rows : INT32_MAX;   // one block per row: contiguous 2*heads*head_dim bytes
+    const int64_t pairs = heads * ((head_dim / 2) / V);
+    const int64_t rpb = pairs <= kEwThreads / 2 ? kEwThreads / pairs : 1;      // rows per block (see the kernel)
+    const int64_t nblk = rpo_cdiv(rows, rpb);
+    int64_t grid = nblk < INT32_MAX ? nblk : INT32_MAX;
     hipStream_t st = (hipStream_t)stream;
     const float sign = backward ? -1.0f : 1.0f;
     if (dtype == RPO_DT_BF16)

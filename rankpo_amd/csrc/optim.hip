@@ -89,12 +89,31 @@ __global__ __launch_bounds__(kOptThreads) void sumsq_kernel(const T* __restrict_
     // block b owns a contiguous chunk of vectors (rounded up to whole 256-vector rows)
     const int64_t per = ((nv + gridDim.x - 1) / gridDim.x + kOptThreads - 1) / kOptThreads * kOptThreads;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = lo + per < nv ? lo + per : nv;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += kOptThreads) {
+    // four independent 16-byte loads in flight per thread (a single load per loop trip left 16 KB in flight per CU with this
+    // grid: 4.1-5.5 TB/s), four accumulators, fixed order
+    float acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+    int64_t i = lo + threadIdx.x;
+    for (; i + 3 * kOptThreads < hi; i += 4 * kOptThreads) {
+        Vec16<T> a, b, c, d;
+        a.load_nt(x + i * V);
+        b.load_nt(x + (i + kOptThreads) * V);
+        c.load_nt(x + (i + 2 * kOptThreads) * V);
+        d.load_nt(x + (i + 3 * kOptThreads) * V);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+            acc = fmaf(a.v[k], a.v[k], acc);
+            acc1 = fmaf(b.v[k], b.v[k], acc1);
+            acc2 = fmaf(c.v[k], c.v[k], acc2);
+            acc3 = fmaf(d.v[k], d.v[k], acc3);
+        }
+    }
+    for (; i < hi; i += kOptThreads) {
         Vec16<T> a;
         a.load_nt(x + i * V);
 #pragma unroll
         for (int k = 0; k < V; ++k) acc = fmaf(a.v[k], a.v[k], acc);
     }
+    acc = (acc + acc1) + (acc2 + acc3);
     if (blockIdx.x == 0)
         for (int64_t i = nv * V + threadIdx.x; i < n; i += kOptThreads) {
             const float a = Elem<T>::ld(x + i);

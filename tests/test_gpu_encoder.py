@@ -48,10 +48,11 @@ def test_swiglu_down_matches_torch(dtype):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("packed", [False, True])
-def test_rope_matches_hf_formula(dtype, packed):
+@pytest.mark.parametrize("H", [5, 40])      # 5 heads: several rows share a block (the K-heads-only call of the rotary fold); 40: one row per block
+def test_rope_matches_hf_formula(dtype, packed, H):
     from rankpo_amd import ops
     torch.manual_seed(1)
-    N, L, H, hd = 3, 17, 5, 64
+    N, L, hd = 3, 17, 64
     pos = torch.arange(L, device=DEV) if not packed else torch.randint(0, 50, (N * L,), device=DEV)
     inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2, device=DEV, dtype=torch.float32) / hd))
     fr = torch.outer(pos.float(), inv)
