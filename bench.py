@@ -332,13 +332,14 @@ def usable_cores():
     return n, how
 
 
-def cpu_baseline(model, cfg, temperature, sample=(20, 42, 8, 3), repeats=3, note=lambda m: None, budget_s=150.0):
+def cpu_baseline(model, cfg, temperature, sample=(20, 42, 8, 3), repeats=3, note=lambda m: None, budget_s=150.0,
+                 long_sample=(256, 1024, 2, 1)):
     """The oracle's training micro-step (encoder fwd+bwd + scoring, float32, eager) on the host cores, on a bounded
     sample of the workload: Q_s queries padded to Lq_s tokens + Q_s * G_s passages padded to Lp_s tokens (right-padded rows
     of random length, first row full: the reference's padded batches) through the SAME architecture and weights; median of
     `repeats` timed steps after one untimed step of the same shape, on every core this process may use.  pairs/s is
-    extrapolated linearly in (padded) tokens to the full-length pair (optimistic for the CPU: the quadratic attention term
-    is ignored)."""
+    extrapolated linearly in (padded) tokens to the full-length pair -- optimistic for the CPU, the quadratic attention term is
+    ignored -- and, from a second sample with longer rows, with that term fitted (`fit`)."""
     from oracle import encoder_ref as E
     Lq_s, Lp_s, Q_s, G_s = sample
     cores, how = usable_cores()
@@ -370,7 +371,27 @@ def cpu_baseline(model, cfg, temperature, sample=(20, 42, 8, 3), repeats=3, note
             break
         if time.perf_counter() - t_start > budget_s and times:
             break
-    return sorted(times)[len(times) // 2], times, Q_s * (Lq_s + G_s * Lp_s), (cores, how), batch, ref
+    med = sorted(times)[len(times) // 2]
+    # A second, LONGER-row sample fits the quadratic (attention) term the token-linear extrapolation ignores: the oracle's eager
+    # attention materialises [N, heads, L, L] scores, so t = a * tokens + b * sum(L_pad^2) over the padded rows (what the reference
+    # runs).  Two samples, two unknowns; one timed step of the second one (the pool and the allocator are warm by now).
+    fit = None
+    if long_sample is not None and time.perf_counter() - t_start < budget_s:
+        Lq2, Lp2, Q2, G2 = long_sample
+        b2 = {"query": mk(Q2, Lq2), "passage": mk(Q2 * G2, Lp2)}
+        t0 = time.perf_counter()
+        oracle_step(w, cd, b2, temperature)
+        dt2 = time.perf_counter() - t0
+        note(f"cpu baseline: oracle step on the long-row sample ({Q2} x {Lq2} + {Q2 * G2} x {Lp2} tokens) {dt2:.2f} s")
+        tok1, quad1 = Q_s * (Lq_s + G_s * Lp_s), Q_s * (Lq_s ** 2 + G_s * Lp_s ** 2)
+        tok2, quad2 = Q2 * (Lq2 + G2 * Lp2), Q2 * (Lq2 ** 2 + G2 * Lp2 ** 2)
+        det = tok1 * quad2 - tok2 * quad1
+        a = (med * quad2 - dt2 * quad1) / det
+        bq = (tok1 * dt2 - tok2 * med) / det
+        if a > 0 and bq >= 0:
+            fit = {"a_s_per_token": a, "b_s_per_token2": bq, "long_sample_seconds": round(dt2, 3),
+                   "long_sample": f"{Q2} queries x {Lq2} tok + {Q2 * G2} passages x {Lp2} tok"}
+    return med, times, Q_s * (Lq_s + G_s * Lp_s), (cores, how), batch, ref, fit
 
 
 PARITY_GRADS = ("embed_tokens.weight", "layers.0.self_attn.q_proj.weight", "layers.0.self_attn.k_proj.weight")
@@ -904,7 +925,8 @@ def main():
             note("sweep done")
         if world == 1 and not args.no_cpu_baseline:
             note("cpu baseline (oracle on host cores) ...")
-            dt, times, toks, (cores, cores_how), sample_batch, ref = cpu_baseline(model, cfg, temperature, note=note)
+            dt, times, toks, (cores, cores_how), sample_batch, ref, fit = cpu_baseline(
+                model, cfg, temperature, note=note, long_sample=(256, 1024, 2, 1) if Lp >= 1024 else None)
             note("step parity: fast path and stock-eager control vs the float32 oracle ...")
             # the timed steps ran with the configuration's dropout (BERT family: HF's 0.1, as the reference trains it); the
             # oracle has none, so the parity leg -- outside the timed region -- compares with every nn.Dropout at p = 0
@@ -920,6 +942,15 @@ def main():
                                              f"through the same {arch} weights: {toks} tokens, median of {len(times)} timed "
                                              f"steps after 1 untimed; pairs/s extrapolated linearly in tokens to "
                                              f"{toks_per_pair:.0f} tokens per full-length pair"}
+            if fit is not None:
+                # the full workload as the reference runs it (padded rows): B queries of Lq + B (1 + K) passages of Lp tokens
+                t_full = fit["a_s_per_token"] * B * (Lq + (1 + K) * Lp) + fit["b_s_per_token2"] * B * (Lq ** 2 + (1 + K) * Lp ** 2)
+                out["cpu_baseline"].update({
+                    "value_with_attention_term": round(B * (1 + K) / t_full, 5),
+                    "attention_term": {**{k: (float(f"{v:.4g}") if isinstance(v, float) else v) for k, v in fit.items()},
+                                       "model": "seconds = a * padded tokens + b * sum over rows of L_pad^2 (the oracle's eager "
+                                                "attention), fitted on the two samples, evaluated at the full batch "
+                                                f"({B} x {Lq} + {B * (1 + K)} x {Lp} tokens): {t_full:.0f} s per step"}})
             try:        # what the port's time is worth in REFERENCE time (tools/time_reference.py, build container)
                 rc = json.load(open(os.path.join(ROOT, "profiles", "ref_cpu_container.json")))
                 por = rc["port_over_reference"]
