@@ -113,6 +113,8 @@ inline unsigned ew_grid(int64_t nvec) { return (unsigned)rpo_cdiv(nvec, kEwThrea
 // W^T.  PyTorch's `.t().contiguous()` moves 0.35 TB/s on these shapes (3.4 ms for a [151552, 2048] bf16 operand); this kernel
 // is HBM-bound.  64 x 64 tile through LDS: 16-byte global loads along the input rows, 2-byte (bf16) / 4-byte (f32) LDS reads
 // down the tile columns, 16-byte global stores along the output rows: whole 128-byte lines on both sides.
+// (Round 3, measured and dropped: a 128 x 128 tile -- 256-byte pieces on both sides -- moved 5.03 TB/s on [151552, 2048] against
+// 5.83 for this one, 5.49 against 5.79 on [151552, 4096]: tools/transpose_ab.py.)
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t R, int64_t C,
