@@ -3204,10 +3204,12 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
         for (int n = 0; n < 2; ++n) acc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
     const int qq = fr >> 2, pp = fr & 3;
     const int vsw = 2 * (4 * (g & 1) + qq);
-    unsigned tr_off[8];                                  // K^T: the forward's V^T addressing on the K image
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        tr_off[c] = (4 * g + qq) * kFa128Row + (((2 * c + (pp >> 1)) ^ vsw) << 4) + 8 * (pp & 1);
+    // K^T: the forward's V^T addressing on the K image.  tr_off[c] = row part + (((2 c + (pp >> 1)) ^ vsw) << 4) + 8 (pp & 1); vsw is
+    // even and everything else of the offset lies below bit 5, so tr_off[c] = tr_off[0] ^ (c << 5): ONE register and an XOR in front
+    // of each read instead of eight registers live across the loop -- round 2's kernel (256 VGPRs, 2 blocks per CU) spilled 7 dwords
+    // to scratch and RELOADED two of them inside the key-tile loop (scratch loads count in vmcnt, next to the LDS-DMA ring's
+    // counted waits).  The XOR is an asm statement so that hipcc does not hoist the eight values back out of the loop.
+    const unsigned tr0 = (4 * g + qq) * kFa128Row + (((pp >> 1) ^ vsw) << 4) + 8 * (pp & 1);
     unsigned row_off[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) row_off[ks] = fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
@@ -3215,6 +3217,12 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
 
 #define RPO_TR2H(OUT0, OUT1, ADDR)                                                                              \
     asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=&v"(OUT0), "=&v"(OUT1) : "v"(ADDR) : "memory")
+#define RPO_TR2H_X(OUT0, OUT1, TB, C)                                                                           \
+    do {                                                                                                        \
+        unsigned a_;                                                                                            \
+        asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a_) : "n"((C) << 5), "v"(tr0));                               \
+        RPO_TR2H(OUT0, OUT1, (TB) + a_);                                                                         \
+    } while (0)
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -3227,14 +3235,14 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
             const char* Vs = Ks + kFa128BN * kFa128Row;
             const unsigned tb = smem_base + cur * kKvTile;
             u32x2 x0, x1, x2, x3, x4, x5, x6, x7, y0, y1, y2, y3, y4, y5, y6, y7;
-            RPO_TR2H(x0, y0, tb + tr_off[0]);
-            RPO_TR2H(x1, y1, tb + tr_off[1]);
-            RPO_TR2H(x2, y2, tb + tr_off[2]);
-            RPO_TR2H(x3, y3, tb + tr_off[3]);
-            RPO_TR2H(x4, y4, tb + tr_off[4]);
-            RPO_TR2H(x5, y5, tb + tr_off[5]);
-            RPO_TR2H(x6, y6, tb + tr_off[6]);
-            RPO_TR2H(x7, y7, tb + tr_off[7]);
+            RPO_TR2H(x0, y0, tb + tr0);
+            RPO_TR2H_X(x1, y1, tb, 1);
+            RPO_TR2H_X(x2, y2, tb, 2);
+            RPO_TR2H_X(x3, y3, tb, 3);
+            RPO_TR2H_X(x4, y4, tb, 4);
+            RPO_TR2H_X(x5, y5, tb, 5);
+            RPO_TR2H_X(x6, y6, tb, 6);
+            RPO_TR2H_X(x7, y7, tb, 7);
             float4_t s[2][2], dp[2][2];                   // [key sub-tile m][query tile n], rows = keys 16m + 4g + r
 #pragma unroll
             for (int m = 0; m < 2; ++m)
@@ -3322,6 +3330,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq128_kernel(
     }
 }
 
+#undef RPO_TR2H_X
+#undef RPO_TR2H
 constexpr int kD128Sl = 32;                                        // query rows per slice
 constexpr int kD128Img = 2 * kD128Sl * kFa128Row + 256;            // Q | dO | 32 x -lse / scale | 32 x -delta = 16640 B
 constexpr int kD128Keys = 128;                                     // keys per block (4 waves x 32)
