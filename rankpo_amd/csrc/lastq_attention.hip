@@ -42,7 +42,7 @@ __device__ __forceinline__ float group_sum(float x) {
 }
 
 template <int HD, int REP, int U>
-__global__ __launch_bounds__(kLqThreads) void lastq_fwd_kernel(
+__global__ __launch_bounds__(kLqThreads, 4) void lastq_fwd_kernel(      // 4 blocks per CU = 128 registers: hipcc took 129-130 without
     const bf16_t* __restrict__ q, int64_t q_stride, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t k_stride,
     int64_t v_stride, const int* __restrict__ cu, int nkv, float scale, bf16_t* __restrict__ out, int64_t out_stride,
     float* __restrict__ lse) {
