@@ -711,6 +711,11 @@ def main():
                     help="N > 1: optimizer state partitioned over the ranks (reduce-scatter + AdamW shard + parameter all-gather, "
                          "the reference's ZeRO-1) instead of replicated (all-reduce); auto = on when the replicated state would "
                          "force blocks to be checkpointed")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% device_count and the process group "
+                         "runs on gloo (RCCL refuses two ranks on one device); exercises the whole N > 1 code path -- launch, "
+                         "cross-device forward with this rank's row window, bucketed gradient mean, comm block -- on the HIP kernels; "
+                         "the numbers it prints are not a measurement")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="CPU rehearsal of the N-rank launch only: gloo process group, barrier, max-over-ranks, one JSON line")
     args = ap.parse_args()
@@ -728,6 +733,8 @@ def main():
                          f"--nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` outside torchrun")
     if args.rehearse_launch:
         return rehearse_launch(rank, world)
+    if args.share_gpu:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
@@ -736,7 +743,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")
         with _StdoutToStderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            if args.share_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
             dist.barrier()                       # creates the RCCL communicator now (banner goes to stderr)
             torch.cuda.synchronize()
 

@@ -19,9 +19,16 @@ import torch.distributed as dist
 
 
 def _all_gather_into(out: torch.Tensor, x: torch.Tensor, async_op=False):
-    """out: [W, *x.shape] contiguous."""
+    """out: [W, *x.shape] contiguous.  nccl (= RCCL): one all_gather_into_tensor.  gloo (the CPU tests; and device tensors in
+    `bench.py --share-gpu`, a rehearsal of the N > 1 path on one GPU): gloo gathers host tensors only, device tensors are staged
+    through the host (synchronous; returns None instead of a work handle)."""
     if dist.get_backend() == "nccl":
         return dist.all_gather_into_tensor(out.view(-1), x.reshape(-1), async_op=async_op)
+    if x.is_cuda:
+        host = [torch.empty(x.shape, dtype=x.dtype) for _ in range(out.shape[0])]
+        dist.all_gather(host, x.cpu())
+        out.copy_(torch.stack(host).to(out.device))
+        return None
     return dist.all_gather(list(out.unbind(0)), x, async_op=async_op)
 
 

@@ -156,11 +156,9 @@ class FlatAdamW:
         if dist.get_backend() == "nccl":
             # in place: `own` IS slice `rank` of the output (NCCL's in-place all-gather form)
             return dist.all_gather_into_tensor(self.flat_param[s:e], own, async_op=True)
+        from .distributed import _all_gather_into
         n = (e - s) // r.world
-        parts = [torch.empty_like(own) for _ in range(r.world)]
-        dist.all_gather(parts, own.clone())
-        for i, t in enumerate(parts):
-            self.flat_param[s + i * n:s + (i + 1) * n].copy_(t)
+        _all_gather_into(self.flat_param[s:e].view(r.world, n), own.clone())     # gloo: host tensors, or staged through the host
         return None
 
 

@@ -77,3 +77,30 @@ def test_distributed_gather_api_and_metrics_allreduce(nccl_world1):
     loss, metrics = tr.compute_loss(model.model, {"query": _batch(rs, 3, 10, 64), "passage": _batch(rs, 6, 12, 64)},
                                     return_outputs=True)
     assert np.isfinite(loss.item()) and "rewards/accuracies" in metrics and "sft_loss" not in metrics
+
+
+def test_two_ranks_end_to_end_on_one_gpu():
+    """The WHOLE N > 1 bench path with two real rank processes on the HIP kernels: `bench.py --gpus 2 --share-gpu` (both ranks on this
+    box's one GPU, process group on gloo because RCCL refuses two ranks on one device; reference: torchrun --nproc-per-node N,
+    scripts/train/run_contrastive.sh:27-30, with negatives_cross_device, modeling.py:287-290).  Checks what the `comm` block is
+    for: the backend saw both ranks, one q||p all-gather per step, the redundantly computed global loss is the SAME on both ranks,
+    the replicas' parameters are bit-identical after the steps -- with the replicated and with the partitioned optimizer state."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    for extra in ([], ["--partition-optimizer", "on", "--gas", "2"]):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "tiny",
+                            "--steps", "3", "--warmup", "1", "--no-sweep", "--no-cpu-baseline"] + extra,
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, r.stdout[-2000:]
+        out = json.loads(lines[0])
+        comm = out["comm"]
+        assert out["n_gpus"] == 2 and comm["ranks_seen"] == 2 and comm["world_size"] == 2
+        assert comm["allgather_calls_per_step"] == 1.0 * (2 if extra else 1)          # one per micro-step
+        assert comm["loss_equal_over_ranks"] is True and comm["params_in_sync"] is True and comm["late_buckets"] == 0
+        assert comm["optimizer_state_partitioned"] == bool(extra)
+        assert np.isfinite(out["loss_last"]) and out["loss_first"] != out["loss_last"]
