@@ -963,14 +963,17 @@ def main():
                                                 f"({B} x {Lq} + {B * (1 + K)} x {Lp} tokens): {t_full:.0f} s per step"}})
             try:        # what the port's time is worth in REFERENCE time (tools/time_reference.py, build container)
                 rc = json.load(open(os.path.join(ROOT, "profiles", "ref_cpu_container.json")))
-                por = rc["port_over_reference"]
+                # the ratio measured on THIS architecture family: the Llama-3.2-1B architecture on the very sample timed above
+                # (weight-bound, short rows), or the BGE-small cfg-1 step for the BERT family
+                leg = rc["full_step_llama_3_2_1b_sample"] if "llama" in arch else rc["full_step_cfg1"]
+                por = leg["port_over_reference"]
                 out["cpu_baseline"].update({
                     "port_over_reference": por,
                     "reference_equivalent_value": round(out["cpu_baseline"]["value"] * por, 5),
                     "port_over_reference_source": ("profiles/ref_cpu_container.json: the reference itself (imported, unmodified) and this "
-                                                   f"port timed on the same cfg-1 step in the build container ({rc['host']['threads']} threads of "
-                                                   f"{rc['host']['cpu_model']}): reference {rc['full_step_cfg1']['reference_median_s']} s, port "
-                                                   f"{rc['full_step_cfg1']['port_median_s']} s per step; the reference cannot travel to the GPU box")})
+                                                   f"port timed on the same step in the build container ({rc['host']['threads']} threads of "
+                                                   f"{rc['host']['cpu_model']}; {leg['case'][:60]}...): reference {leg['reference_median_s']} s, "
+                                                   f"port {leg['port_median_s']} s per step; the reference cannot travel to the GPU box")})
             except Exception:
                 pass
             if not out["step_loss_parity"]["pass"]:

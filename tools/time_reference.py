@@ -147,6 +147,63 @@ def full_step_cfg1(modeling, tmpdir, repeats):
     return res
 
 
+def full_step_llama(modeling, tmpdir, repeats):
+    """The architecture of the HEADLINE workload (BASELINE.json configs[1]: Llama-3.2-1B, random init, f32 on the CPU) on the sample
+    `bench.py`'s cpu_baseline times on the GPU box (8 queries x 20 tokens + 24 passages x 42 tokens, right-padded): the reference's own
+    ModelForTraining (transformers' LlamaModel, sdpa) against the oracle port on the same weights and batch."""
+    from transformers import LlamaConfig, LlamaModel
+    from oracle import encoder_ref as E
+    from rankpo_amd import encoder as PE
+    torch.manual_seed(0)
+    mine = PE.llama_3_2_1b_config()
+    hcfg = LlamaConfig(vocab_size=mine.vocab_size, hidden_size=2048, intermediate_size=8192, num_hidden_layers=16,
+                       num_attention_heads=32, num_key_value_heads=8, head_dim=64, rms_norm_eps=1e-5, rope_theta=500000.0,
+                       rope_scaling=dict(PE.LLAMA3_ROPE), max_position_embeddings=131072, pad_token_id=mine.pad_token_id,
+                       attention_bias=False, tie_word_embeddings=False)
+    path = os.path.join(tmpdir, "llama_3_2_1b_arch")
+    LlamaModel(hcfg).save_pretrained(path)
+    ref = modeling.ModelForTraining(path, attn_implementation="sdpa", temperature=T, use_inbatch_neg=True,
+                                    negatives_cross_device=False, normalize_embeddings=True)
+    ref.train()
+    g = torch.Generator().manual_seed(7)
+
+    def side(N, L):
+        lens = torch.randint(L // 2, L + 1, (N,), generator=g)
+        lens[0] = L
+        mk = (torch.arange(L)[None, :] < lens[:, None]).long()
+        ids = torch.randint(1000, mine.vocab_size - 1000, (N, L), generator=g)
+        return {"input_ids": ids * mk + mine.pad_token_id * (1 - mk), "attention_mask": mk}
+    batch = {"query": side(8, 20), "passage": side(24, 42)}
+    w = {k: v.detach().clone().float().requires_grad_(True) for k, v in ref.model.state_dict().items()}
+    cd = mine.to_dict()
+    losses = {}
+
+    def ref_step():
+        ref.zero_grad(set_to_none=True)
+        o = ref(**batch)
+        o["loss"].backward()
+        losses["reference"] = float(o["loss"])
+
+    def port_step():
+        for t in w.values():
+            t.grad = None
+        loss = E.contrastive_step(w, cd, batch, T)[0]
+        loss.backward()
+        losses["port"] = float(loss)
+    tr = timeit(ref_step, 1, repeats)
+    tp = timeit(port_step, 1, repeats)
+    mr, mp_ = statistics.median(tr), statistics.median(tp)
+    res = {"case": "Llama-3.2-1B architecture (16 blocks, d 2048, 32 / 8 heads, ff 8192, llama3 rope scaling, vocab 128263), random init, f32, "
+                   "8 queries x 20 tok + 24 passages x 42 tok (bench.py's cpu_baseline sample), T = 0.02, in-batch negatives, sdpa",
+           "tokens": 8 * 20 + 24 * 42, "reference_step_s": [round(t, 3) for t in tr], "port_step_s": [round(t, 3) for t in tp],
+           "reference_median_s": round(mr, 3), "port_median_s": round(mp_, 3), "port_over_reference": round(mp_ / mr, 3),
+           "loss_reference": losses["reference"], "loss_port": losses["port"],
+           "method": f"median of {repeats} fwd+bwd after 1 warm-up, same weights, same batch"}
+    assert abs(losses["reference"] - losses["port"]) < 5e-4 * max(1.0, abs(losses["reference"])), losses
+    print(res, flush=True)
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "ref_cpu_container.json"))
@@ -159,12 +216,13 @@ def main():
     with tempfile.TemporaryDirectory() as tmp:
         sc = scoring_cases(modeling, tmp, make_ref_model)
         full = full_step_cfg1(modeling, tmp, args.repeats)
+        llama = full_step_llama(modeling, tmp, max(2, args.repeats - 2))
     import transformers
     out = {"what": "the reference (yflyzhang/RankPO, /root/reference/src/modeling.py, imported unmodified) and the oracle port timed on the "
                    "same inputs in the build container (SURVEY.md §8d(1)); tools/time_reference.py",
            "host": {"cpu_model": cpu_model(), "threads": args.threads, "torch": torch.__version__, "transformers": transformers.__version__},
-           "scoring_only": sc, "full_step_cfg1": full,
-           "port_over_reference": full["port_over_reference"],
+           "scoring_only": sc, "full_step_cfg1": full, "full_step_llama_3_2_1b_sample": llama,
+           "port_over_reference": full["port_over_reference"], "port_over_reference_llama": llama["port_over_reference"],
            "port_over_reference_note": "time of the oracle port / time of the reference on the cfg-1 full step (encoder-bound, like the "
                                        "metric); > 1 means the port is SLOWER than the reference, so a cpu_baseline timed with the port "
                                        "UNDERSTATES the reference by that factor"}
