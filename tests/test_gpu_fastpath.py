@@ -194,10 +194,12 @@ def test_left_padded_and_holed_masks_through_embed(kind, dtype, tol):
     assert (got2 - ref).abs().max() < tol
 
 
-def test_real_width_and_length_parity():
+@pytest.mark.parametrize("arch", ["llama-3.2-1b", "llama-3-8b"])
+def test_real_width_and_length_parity(arch):
     """The gate above runs at d = 512 with <= 320-token rows.  This one runs the SAME rule at the width and length the headline
     number is measured at (BASELINE.json configs[1]; reference modeling.py:206-238): 2 blocks of the Llama-3.2-1B architecture
-    (d 2048, 32 / 8 heads, head_dim 64, ff 8192, the real llama3 rope scaling with original_max_position_embeddings 8192),
+    (d 2048, 32 / 8 heads, head_dim 64, ff 8192, the real llama3 rope scaling with original_max_position_embeddings 8192) -- and of
+    the Llama-3-8B architecture (configs[4]: d 4096, head_dim 128, ff 14336) --,
     2 queries of <= 1280 tokens + 6 passages of <= 4096 tokens (one full-length row each, G = 3): positions beyond 2048, the
     full-width GEMM shapes, 30 query tiles per sequence in the attention work lists and the filler sequence at scale.
 
@@ -210,9 +212,13 @@ def test_real_width_and_length_parity():
     assert not torch.backends.cuda.matmul.allow_tf32
     torch.manual_seed(11)
     V = 8192
-    cfg = PE.llama_3_2_1b_config(vocab_size=V, num_hidden_layers=2, pad_token_id=0)
-    assert (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size) == (2048, 32, 8, 64, 8192)
-    assert cfg.rope_scaling["rope_type"] == "llama3" and cfg.rope_scaling["original_max_position_embeddings"] == 8192
+    if arch == "llama-3.2-1b":
+        cfg = PE.llama_3_2_1b_config(vocab_size=V, num_hidden_layers=2, pad_token_id=0)
+        assert (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size) == (2048, 32, 8, 64, 8192)
+        assert cfg.rope_scaling["rope_type"] == "llama3" and cfg.rope_scaling["original_max_position_embeddings"] == 8192
+    else:       # BASELINE.json configs[4]: the Llama-3-8B architecture (head_dim 128: the other set of attention kernels), plain rope
+        cfg = PE.llama_3_8b_config(vocab_size=V, num_hidden_layers=2, pad_token_id=0)
+        assert (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.intermediate_size) == (4096, 32, 8, 128, 14336)
     enc = PE.LlamaEncoder(cfg).to(DEV).to(torch.bfloat16)
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=T_CONTRASTIVE).train()
     rs = np.random.RandomState(77)
