@@ -17,6 +17,7 @@
 // Backward: dS = grad * (softmax(S) - onehot) / (Q T) is recomputed from the stored scores and lse;
 //   dq = dS p (own q rows), dp = dS^T q (own p rows).
 #include "common.hpp"
+#include <atomic>
 #include <cstdlib>
 
 int rpo_launch_grouped_dots(const void* q, const void* p, int64_t B, int64_t G, int64_t d, int dtype, float* out,
@@ -663,11 +664,16 @@ __device__ __forceinline__ void skinny_fused_finalize(int tid, int64_t Q, int ng
     if (tid == 0) loss_out[0] = tot / (float)Q;
 }
 
+// Arrival counters of the multi-block launches (one slot per launch, handed out round-robin by the host): zero at module
+// load, and the last block to arrive puts its slot back to zero, so no memset launch precedes the kernel.
+constexpr int kSkinnyTicketSlots = 64;
+__device__ unsigned g_skinny_ticket[kSkinnyTicketSlots];
+
 template <typename T, int NG>
 __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
     const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
     int scale, int do_stats, int64_t group, T* __restrict__ scores, float2* __restrict__ partial,
-    float* __restrict__ lse_out, float* __restrict__ loss_out) {
+    float* __restrict__ lse_out, float* __restrict__ loss_out, int ticket_slot) {
     typedef typename Mma<T>::Frag Frag;
     constexpr int CE = 16 / (int)sizeof(T);   // elements per chunk
     constexpr int SE = 4 * CE;                // elements per 64-byte K segment
@@ -731,8 +737,51 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
         }
         __syncthreads();                              // s_acc is rewritten by the next pass
     }
-    if (!fused) return;
-    skinny_fused_finalize(tid, Q, ngroups, s_part, s_tgt, s_red, lse_out, loss_out);
+    if (fused) {
+        skinny_fused_finalize(tid, Q, ngroups, s_part, s_tgt, s_red, lse_out, loss_out);
+        return;
+    }
+    if (!do_stats || ticket_slot < 0) return;
+    // Several blocks, still ONE launch (the W = 8 scoring shape, 64 x 384): every block publishes its partials and scores,
+    // then takes a ticket; the block that arrives last merges the per-group partials of each row in group order -- the order
+    // ce_finalize_kernel uses, so lse and loss are bit-identical to the two-launch form -- and writes lse / loss.
+    __shared__ int s_last;
+    __syncthreads();                                  // the block's stores happen-before thread 0's release below
+    if (tid == 0) {
+        unsigned* ticket = g_skinny_ticket + ticket_slot;
+        // release: the block's stores (ordered before this by the barrier) are visible to whoever reads the ticket; acquire: the
+        // last arriver sees every other block's
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == gridDim.x - 1);
+        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the slot's next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
+    float rowloss = 0.f;
+    if (tid < Q) {
+        float m = RPO_NEG_INF, l = 0.f;
+        const unsigned long long* pw = reinterpret_cast<const unsigned long long*>(partial);
+        for (int b2 = 0; b2 < ngroups; ++b2) {
+            const unsigned long long w = __hip_atomic_load(pw + (int64_t)b2 * Q + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            softmax_merge(m, l, __uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+        }
+        const float lse = m + logf(l);
+        lse_out[tid] = lse;
+        // the positive's score as stored (other blocks wrote it: read past this CU's caches)
+        const T* sp = scores + (int64_t)tid * P + (int64_t)tid * group;
+        float tgt;
+        if constexpr (sizeof(T) == 2) {
+            const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned short*>(sp), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+            tgt = __uint_as_float(w << 16);
+        } else {
+            tgt = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(sp), __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT));
+        }
+        rowloss = lse - tgt;
+    }
+    const float tot = block_sum<8>(rowloss, s_red);
+    if (tid == 0) loss_out[0] = tot / (float)Q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1247,14 +1296,18 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         const int64_t bytes = (Q + P) * d * (int64_t)sizeof(T);
         const bool one_block = pl.nPb <= kSkinnyMaxFusedGroups && bytes <= 384 * 1024;
         const unsigned nblk = one_block ? 1u : (unsigned)npass;
-        fused_finalize = do_stats && nblk == 1;
+        // several blocks: the last block to arrive finalizes (one launch; needs the scores in memory for the positives' column)
+        static std::atomic<unsigned> next_slot{0};
+        const int slot = (nblk > 1 && do_stats && scores_out != nullptr)
+                             ? (int)(next_slot.fetch_add(1, std::memory_order_relaxed) % (unsigned)kSkinnyTicketSlots) : -1;
+        fused_finalize = do_stats && (nblk == 1 || slot >= 0);
         const dim3 grid(nblk), block(kSkinnyThreads);
         if (ng == 4)
             RPO_LAUNCH((sim_skinny_kernel<T, 4>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d, temperature, scale,
-                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out);
+                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out, slot);
         else
             RPO_LAUNCH((sim_skinny_kernel<T, 1>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d, temperature, scale,
-                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out);
+                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out, slot);
     } else {
         RPO_LAUNCH(sim_rowwise_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q, (const T*)p, Q,
                            P, d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial);

@@ -210,6 +210,39 @@ def test_infonce_forward_backward_shapes(dtype, Q, P, d):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Q,P,d", [(64, 384, 2048), (16, 96, 2048), (33, 231, 4096)])
+def test_infonce_many_block_single_launch_finalize(dtype, Q, P, d):
+    """The multi-block launches of the skinny kernel (the W = 8 scoring shape of modeling.py:287-314, 64 x 384) finish lse and
+    loss in the SAME launch: the last block to arrive merges the partials.  The arrival counters are reused round-robin and put
+    back to zero by that block; 150 launches walk every slot more than twice, two streams interleave their slots, and every
+    result must equal the softmax / CE of the scores the launch returned -- the inputs change every launch, so a stale or
+    double-counted ticket shows as a loss that was never written (an earlier launch's value) or one taken from incomplete partials."""
+    rs = np.random.RandomState(Q + P)
+    G = P // Q
+    tgt = np.arange(Q) * G
+    side = torch.cuda.Stream()
+    first = None
+    for it in range(150):
+        qn, pn = unit(rs.randn(Q, d)), unit(rs.randn(P, d))
+        q, p = t(qn, dtype), t(pn, dtype)
+        with torch.cuda.stream(side if it % 3 == 2 else torch.cuda.current_stream()):
+            if it % 3 == 2:
+                side.wait_stream(torch.cuda.default_stream())
+            loss, scores = ops().infonce_loss(q, p, T)
+            if it == 0:
+                again, _ = ops().infonce_loss(q, p, T)
+                first = (loss, again)
+        if it % 3 == 2:
+            torch.cuda.default_stream().wait_stream(side)
+        if it % 10 == 0 or it % 3 == 2:
+            s = npf(scores)
+            m = s.max(-1, keepdims=True)
+            lse = (m + np.log(np.exp(s - m).sum(-1, keepdims=True)))[:, 0]
+            np.testing.assert_allclose(loss.item(), (lse - s[np.arange(Q), tgt]).mean(), rtol=2e-5, atol=2e-6)
+    assert first[0].item() == first[1].item()        # same inputs, two launches, two slots: bit-identical
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_infonce_no_inbatch(dtype):
     rs = np.random.RandomState(11)
     B, G, d = 8, 6, 256
