@@ -47,12 +47,17 @@ __device__ unsigned long long g_fa_stamp[8 * 8];
 #endif
 
 
-// two f32 -> one dword of two bf16 (round to nearest even) in ONE instruction; written as `f32_to_bf16(a) | f32_to_bf16(b) << 16`
-// hipcc converts each value on its own and merges them with a third instruction.
+// two f32 -> one dword of two bf16 (round to nearest even) in ONE v_cvt_pk_bf16_f32; written as `f32_to_bf16(a) | f32_to_bf16(b) << 16`
+// hipcc converts each value on its own and merges them with a third instruction.  A vector conversion, NOT an asm statement: the
+// instruction must be visible to hipcc's hazard recognizer -- a VALU instruction that reads the result of the v_exp_f32 right in
+// front of it needs one wait state (transcendental forwarding), which hipcc cannot insert in front of an opaque asm.  Rounds 1-2
+// had the asm form; with the forward kernels' row sums moved to the matrix pipe (round 3) nothing stood between the last v_exp_f32
+// of a key tile and the conversion any more, and the head_dim-128 kernel packed the PRE-exp score (-1e30 on masked keys) into P.
 __device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
 }
 
 // two accumulator tiles (rows 4g + r of each) -> one 8 x bf16 operand fragment: k-slots {4g + j, 16 + 4g + (j - 4)}
@@ -116,6 +121,19 @@ __device__ __forceinline__ void rope_frag(short8_t& lo, short8_t& hi, const floa
     const u32x4 wh = {pack_bf16(y2[0], y2[1]), pack_bf16(y2[2], y2[3]), pack_bf16(y2[4], y2[5]), pack_bf16(y2[6], y2[7])};
     lo = __builtin_bit_cast(short8_t, wl);
     hi = __builtin_bit_cast(short8_t, wh);
+}
+
+// Cross-group reductions of the forward kernels (a query's scores sit in lanes fr, fr + 16, fr + 32, fr + 48): gfx950's row swaps
+// (v_permlane16_swap / v_permlane32_swap: two VALU instructions) instead of __shfl_xor's ds_bpermute round trips through the LDS
+// queue, which sat in the dependent chain max -> exchange -> max -> exchange -> exp of every key tile.
+__device__ __forceinline__ float max_xor16(float v) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return max2_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+// max(v, v of lane ^ 32, also)
+__device__ __forceinline__ float max_xor32_and(float v, float also) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return max3_raw(__uint_as_float(r[0]), __uint_as_float(r[1]), also);
 }
 
 // Query-tile work list, two formats (`tcols`, an argument of the C entry points):
@@ -220,6 +238,19 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 #pragma unroll
         for (int n = 0; n < 2; ++n) oacc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
     float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    // The softmax denominators come out of the matrix pipe: one more A tile of ONES beside V^T gives sum_keys P^T[key][q] in every row
+    // of a 16 x 16 accumulator (all four registers of lane (g, fr) = the row sum of query fr, summed over the key groups of all four
+    // g) -- 4 MFMAs per key tile instead of 32 v_add + 2 cross-group exchanges per query tile in a VALU-bound loop.  The sum is
+    // taken over the bf16-rounded probabilities, the very operand O^T is accumulated from.
+    float4_t lacc[2] = {float4_t{0.f, 0.f, 0.f, 0.f}, float4_t{0.f, 0.f, 0.f, 0.f}};
+    short8_t ones;                                       // bf16 1.0 x 8, pinned in four registers for the whole kernel
+    {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+        u32x4_ w;
+        asm volatile("v_mov_b32 %0, 0x3f803f80\n\tv_mov_b32 %1, 0x3f803f80\n\tv_mov_b32 %2, 0x3f803f80\n\tv_mov_b32 %3, 0x3f803f80"
+                     : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]));
+        ones = __builtin_bit_cast(short8_t, w);
+    }
 
     // per-lane offsets inside an image.  K row reads: row 16 m + fr, chunk (4 ks + g) ^ (fr & 7).  V transposed reads:
     // lane (g, qq, pp) addresses row 32 sI + 16 h + 4 g + qq, hd columns 16 c + 4 pp .. + 3 = chunk (2 c) ^ x with
@@ -314,8 +345,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                 mm = max3_raw(mm, s[2][n][3], s[3][n][0]);
                 mm = max3_raw(mm, s[3][n][1], s[3][n][2]);
                 mm = max2_raw(mm, s[3][n][3]);
-                mm = max2_raw(mm, __shfl_xor(mm, 16, 64));
-                mm = max3_raw(mm, __shfl_xor(mm, 32, 64), mrun[n]);
+                mm = max_xor32_and(max_xor16(mm), mrun[n]);
                 mnew[n] = mm;
             }
             // the running maximum rarely moves after the first tiles: skip the rescale of O (32 multiplies) when no lane's did
@@ -323,7 +353,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const float alpha = __builtin_amdgcn_exp2f((mrun[n] - mnew[n]) * scale_log2e);
-                    lrun[n] *= alpha;
+                    lacc[n] *= alpha;
                     mrun[n] = mnew[n];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) oacc[c][n] *= alpha;
@@ -333,19 +363,10 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const float mls = mnew[n] * scale_log2e;
-                float sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -mls));
-                        s[m][n][r] = pv;
-                        sum[r] += pv;
-                    }
-                float st = (sum[0] + sum[1]) + (sum[2] + sum[3]);
-                st += __shfl_xor(st, 16, 64);
-                st += __shfl_xor(st, 32, 64);
-                lrun[n] += st;
+                    for (int r = 0; r < 4; ++r) s[m][n][r] = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -mls));
                 pfrag[0][n] = pack_frag(s[0][n], s[1][n]);
                 pfrag[1][n] = pack_frag(s[2][n], s[3][n]);
             }
@@ -370,6 +391,11 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     oacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt1[c], pfrag[1][n], oacc[c][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfrag[0][n], lacc[n], 0, 0, 0);
+                lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfrag[1][n], lacc[n], 0, 0, 0);
+            }
             RPO_FSTAMP(tg);
             RPO_FSTAMP_ADD(5, tf, tg);
 #if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
@@ -396,6 +422,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     for (int n = 0; n < 2; ++n) {
         const int qi = qw + 16 * n + fr;
         if (qi >= len) continue;
+        lrun[n] = lacc[n][0];
         const float inv = 1.0f / lrun[n];
         bf16_t* orow = o + (t0 + qi) * so + h * kFaHD;
 #pragma unroll
@@ -501,6 +528,15 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
 #pragma unroll
         for (int n = 0; n < 2; ++n) oacc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
     float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    float4_t lacc[2] = {float4_t{0.f, 0.f, 0.f, 0.f}, float4_t{0.f, 0.f, 0.f, 0.f}};     // softmax denominators from the matrix pipe (fa_fwd_kernel)
+    short8_t ones;                                       // bf16 1.0 x 8, pinned in four registers for the whole kernel
+    {
+        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
+        u32x4_ w;
+        asm volatile("v_mov_b32 %0, 0x3f803f80\n\tv_mov_b32 %1, 0x3f803f80\n\tv_mov_b32 %2, 0x3f803f80\n\tv_mov_b32 %3, 0x3f803f80"
+                     : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]));
+        ones = __builtin_bit_cast(short8_t, w);
+    }
 
     // K row reads: row 16 m + fr, chunk (4 ks + g) ^ 2 (fr & 7).  V transposed reads: lane (g, qq, pp) addresses row 16 h + 4 g + qq,
     // hd columns 16 c + 4 pp .. + 3 = chunk (2 c + (pp >> 1)) ^ 2 (4 (g & 1) + qq), byte 8 (pp & 1) inside it; h = immediate 4096.
@@ -575,15 +611,14 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
                 mm = max3_raw(mm, s[0][n][3], s[1][n][0]);
                 mm = max3_raw(mm, s[1][n][1], s[1][n][2]);
                 mm = max2_raw(mm, s[1][n][3]);
-                mm = max2_raw(mm, __shfl_xor(mm, 16, 64));
-                mm = max3_raw(mm, __shfl_xor(mm, 32, 64), mrun[n]);
+                mm = max_xor32_and(max_xor16(mm), mrun[n]);
                 mnew[n] = mm;
             }
             if (__builtin_amdgcn_ballot_w64(mnew[0] != mrun[0] || mnew[1] != mrun[1]) != 0) {
 #pragma unroll
                 for (int n = 0; n < 2; ++n) {
                     const float alpha = __builtin_amdgcn_exp2f((mrun[n] - mnew[n]) * scale_log2e);
-                    lrun[n] *= alpha;
+                    lacc[n] *= alpha;
                     mrun[n] = mnew[n];
 #pragma unroll
                     for (int c = 0; c < 8; ++c) oacc[c][n] *= alpha;
@@ -593,19 +628,10 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
                 const float mls = mnew[n] * scale_log2e;
-                float sum[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -mls));
-                        s[m][n][r] = pv;
-                        sum[r] += pv;
-                    }
-                float st = (sum[0] + sum[1]) + (sum[2] + sum[3]);
-                st += __shfl_xor(st, 16, 64);
-                st += __shfl_xor(st, 32, 64);
-                lrun[n] += st;
+                    for (int r = 0; r < 4; ++r) s[m][n][r] = __builtin_amdgcn_exp2f(fmaf(s[m][n][r], scale_log2e, -mls));
                 pfrag[n] = pack_frag(s[0][n], s[1][n]);
             }
             asm volatile("s_waitcnt lgkmcnt(0)"
@@ -620,6 +646,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
                     oacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[c], pfrag[n], oacc[c][n], 0, 0, 0);
+#pragma unroll
+            for (int n = 0; n < 2; ++n) lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfrag[n], lacc[n], 0, 0, 0);
         }
         cur = cur == 2 ? 0 : cur + 1;
     }
@@ -627,6 +655,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
     for (int n = 0; n < 2; ++n) {
         const int qi = qw + 16 * n + fr;
         if (qi >= len) continue;
+        lrun[n] = lacc[n][0];
         const float inv = 1.0f / lrun[n];
         bf16_t* orow = o + (t0 + qi) * so + h * kFa128HD;
 #pragma unroll

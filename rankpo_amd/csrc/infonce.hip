@@ -69,10 +69,11 @@ __device__ __forceinline__ float finish_score(float acc, float temperature, floa
 
 // two f32 -> one dword of two bf16 (round to nearest even, NaN kept) in ONE v_cvt_pk_bf16_f32; written as
 // `f32_to_bf16(a) | f32_to_bf16(b) << 16` hipcc converts each value on its own and merges them with a third instruction.
-__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {
-    unsigned r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
+__device__ __forceinline__ unsigned pack2_bf16(float a, float b) {     // a vector conversion, not asm: hipcc must see the instruction (hazards)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_));
 }
 
 // exp(v - m) as one FMA + one v_exp_f32

@@ -693,3 +693,23 @@ def test_generated_dkdv128_bodies_are_in_sync():
     gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_dkdv128_body.py")], capture_output=True,
                          text=True, check=True, env=env).stdout
     assert gen == open(os.path.join(root, "rankpo_amd", "csrc", "attention_dkdv128_gen.inc")).read()
+
+
+def test_no_valu_reads_a_transcendental_result_in_the_next_slot(tmp_path):
+    """gfx950: a VALU instruction must not read the result of the v_exp_f32 / v_rcp_f32 / ... issued right in front of it (one wait
+    state).  hipcc pads what it can see; the hand-placed asm streams and the one-instruction asm helpers it cannot.  Round 3's
+    forward attention kernel packed un-exponentiated scores at head_dim 128 exactly this way (asm v_cvt_pk_bf16_f32 scheduled right
+    behind its v_exp_f32) until the conversion became a compiler-visible vector conversion: this scans the ISA of every kernel of the
+    library, built with the flags of the real build (no GPU needed: hipcc cross-compiles)."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc")
+    root = os.path.join(os.path.dirname(__file__), "..")
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "rankpo_amd", "csrc"), "isa", f"ISA_DIR={tmp_path}"], check=True,
+                   capture_output=True, text=True)
+    files = sorted(str(p) for p in tmp_path.glob("*.s"))
+    assert len(files) == 8, files
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_trans_hazard.py")] + files, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:]
