@@ -337,14 +337,14 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
             float mnew[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float mm = max3_raw(s[0][n][0], s[0][n][1], s[0][n][2]);          // 16 scores of this lane: 8 v_max3_f32
-                mm = max3_raw(mm, s[0][n][3], s[1][n][0]);
-                mm = max3_raw(mm, s[1][n][1], s[1][n][2]);
-                mm = max3_raw(mm, s[1][n][3], s[2][n][0]);
-                mm = max3_raw(mm, s[2][n][1], s[2][n][2]);
-                mm = max3_raw(mm, s[2][n][3], s[3][n][0]);
-                mm = max3_raw(mm, s[3][n][1], s[3][n][2]);
-                mm = max2_raw(mm, s[3][n][3]);
+                float mm = max3_known(s[0][n][0], s[0][n][1], s[0][n][2]);          // 16 scores of this lane: 8 v_max3_f32
+                mm = max3_known(mm, s[0][n][3], s[1][n][0]);
+                mm = max3_known(mm, s[1][n][1], s[1][n][2]);
+                mm = max3_known(mm, s[1][n][3], s[2][n][0]);
+                mm = max3_known(mm, s[2][n][1], s[2][n][2]);
+                mm = max3_known(mm, s[2][n][3], s[3][n][0]);
+                mm = max3_known(mm, s[3][n][1], s[3][n][2]);
+                mm = max2_known(mm, s[3][n][3]);
                 mm = max_xor32_and(max_xor16(mm), mrun[n]);
                 mnew[n] = mm;
             }
@@ -607,10 +607,10 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
             float mnew[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
-                float mm = max3_raw(s[0][n][0], s[0][n][1], s[0][n][2]);
-                mm = max3_raw(mm, s[0][n][3], s[1][n][0]);
-                mm = max3_raw(mm, s[1][n][1], s[1][n][2]);
-                mm = max2_raw(mm, s[1][n][3]);
+                float mm = max3_known(s[0][n][0], s[0][n][1], s[0][n][2]);
+                mm = max3_known(mm, s[0][n][3], s[1][n][0]);
+                mm = max3_known(mm, s[1][n][1], s[1][n][2]);
+                mm = max2_known(mm, s[1][n][3]);
                 mm = max_xor32_and(max_xor16(mm), mrun[n]);
                 mnew[n] = mm;
             }

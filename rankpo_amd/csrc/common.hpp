@@ -112,6 +112,17 @@ __device__ __forceinline__ float max2_raw(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// the same on values hipcc KNOWS to be quiet numbers (MFMA results it has not lost track of): plain fmaxf, which then compiles to
+// v_max3_f32 / v_max_f32 without the canonicalising instruction, stays visible to hipcc's hazard recognizer and scheduler, and
+// does not cost the `s_nop 0` hipcc puts behind every asm statement whose result the next instruction reads.  The forward attention
+// kernels' score maxima use these: an asm instruction as the FIRST reader of an MFMA result is not covered by hipcc's wait states
+// for MFMA -> VALU reads (measured: 1 % slower than the asm form, two canonicalising instructions per chain survive; bit-identical)
+__device__ __forceinline__ float max3_known(float a, float b, float c) {
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
+}
+__device__ __forceinline__ float max2_known(float a, float b) {
+    return __builtin_fmaxf(a, b);
+}
 
 // ---- wave / block reductions (64-wide waves) -----------------------------------------------------
 __device__ __forceinline__ float wave_sum(float x) {
