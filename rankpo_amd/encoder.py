@@ -464,16 +464,20 @@ class LlamaEncoder(nn.Module):
             inv = self._inv_freq[key] = self._inv_freq["cpu"].to(pos.device)
         return RopeTables(torch.outer(pos.to(torch.float32), inv))
 
-    def _mask(self, attention_mask, L, dtype):
+    def _mask(self, attention_mask, L, dtype, right_padded=None):
         """None (pure causal attention, module docstring) when the MASK ITSELF is right-padded -- every row is ones followed
         by zeros -- else the boolean [N, 1, L, L] `causal & key-is-kept` mask HF builds from any attention_mask
         (modeling.py:219).  Decided from the mask, never from the config: a left-padded or holed batch through a
         default-config encoder must not attend to its pad tokens.  One host sync (this is the general padded path; the
-        packed training path has its own)."""
+        packed training path has its own) -- unless the caller already knows the answer: `right_padded` = what the packed
+        path's own check of this very mask found (`last_right_padded`), so a batch that fell back from it is not
+        synchronised on twice."""
         if attention_mask is None:
             return None
         m = attention_mask
-        if bool((m[:, 1:].ne(0) <= m[:, :-1].ne(0)).all()):
+        if right_padded is None:
+            right_padded = bool((m[:, 1:].ne(0) <= m[:, :-1].ne(0)).all())
+        if right_padded:
             return None
         keep = m.ne(0)[:, None, None, :]
         causal = torch.ones(L, L, dtype=torch.bool, device=m.device).tril()[None, None]
@@ -481,20 +485,20 @@ class LlamaEncoder(nn.Module):
         # nor read as a key), so that no softmax row is empty whatever the attention backend does with those
         return (keep & causal) | torch.eye(L, dtype=torch.bool, device=m.device)[None, None]
 
-    def hidden_states(self, input_ids, attention_mask=None):
+    def hidden_states(self, input_ids, attention_mask=None, right_padded=None):
         """Output of the last block, BEFORE the final RMSNorm."""
-        x, delta = self._stack(input_ids, attention_mask)
+        x, delta = self._stack(input_ids, attention_mask, right_padded)
         return x if delta is None else x + delta
 
-    def _stack(self, input_ids, attention_mask):
+    def _stack(self, input_ids, attention_mask, right_padded=None):
         x = self.embed_tokens(input_ids)
         N, L, _ = x.shape
         rope = self._rope(torch.arange(L, device=x.device))
-        mask = self._mask(attention_mask, L, x.dtype)
+        mask = self._mask(attention_mask, L, x.dtype, right_padded)
         return self._run_layers(x, rope, mask)
 
-    def forward(self, input_ids=None, attention_mask=None, return_dict=True, **_):
-        x, delta = self._stack(input_ids, attention_mask)
+    def forward(self, input_ids=None, attention_mask=None, return_dict=True, right_padded=None, **_):
+        x, delta = self._stack(input_ids, attention_mask, right_padded)
         h = _add_norm(x, delta, self.norm)[1]
         return EncoderOutput(last_hidden_state=h) if return_dict else (h,)
 
@@ -526,16 +530,20 @@ class LlamaEncoder(nn.Module):
         stats = []
         for _, m in batches:
             lens_d = m.sum(-1)
+            rp = (m[:, 1:].ne(0) <= m[:, :-1].ne(0)).all()                               # what `_mask` asks of a mask
             ok = (m[:, 1:] <= m[:, :-1]).all() & (lens_d > 0).all() & ((m == 0) | (m == 1)).all()
-            stats.append(torch.cat([lens_d.to(torch.int64), ok.to(torch.int64)[None]]))
+            stats.append(torch.cat([lens_d.to(torch.int64), ok.to(torch.int64)[None], rp.to(torch.int64)[None]]))
         info = torch.cat(stats).tolist()                                                   # the one sync
-        lens, o = [], 0
+        lens, o, oks = [], 0, []
+        self.last_right_padded = []          # per batch; a caller that falls back to the padded path hands it to forward()
         for _, m in batches:
             n = m.shape[0]
-            if not info[o + n]:
-                return None
+            oks.append(bool(info[o + n]))
+            self.last_right_padded.append(bool(info[o + n + 1]))
             lens += info[o:o + n]
-            o += n + 1
+            o += n + 2
+        if not all(oks):
+            return None
         ids_parts, pos_parts = [], []
         for ids, m in batches:
             L = m.shape[1]

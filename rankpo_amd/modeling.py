@@ -128,7 +128,10 @@ class ModelForTraining(nn.Module):
             pooled = self.model.pooled_last_token(inputs["input_ids"], inputs["attention_mask"])
             if pooled is not None:
                 return ops.pool_normalize(pooled[:, None, :], None, "cls", self.normalize_embeddings)
-        outputs = self.model(**inputs, return_dict=True)
+            # fell back: the packed path's check already synchronised on this mask once; its verdict spares the padded path's own
+            outputs = self.model(**inputs, return_dict=True, right_padded=self.model.last_right_padded[0])
+        else:
+            outputs = self.model(**inputs, return_dict=True)
         last_hidden_state = outputs.last_hidden_state
         attention_mask = inputs["attention_mask"]
         return ops.pool_normalize(last_hidden_state, attention_mask, self.pooling_mode, self.normalize_embeddings)
@@ -289,7 +292,8 @@ class ModelForInference(nn.Module):
                                     return_tensors="pt")
             inputs = {k: v.to(self.device) for k, v in inputs.items()}
             pooled = None
-            if mode == "last" and hasattr(self.model, "pooled_last_token"):
+            packed_tried = mode == "last" and hasattr(self.model, "pooled_last_token")
+            if packed_tried:
                 # right-padded batches (the tokenizer's default): packed tokens, no pad token is ever computed, the last block
                 # runs for the pooled rows only; ONE host sync per batch (the lengths); None for any other mask
                 pooled = self.model.pooled_last_token(inputs["input_ids"], inputs["attention_mask"])
@@ -298,8 +302,9 @@ class ModelForInference(nn.Module):
                     pooled = pooled.float()
                 emb = ops.pool_normalize(pooled[:, None, :], None, "cls", self.normalize_embeddings)
             else:
+                hint = {"right_padded": self.model.last_right_padded[0]} if packed_tried else {}
                 h = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
-                               return_dict=True).last_hidden_state
+                               return_dict=True, **hint).last_hidden_state
                 if h.dtype == torch.float16:        # the HIP kernels take f32 / bf16
                     h = h.float()
                 emb = ops.pool_normalize(h, inputs["attention_mask"], mode, self.normalize_embeddings)

@@ -713,3 +713,29 @@ def test_no_valu_reads_a_transcendental_result_in_the_next_slot(tmp_path):
     assert len(files) == 8, files
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_trans_hazard.py")] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
+
+
+def test_packed_path_verdict_spares_the_padded_paths_sync():
+    """`pooled_last_token_multi` looks at every mask once (its one host sync) and leaves, per batch, whether the mask is right-padded
+    in `last_right_padded`; `_mask(right_padded=...)` then decides without a second look at the tensor (advisor finding of round 2:
+    a batch that falls back synchronised twice).  Left-padded, holed and empty-row masks return None from the packed path."""
+    import torch
+    from rankpo_amd import encoder as PE
+    cfg = PE.llama_config(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2,
+                          num_key_value_heads=1, pad_token_id=0)
+    enc = PE.LlamaEncoder(cfg)
+    ids = torch.ones(3, 6, dtype=torch.int64)
+    left = torch.tensor([[0, 0, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1]])
+    right_with_empty_row = torch.tensor([[1, 1, 1, 0, 0, 0], [0, 0, 0, 0, 0, 0], [1, 1, 1, 1, 1, 1]])
+    assert enc.pooled_last_token_multi([(ids, left)]) is None and enc.last_right_padded == [False]
+    assert enc.pooled_last_token_multi([(ids, right_with_empty_row), (ids, left)]) is None
+    assert enc.last_right_padded == [True, False]         # an empty row fails the packed path, but the mask IS right-padded
+
+    class NoLook:                                           # a mask whose values must not be read
+        def __getattr__(self, name):
+            raise AssertionError(f"_mask touched the mask ({name}) although the verdict was given")
+    assert enc._mask(NoLook(), 6, torch.float32, right_padded=True) is None
+    m = enc._mask(left, 6, torch.float32, right_padded=False)
+    assert m.shape == (3, 1, 6, 6) and m.dtype == torch.bool
+    assert torch.equal(m, enc._mask(left, 6, torch.float32))                         # the verdict changes no result
+    assert enc._mask(right_with_empty_row, 6, torch.float32) is None
