@@ -1,4 +1,4 @@
-"""Stress test of the hand-written attention backward (random shapes, determinism, agreement with PyTorch's op).
+"""Stress test of the hand-written attention forward and backward (random shapes, determinism, agreement with PyTorch's op).
 usage: [HD=128] [ROPE=1] python tools/fa_stress.py [cases]   (HD: head_dim 64 / 128; ROPE=1: rotary folded into forward and backward)"""
 import os, sys
 import numpy as np, torch
@@ -31,6 +31,12 @@ for ci in range(cases):
         b = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, kt, SC, key_block=KB)
         assert all(torch.equal(x, y) for x, y in zip(a, b)), ("not deterministic", ci, lens)
     r = torch.ops.aten._flash_attention_forward(q, k, v, cu, cu, max(lens), max(lens), 0.0, True, False, scale=SC)
+    out2, lse2 = ops.flash_attn_varlen_fwd(q, k, v, cu, tiles, SC)
+    assert torch.equal(out, out2) and torch.equal(lse, lse2), ("forward not deterministic", ci, lens)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all(), ("forward non-finite", ci, lens)
+    ferr = (out.float() - r[0].float()).abs().max().item() / max(1.0, r[0].float().abs().max().item())
+    worst = max(worst, ferr)
+    assert ferr < 0.02, ("out", ferr, ci, nh, nkv, lens)
     d = torch.ops.aten._flash_attention_backward(go, q, k, v, r[0], r[1], cu, cu, max(lens), max(lens), 0.0, True, r[2], r[3], scale=SC)
     for name, x, y in zip(("dq", "dk", "dv"), a, d):
         assert torch.isfinite(x.float()).all(), (name, "non-finite", ci, lens)
