@@ -237,7 +237,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     for (int c = 0; c < 4; ++c)
 #pragma unroll
         for (int n = 0; n < 2; ++n) oacc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
-    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    float mrun[2] = {-1e30f, -1e30f};
     // The softmax denominators come out of the matrix pipe: one more A tile of ONES beside V^T gives sum_keys P^T[key][q] in every row
     // of a 16 x 16 accumulator (all four registers of lane (g, fr) = the row sum of query fr, summed over the key groups of all four
     // g) -- 4 MFMAs per key tile instead of 32 v_add + 2 cross-group exchanges per query tile in a VALU-bound loop.  The sum is
@@ -422,8 +422,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     for (int n = 0; n < 2; ++n) {
         const int qi = qw + 16 * n + fr;
         if (qi >= len) continue;
-        lrun[n] = lacc[n][0];
-        const float inv = 1.0f / lrun[n];
+        const float l = lacc[n][0];                      // every row of the ones-tile accumulator holds the row sum
+        const float inv = 1.0f / l;
         bf16_t* orow = o + (t0 + qi) * so + h * kFaHD;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
         }
         if (g == 0)
             lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
-                mrun[n] * scale + logf(lrun[n]);
+                mrun[n] * scale + logf(l);
     }
 }
 
@@ -527,7 +527,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
     for (int c = 0; c < 8; ++c)
 #pragma unroll
         for (int n = 0; n < 2; ++n) oacc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
-    float mrun[2] = {-1e30f, -1e30f}, lrun[2] = {0.f, 0.f};
+    float mrun[2] = {-1e30f, -1e30f};
     float4_t lacc[2] = {float4_t{0.f, 0.f, 0.f, 0.f}, float4_t{0.f, 0.f, 0.f, 0.f}};     // softmax denominators from the matrix pipe (fa_fwd_kernel)
     short8_t ones;                                       // bf16 1.0 x 8, pinned in four registers for the whole kernel
     {
@@ -655,8 +655,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
     for (int n = 0; n < 2; ++n) {
         const int qi = qw + 16 * n + fr;
         if (qi >= len) continue;
-        lrun[n] = lacc[n][0];
-        const float inv = 1.0f / lrun[n];
+        const float l = lacc[n][0];                      // every row of the ones-tile accumulator holds the row sum
+        const float inv = 1.0f / l;
         bf16_t* orow = o + (t0 + qi) * so + h * kFa128HD;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -667,7 +667,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd128_kernel(
         }
         if (g == 0)
             lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
-                mrun[n] * scale + logf(lrun[n]);
+                mrun[n] * scale + logf(l);
     }
 }
 
