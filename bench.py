@@ -498,7 +498,7 @@ class _StdoutToStderr:
 COMM_KEYS = ("backend", "ranks_seen", "world_size", "collectives_per_step", "allgather_calls_per_step", "allgather_bytes_per_rank",
              "allgather_wait_us", "allgather_wait_us_max", "allreduce_bytes", "allreduce_buckets", "allreduce_exposed_ms",
              "allreduce_exposed_ms_max", "late_buckets", "optimizer_state_partitioned", "param_allgather_exposed_ms", "loss_min_over_ranks", "loss_max_over_ranks", "loss_equal_over_ranks",
-             "params_in_sync", "ms_per_step_min_over_ranks", "ms_per_step_max_over_ranks", "timer")
+             "params_in_sync", "ms_per_step_min_over_ranks", "ms_per_step_max_over_ranks", "rebalance", "timer")
 
 
 class CommProbe:
@@ -574,7 +574,7 @@ class CommProbe:
         return [1e3 * (b - a) for a, b in pairs]
 
 
-def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=None):
+def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=None, balance=None):
     """The N > 1 part of the JSON line (also emitted by the world-1 `--force-dist` rehearsal and, on gloo, by
     `--rehearse-launch`): what the communicator saw and what the collectives cost, measured in this run.  Collective calls:
     every rank must call this."""
@@ -613,6 +613,12 @@ def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=Non
         "loss_min_over_ranks": lmin, "loss_max_over_ranks": lmax, "loss_equal_over_ranks": bool(lmin == lmax),
         "params_in_sync": in_sync,
         "ms_per_step_min_over_ranks": rnd(red(ms, dist.ReduceOp.MIN)), "ms_per_step_max_over_ranks": rnd(red(ms, dist.ReduceOp.MAX)),
+        # groups of the global batch re-dealt to the ranks by packed-token cost (distributed.rebalance_groups): the most loaded
+        # rank's cost over the mean, as the per-rank batches came and as they ran, averaged over the timed micro-steps
+        "rebalance": (None if not balance else {
+            "micro_steps": len(balance),
+            "max_over_mean_as_sampled": rnd(mean([max(b["cost_before"]) * len(b["cost_before"]) / sum(b["cost_before"]) for b in balance]), 4),
+            "max_over_mean_as_run": rnd(mean([max(b["cost_after"]) * len(b["cost_after"]) / sum(b["cost_after"]) for b in balance]), 4)}),
         "timer": ("HIP events on the launch stream around EmbeddingGather.wait / FlatGradAllReducer.finish" if probe.use_events
                   else "host clock (CPU rehearsal)"),
     }
@@ -656,15 +662,21 @@ def rehearse_launch(rank, world):
     dist.barrier()
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    from rankpo_amd.distributed import EmbeddingGather, FlatGradAllReducer
+    from rankpo_amd.distributed import EmbeddingGather, FlatGradAllReducer, rebalance_groups
     probe = CommProbe(use_events=False)
     probe.install()
     torch.manual_seed(0)
     lin = torch.nn.Linear(16, 4)
     red_ = FlatGradAllReducer(list(lin.parameters()), bucket_mb=1e-4)
     probe.enabled = True
-    steps, t0, loss = 3, time.perf_counter(), None
+    steps, t0, loss, bal = 3, time.perf_counter(), None, []
     for i in range(steps):
+        # token batches whose size grows with the rank, re-dealt by cost as the N > 1 bench does before every micro-step
+        Lq, Lp = 4 + rank, 8 + 4 * rank
+        qm = (torch.arange(Lq)[None, :] < torch.tensor([[Lq], [2]])).long()
+        pm = (torch.arange(Lp)[None, :] < torch.tensor([[Lp], [3], [Lp - 1], [1]])).long()
+        _, _, info = rebalance_groups({"input_ids": qm * 7, "attention_mask": qm}, {"input_ids": pm * 9, "attention_mask": pm})
+        bal.append(info)
         x = torch.full((6, 16), float(rank + i + 1))
         emb = lin(x)
         allrows = EmbeddingGather(emb).wait()                    # [W * 6, 4]
@@ -678,7 +690,7 @@ def rehearse_launch(rank, world):
         red_.zero_()
     probe.enabled = False
     flat = torch.cat([p_.detach().reshape(-1) for p_ in lin.parameters()])
-    comm = comm_block(probe, torch.device("cpu"), red_, loss, time.perf_counter() - t0, steps, flat_param=flat)
+    comm = comm_block(probe, torch.device("cpu"), red_, loss, time.perf_counter() - t0, steps, flat_param=flat, balance=bal)
     if rank == 0:
         print(json.dumps({"rehearsal": "launch", "n_gpus": world, "max_over_ranks": t.item(), "comm": comm}), flush=True)
     dist.barrier()
@@ -711,6 +723,11 @@ def main():
                     help="N > 1: optimizer state partitioned over the ranks (reduce-scatter + AdamW shard + parameter all-gather, "
                          "the reference's ZeRO-1) instead of replicated (all-reduce); auto = on when the replicated state would "
                          "force blocks to be checkpointed")
+    ap.add_argument("--balance", default="auto", choices=("auto", "on", "off"),
+                    help="N > 1: re-deal the (query + its passages) groups of the global batch to the ranks by packed-token cost "
+                         "before every micro-step (one small all-gather of token ids; the global batch, loss and gradient are "
+                         "unchanged): every step ends in a gather all ranks wait at, so it lasts as long as the rank with the most "
+                         "tokens.  auto = on when there is more than one rank")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: rank r uses device r %% device_count and the process group "
                          "runs on gloo (RCCL refuses two ranks on one device); exercises the whole N > 1 code path -- launch, "
@@ -814,14 +831,27 @@ def main():
     if multi:
         probe = CommProbe(use_events=True)
         probe.install()
+    balance = multi and (args.balance == "on" or (args.balance == "auto" and world > 1))
+    bal_log = []
+    pad_id = cfg.pad_token_id if cfg.pad_token_id is not None else 0
+
+    def dealt(b):
+        """This rank's micro-batch, after the global batch's groups were re-dealt by packed-token cost (inside the timed step)."""
+        if not balance:
+            return b
+        from rankpo_amd.distributed import rebalance_groups
+        q, p, info = rebalance_groups(b["query"], b["passage"], pad_id)
+        if probe is not None and probe.enabled:
+            bal_log.append(info)
+        return {"query": q, "passage": p}
     if args.workload == "cfg4":
         # RankPO stage (rankpo_trainer.py:570-587): policy = the bare encoder, no reference model (reference_free),
         # metrics stay on the device (one host copy per LOG step, not per micro-step)
         trainer = rankpo_amd.RankPOTrainer(enc, None, beta=2.0, temperature=temperature, loss_type="sigmoid",
                                            reference_free=True, rankpo_weight=1.0, sft_weight=0.0)
-        loss_fn = lambda b: trainer.get_batch_loss_metrics(enc, b, "train", sync_metrics=False)[0]
+        loss_fn = lambda b: trainer.get_batch_loss_metrics(enc, dealt(b), "train", sync_metrics=False)[0]
     else:
-        loss_fn = lambda b: model(**b)["loss"]
+        loss_fn = lambda b: model(**dealt(b))["loss"]
     ts = TrainStep(model.parameters(), loss_fn, lr=1e-5, max_grad_norm=1.0,
                    gradient_accumulation_steps=gas, total_steps=max(10, args.steps + args.warmup), warmup_ratio=0.1,
                    force_collectives=args.force_dist, partition_optimizer=partition)
@@ -870,7 +900,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
-        comm = comm_block(probe, device, ts.opt.reducer, losses[-1], t_local, args.steps, flat_param=ts.opt.flat_param)
+        comm = comm_block(probe, device, ts.opt.reducer, losses[-1], t_local, args.steps, flat_param=ts.opt.flat_param, balance=bal_log)
     pairs = world * B * (1 + K) * gas * args.steps
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
 
@@ -886,7 +916,8 @@ def main():
                                    (f"{args.workload}: {arch} contrastive, B={B}/GPU, K={K}, q_len={Lq}, p_len={Lp}, "
                                     f"T={temperature}, in-batch negs" + (", cross-device negs" if multi else "")),
                        "global_batch": world * B, "pairs_per_step": world * B * (1 + K) * gas,
-                       "parallelism": f"dp{world}", "optimizer": f"AdamW(flat, HIP) + clip 1.0, GAS={gas}", "micro_steps_per_step": gas,
+                       "parallelism": f"dp{world}" + (", groups re-dealt to ranks by packed-token cost every micro-step" if balance else ""),
+                       "optimizer": f"AdamW(flat, HIP) + clip 1.0, GAS={gas}", "micro_steps_per_step": gas,
                        "optimizer_state": (f"partitioned over {world} ranks (reduce-scatter, AdamW on 1/{world}, parameter all-gather)"
                                            if ts.opt.partition else "replicated (bucketed all-reduce)"),
                        "grad_checkpointing": "all blocks" if ckpt < 0 else f"first {ckpt} blocks",

@@ -9,6 +9,9 @@ on ROCm; "gloo" in the CPU tests).
   gather in flight during the query tower when the towers run one after the other.
 * `FlatGradAllReducer` -- data-parallel gradient mean over flat buckets (replaces DeepSpeed ZeRO-1's reduction;
   SURVEY.md §8e): buckets are all-reduced asynchronously as soon as backward has produced them.
+* `rebalance_groups` -- with cross-device negatives every step ends in a gather all ranks wait at, so a step lasts as long as the
+  rank with the most tokens; the (query + its passages) groups of the GLOBAL batch are re-dealt to the ranks by packed-token
+  cost before the encoder runs.  The global batch, hence the loss and its gradient, is unchanged.
 """
 from __future__ import annotations
 
@@ -30,6 +33,105 @@ def _all_gather_into(out: torch.Tensor, x: torch.Tensor, async_op=False):
         out.copy_(torch.stack(host).to(out.device))
         return None
     return dist.all_gather(list(out.unbind(0)), x, async_op=async_op)
+
+
+def deal_balanced(costs, hands: int) -> List[List[int]]:
+    """Deal len(costs) items (a multiple of `hands`) into `hands` hands of EQUAL size so that the most expensive hand is as cheap
+    as a greedy pass gets it: items by decreasing cost, each to the cheapest hand that is not full yet (longest-processing-time
+    first under a cardinality constraint, then pairwise swaps out of the most expensive hand while they help).  Deterministic (ties by index), so every rank computes the same deal from the same
+    costs.  Returns the item indices of each hand in increasing order."""
+    n = len(costs)
+    if hands <= 0 or n % hands:
+        raise ValueError(f"cannot deal {n} items into {hands} equal hands")
+    per = n // hands
+    total = [0.0] * hands
+    out: List[List[int]] = [[] for _ in range(hands)]
+    for i in sorted(range(n), key=lambda j: (-float(costs[j]), j)):
+        h = min((k for k in range(hands) if len(out[k]) < per), key=lambda k: (total[k], k))
+        out[h].append(i)
+        total[h] += float(costs[i])
+    # refinement: swap one item of the most expensive hand with one of another hand while that lowers the larger of the two totals
+    for _ in range(4 * n):
+        hi = max(range(hands), key=lambda k: (total[k], -k))
+        best = None
+        for lo in range(hands):
+            if lo == hi:
+                continue
+            for a in out[hi]:
+                for b in out[lo]:
+                    d = float(costs[a]) - float(costs[b])
+                    if d <= 0.0:
+                        continue
+                    new_max = max(total[hi] - d, total[lo] + d)
+                    if new_max < total[hi] - 1e-12 and (best is None or new_max < best[0]):
+                        best = (new_max, lo, a, b)
+        if best is None:
+            break
+        _, lo, a, b = best
+        d = float(costs[a]) - float(costs[b])
+        out[hi][out[hi].index(a)] = b
+        out[lo][out[lo].index(b)] = a
+        total[hi] -= d
+        total[lo] += d
+    return [sorted(h) for h in out]
+
+
+# cost of one packed sequence of L tokens in units of "token through the GEMMs": the projections and the MLP are linear in L, causal
+# attention is L^2 / 2; on the Llama-3.2-1B shape attention is ~19 % of the encoder's time at 4096-token rows (DESIGN.md §5)
+_ATTN_COST_AT = (4096, 0.25)
+
+
+def sequence_cost(lengths: torch.Tensor) -> torch.Tensor:
+    L = lengths.to(torch.float64)
+    return L * (1.0 + _ATTN_COST_AT[1] * L / _ATTN_COST_AT[0])
+
+
+def rebalance_groups(query: dict, passage: dict, pad_token_id: int = 0):
+    """query: {'input_ids', 'attention_mask'} [B, Lq]; passage: the same [B G, Lp] with the G passages of query b in rows
+    b G .. b G + G - 1 (the collators' layout, data_utils.py).  Every rank holds B such groups; returns this rank's B groups of a
+    re-deal of all W B groups that evens out the ranks' packed-token cost, plus the per-rank costs before and after (host
+    floats).  Mechanism: the padded widths are made equal over the ranks (all-reduce MAX), ids and masks are all-gathered (a few
+    MB of integers per step at the reference's shapes), every rank computes the same deal and keeps its hand -- no second
+    exchange.  One host sync (the lengths).  The union of the ranks' batches is the same set of groups as before, so with
+    cross-device negatives the loss (a mean over the global batch, modeling.py:287-314) and its gradient do not change; a rank's
+    OWN rows do (reference: the sampler's assignment of examples to ranks is random to begin with)."""
+    W, r = dist.get_world_size(), dist.get_rank()
+    B = query["input_ids"].shape[0]
+    G = passage["input_ids"].shape[0] // B
+    dev = query["input_ids"].device
+    widths = torch.tensor([query["input_ids"].shape[1], passage["input_ids"].shape[1]], dtype=torch.int64, device=dev)
+    if dist.get_backend() != "nccl" and widths.is_cuda:
+        wh = widths.cpu()
+        dist.all_reduce(wh, op=dist.ReduceOp.MAX)
+        widths = wh
+    else:
+        dist.all_reduce(widths, op=dist.ReduceOp.MAX)
+    Lq, Lp = (int(x) for x in widths.tolist())
+
+    def widen(t, width, value):
+        if t.shape[1] == width:
+            return t.contiguous()
+        out = torch.full((t.shape[0], width), value, dtype=t.dtype, device=t.device)
+        out[:, :t.shape[1]] = t
+        return out
+    # one block per rank: [B, Lq + G Lp] ids | the same for the masks
+    ids = torch.cat([widen(query["input_ids"], Lq, pad_token_id), widen(passage["input_ids"], Lp, pad_token_id).view(B, G * Lp)], 1)
+    msk = torch.cat([widen(query["attention_mask"], Lq, 0), widen(passage["attention_mask"], Lp, 0).view(B, G * Lp)], 1)
+    block = torch.stack([ids, msk.to(ids.dtype)]).contiguous()                       # [2, B, Lq + G Lp]
+    allb = torch.empty((W,) + tuple(block.shape), dtype=block.dtype, device=dev)
+    _all_gather_into(allb, block)
+    all_ids = allb[:, 0].reshape(W * B, Lq + G * Lp)
+    all_msk = allb[:, 1].reshape(W * B, Lq + G * Lp)
+    lens = torch.cat([all_msk[:, :Lq].sum(-1, keepdim=True), all_msk[:, Lq:].view(W * B, G, Lp).sum(-1)], 1)    # [W B, 1 + G]
+    cost = sequence_cost(lens).sum(-1).tolist()                                        # the one host sync
+    hands = deal_balanced(cost, W)
+    before = [sum(cost[k * B:(k + 1) * B]) for k in range(W)]
+    after = [sum(cost[i] for i in h) for h in hands]
+    mine = torch.tensor(hands[r], dtype=torch.int64, device=dev)
+    ids_r, msk_r = all_ids.index_select(0, mine), all_msk.index_select(0, mine)
+    q = {"input_ids": ids_r[:, :Lq].contiguous(), "attention_mask": msk_r[:, :Lq].contiguous().to(query["attention_mask"].dtype)}
+    p = {"input_ids": ids_r[:, Lq:].reshape(B * G, Lp), "attention_mask": msk_r[:, Lq:].reshape(B * G, Lp).to(passage["attention_mask"].dtype)}
+    return q, p, {"cost_before": before, "cost_after": after, "groups": hands[r]}
 
 
 class _AllGatherLocalGrad(torch.autograd.Function):

@@ -103,4 +103,8 @@ def test_two_ranks_end_to_end_on_one_gpu():
         assert comm["allgather_calls_per_step"] == 1.0 * (2 if extra else 1)          # one per micro-step
         assert comm["loss_equal_over_ranks"] is True and comm["params_in_sync"] is True and comm["late_buckets"] == 0
         assert comm["optimizer_state_partitioned"] == bool(extra)
+        # the global batch's groups were re-dealt to the ranks by packed-token cost before every micro-step (the loss equality
+        # above holds WITH the re-deal: the global batch is unchanged)
+        rb = comm["rebalance"]
+        assert rb["micro_steps"] == 3 * (2 if extra else 1) and 1.0 <= rb["max_over_mean_as_run"] <= rb["max_over_mean_as_sampled"]
         assert np.isfinite(out["loss_last"]) and out["loss_first"] != out["loss_last"]

@@ -322,7 +322,10 @@ def test_bench_launches_its_own_ranks():
     assert tuple(comm) == importlib.import_module("bench").COMM_KEYS
     assert all(v is not None for v in comm.values()), comm
     assert comm["backend"] == "gloo" and comm["ranks_seen"] == comm["world_size"] == 2
-    assert comm["allgather_calls_per_step"] == 1.0 and comm["collectives_per_step"] == 1.0 + comm["allreduce_buckets"]
+    # per step: the q||p gather + one all-reduce per bucket + the two collectives of the batch re-deal (widths, token ids)
+    assert comm["allgather_calls_per_step"] == 1.0 and comm["collectives_per_step"] == 3.0 + comm["allreduce_buckets"]
+    rb = comm["rebalance"]
+    assert rb["micro_steps"] == 3 and 1.0 <= rb["max_over_mean_as_run"] < rb["max_over_mean_as_sampled"]
     assert comm["late_buckets"] == 0 and comm["loss_equal_over_ranks"] is True and comm["params_in_sync"] is True
     assert comm["loss_min_over_ranks"] == comm["loss_max_over_ranks"] > 0
     assert 0 < comm["ms_per_step_min_over_ranks"] <= comm["ms_per_step_max_over_ranks"]
@@ -739,3 +742,80 @@ def test_packed_path_verdict_spares_the_padded_paths_sync():
     assert m.shape == (3, 1, 6, 6) and m.dtype == torch.bool
     assert torch.equal(m, enc._mask(left, 6, torch.float32))                         # the verdict changes no result
     assert enc._mask(right_with_empty_row, 6, torch.float32) is None
+
+
+def test_deal_balanced_is_an_equal_sized_partition_that_evens_out_the_cost():
+    from rankpo_amd.distributed import deal_balanced
+    rs = np.random.RandomState(5)
+    for hands, per in ((2, 8), (4, 8), (8, 8), (8, 1), (3, 5), (1, 7)):
+        c = rs.uniform(10.0, 20.0, size=hands * per).tolist()
+        h = deal_balanced(c, hands)
+        assert sorted(sum(h, [])) == list(range(hands * per)) and all(len(x) == per for x in h)
+        tot = [sum(c[i] for i in x) for x in h]
+        naive = [sum(c[k * per:(k + 1) * per]) for k in range(hands)]
+        assert max(tot) <= max(naive) + 1e-9
+        if per >= 5 and hands > 1:
+            assert max(tot) / (sum(tot) / hands) < 1.01 < max(naive) / (sum(naive) / hands) + 0.05     # within 1 % of perfect balance
+        assert h == deal_balanced(c, hands)                                        # deterministic: every rank computes the same deal
+    with pytest.raises(ValueError):
+        deal_balanced([1.0, 2.0, 3.0], 2)
+
+
+def _rebalance_worker(rank, world, port, ret):
+    """`rebalance_groups` under gloo: ranks hold batches of different padded widths; afterwards the union of the ranks' (query +
+    its passages) groups is the same set, every group is intact and in the collators' layout, the most expensive rank got cheaper,
+    and every rank reports the same deal."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from rankpo_amd.distributed import rebalance_groups, sequence_cost
+        B, G = 4, 3
+        rs = np.random.RandomState(100 + rank)
+        Lq, Lp = 6 + rank, 12 + 2 * rank                       # the collators pad to the longest row of the LOCAL batch
+        def side(n, L, tag0):
+            lens = rs.randint(1, L + 1, size=n)
+            lens[0] = L
+            m = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+            ids = rs.randint(100, 200, size=(n, L)) * m
+            return ids, m, lens
+        q_ids, q_m, q_len = side(B, Lq, 0)
+        p_ids, p_m, p_len = side(B * G, Lp, 0)
+        # tag every sequence with its global group id in its first token (all sequences have >= 1 token)
+        for b in range(B):
+            q_ids[b, 0] = 1000 + rank * B + b
+            p_ids[b * G:(b + 1) * G, 0] = 1000 + rank * B + b
+        q = {"input_ids": torch.tensor(q_ids), "attention_mask": torch.tensor(q_m)}
+        p = {"input_ids": torch.tensor(p_ids), "attention_mask": torch.tensor(p_m)}
+        q2, p2, info = rebalance_groups(q, p, pad_token_id=0)
+        ok = q2["input_ids"].shape[0] == B and p2["input_ids"].shape[0] == B * G
+        ok &= q2["input_ids"].shape == q2["attention_mask"].shape and p2["input_ids"].shape == p2["attention_mask"].shape
+        tags_q = q2["input_ids"][:, 0].tolist()
+        tags_p = p2["input_ids"][:, 0].view(B, G).tolist()
+        ok &= all(tp == [tq] * G for tq, tp in zip(tags_q, tags_p))              # groups intact, passages behind their query
+        ok &= bool((q2["input_ids"] * (1 - q2["attention_mask"])).eq(0).all())      # pad id under the mask's zeros
+        # right-padded still, token counts of my groups = what the deal says
+        ok &= bool((q2["attention_mask"][:, 1:] <= q2["attention_mask"][:, :-1]).all())
+        my_cost = float(sequence_cost(torch.cat([q2["attention_mask"].sum(-1, keepdim=True),
+                                                 p2["attention_mask"].sum(-1).view(B, G)], 1)).sum())
+        ok &= abs(my_cost - info["cost_after"][rank]) < 1e-6
+        ok &= max(info["cost_after"]) <= max(info["cost_before"]) + 1e-9
+        # the same set of groups overall, the same deal on every rank
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (tags_q, info["cost_after"], [int(q2["attention_mask"].sum()), int(p2["attention_mask"].sum())]))
+        ok &= sorted(sum((g[0] for g in gathered), [])) == [1000 + i for i in range(world * B)]
+        ok &= all(g[1] == gathered[0][1] for g in gathered)
+        tot = [None] * world
+        dist.all_gather_object(tot, int(q_m.sum() + p_m.sum()))
+        ok &= sum(tot) == sum(g[2][0] + g[2][1] for g in gathered)                    # no token lost or invented
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_rebalance_groups(world):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rebalance_worker, args=(world, 29761 + world, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
