@@ -108,3 +108,26 @@ def test_two_ranks_end_to_end_on_one_gpu():
         rb = comm["rebalance"]
         assert rb["micro_steps"] == 3 * (2 if extra else 1) and 1.0 <= rb["max_over_mean_as_run"] <= rb["max_over_mean_as_sampled"]
         assert np.isfinite(out["loss_last"]) and out["loss_first"] != out["loss_last"]
+
+
+def test_rebalanced_global_batch_gives_the_same_loss():
+    """`bench.py --balance on` re-deals the (query + passages) groups of the global batch to the ranks by packed-token cost
+    (distributed.rebalance_groups); the global batch is the same set of groups, so the cross-device InfoNCE loss of the first step
+    -- before any parameter moved -- must equal the un-balanced run's up to the summation order of a bf16 forward
+    (reference: modeling.py:287-314, the loss is a mean over the gathered batch)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    first = {}
+    for mode in ("on", "off"):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--share-gpu", "--workload", "tiny",
+                            "--steps", "1", "--warmup", "0", "--no-sweep", "--no-cpu-baseline", "--balance", mode],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert (out["comm"]["rebalance"] is not None) == (mode == "on")
+        assert out["comm"]["loss_equal_over_ranks"] is True
+        first[mode] = out["loss_first"]
+    assert abs(first["on"] - first["off"]) <= 2e-3 * abs(first["off"]), first
