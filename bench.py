@@ -50,6 +50,7 @@ WORKLOADS = {
     "cfg1": ("bge-small", 8, 5, 128, 256, 0.02, "f32"),
     "cfg4": ("llama-3.2-1b", 8, 1, 1280, 4096, 0.1, "bf16"),      # RankPO: reference_free, sigmoid, beta 2.0
     "cfg5": ("llama-3-8b", 8, 5, 1280, 4096, 0.02, "bf16"),       # 8B contrastive (per-GPU part of configs[4])
+    "cfg5r": ("llama-3-8b", 8, 1, 1280, 4096, 0.1, "bf16"),       # 8B RankPO + 0.5 x SFT (InfoNCE) loss: the other half of configs[4]
     "tiny": ("llama-tiny", 8, 5, 160, 512, 0.02, "bf16"),
 }
 
@@ -844,11 +845,13 @@ def main():
         if probe is not None and probe.enabled:
             bal_log.append(info)
         return {"query": q, "passage": p}
-    if args.workload == "cfg4":
+    rankpo_wl = args.workload in ("cfg4", "cfg5r")
+    if rankpo_wl:
         # RankPO stage (rankpo_trainer.py:570-587): policy = the bare encoder, no reference model (reference_free),
         # metrics stay on the device (one host copy per LOG step, not per micro-step)
         trainer = rankpo_amd.RankPOTrainer(enc, None, beta=2.0, temperature=temperature, loss_type="sigmoid",
-                                           reference_free=True, rankpo_weight=1.0, sft_weight=0.0)
+                                           reference_free=True, rankpo_weight=1.0,
+                                           sft_weight=0.5 if args.workload == "cfg5r" else 0.0)
         loss_fn = lambda b: trainer.get_batch_loss_metrics(enc, dealt(b), "train", sync_metrics=False)[0]
     else:
         loss_fn = lambda b: model(**dealt(b))["loss"]
@@ -911,8 +914,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": dtn, "data": "synthetic",
-            "config": {"workload": (f"{args.workload}: {arch} RankPO (reference_free, sigmoid, beta=2.0), B={B}/GPU, "
-                                    f"chosen+rejected, q_len={Lq}, p_len={Lp}, T={temperature}") if args.workload == "cfg4" else
+            "config": {"workload": (f"{args.workload}: {arch} RankPO (reference_free, sigmoid, beta=2.0"
+                                    + (", sft_weight=0.5" if args.workload == "cfg5r" else "") + f"), B={B}/GPU, "
+                                    f"chosen+rejected, q_len={Lq}, p_len={Lp}, T={temperature}") if rankpo_wl else
                                    (f"{args.workload}: {arch} contrastive, B={B}/GPU, K={K}, q_len={Lq}, p_len={Lp}, "
                                     f"T={temperature}, in-batch negs" + (", cross-device negs" if multi else "")),
                        "global_batch": world * B, "pairs_per_step": world * B * (1 + K) * gas,
