@@ -582,21 +582,28 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
 
 ATTN_KEY_BLOCK_HD128 = 128   # keys per block of the head_dim-128 dK/dV kernel
 ATTN_KEY_BLOCK = 256     # keys per entry of the dK/dV work list (256: one-wave-per-SIMD kernel; 64: the 8-wave kernel)
-ATTN_SWEEP_DOWN = False  # dK/dV schedule: key blocks of a (sequence, kv head) side by side, sweeping the query slices downwards
-ATTN_SWEEP_DOWN_HD128 = True   # ... at head_dim 128 (128-key blocks: 32 per 4096-token group = one XCD's CUs; the kernel waits on
-#                                its Q / dO stream there): group-ordered list + downward sweep measured 7.54 vs 7.78 ms (round 3)
+# dK/dV schedule: the key blocks of a (sequence, kv head) side by side on one XCD, all sweeping the query slices DOWNWARDS from the
+# last one, so that the group's Q / dO slices are fetched from HBM once and served from that XCD's L2 to the other blocks (round 1's
+# heaviest-first list + ascending sweep: 10 % L2 hits, ~4 x the algorithmic traffic).  Pure group order ends every XCD's list in one
+# group's blocks of very unequal weight (measured: -2.8 % at head_dim 64, +1.8 % at 128 against heaviest-first); with the last
+# ATTN_GROUP_TAIL of each XCD's work in heaviest-first order the launch ends in the lightest blocks: head_dim 128 7.64 -> 7.22 ms,
+# head_dim 64 equal to heaviest-first in time (7.27 vs 7.26 ms) at a fraction of its HBM traffic (tools/fa_tiles_ab.py, round 3).
+ATTN_SWEEP_DOWN = True
+ATTN_SWEEP_DOWN_HD128 = True
+ATTN_GROUP_TAIL = 0.35
 
 
 def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = ATTN_KEY_BLOCK, group_order=None):
     """int32 [n, 3] = (sequence id, kv head, first key of a key block): the key blocks of one (sequence, kv head) read the same
     Q / dO rows and are placed on one XCD by the kernel's block -> entry map.  block_n = 256 keys (default, the
     one-wave-per-SIMD dK/dV kernel at head_dim 64), 64 (the 8-wave kernel, A/B) or 128 (`ATTN_KEY_BLOCK_HD128`: the head_dim-128
-    dK/dV kernel); whoever builds a table with another block_n than the default passes the same key_block to
+    dK/dV kernel).  group_order: False = heaviest blocks of an XCD's eighth first, True = groups contiguous, a fraction f = groups
+    contiguous with the last f of the eighth's work heaviest-first (default: ATTN_GROUP_TAIL); whoever builds a table with another block_n than the default passes the same key_block to
     `flash_attn_varlen(_qkv)` as well -- it is an argument of the C call, not an environment switch."""
     if block_n not in (64, 128, 256):
         raise ValueError("attn_key_tile_table: block_n must be 64, 128 or 256")
     if group_order is None:
-        group_order = ATTN_SWEEP_DOWN_HD128 if block_n == 128 else ATTN_SWEEP_DOWN
+        group_order = ATTN_GROUP_TAIL if (ATTN_SWEEP_DOWN_HD128 if block_n == 128 else ATTN_SWEEP_DOWN) else False
     return _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order)
 
 
@@ -632,6 +639,13 @@ def _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order=False)
         sel = np.nonzero(xcd == x)[0]
         if not group_order:                     # heaviest blocks of the eighth first (round 1's schedule)
             sel = sel[np.argsort(-work[sel], kind="stable")]
+        elif group_order is not True:           # a fraction f in (0, 1): group order, but the LAST f of the eighth's work heaviest first
+            # (group order ends in one group's blocks of very unequal weight, with the XCD's other CUs idle behind the heavy
+            # ones; the heaviest-first tail ends in the lightest blocks)
+            csum = np.cumsum(work[sel])
+            cut = int(np.searchsorted(csum, (1.0 - float(group_order)) * csum[-1])) if len(sel) else 0
+            tail = sel[cut:]
+            sel = np.concatenate([sel[:cut], tail[np.argsort(-work[tail], kind="stable")]])
         # group_order: index order = (kv head, sequence longest first, first key ascending): the key blocks of a
         # (sequence, kv head) stay next to each other, heaviest first (pairs with sweep_down=True of the kernel)
         chunks.append(np.stack([seqs[sel], heads[sel], k0s[sel]], 1).astype(np.int32))

@@ -44,7 +44,9 @@ for rnd in range(int(os.environ.get("ROUNDS", "7"))):
 kts = {"heavy/up": (ops.attn_key_tile_table(lens, DEV, nkv, KB, group_order=False), False),
        "group/down": (ops.attn_key_tile_table(lens, DEV, nkv, KB, group_order=True), True),
        "heavy/down": (ops.attn_key_tile_table(lens, DEV, nkv, KB, group_order=False), True),
-       "group/up": (ops.attn_key_tile_table(lens, DEV, nkv, KB, group_order=True), False)}
+       "group/up": (ops.attn_key_tile_table(lens, DEV, nkv, KB, group_order=True), False),
+       **{f"group+heavy tail {f}/down": (ops.attn_key_tile_table(lens, DEV, nkv, KB, group_order=f), True)
+          for f in (0.2, 0.35, 0.5, 0.65, 0.8)}}
 tb3 = tabs["xcd3"]
 r2 = {n: [] for n in kts}
 for n, (ktab, down) in kts.items():
