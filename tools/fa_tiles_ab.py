@@ -11,7 +11,11 @@ nh, nkv, N, L = 32, 8, (48 if hd == 64 else 24), 4096
 KB = 256 if hd == 64 else 128
 SC = 1.0 / hd ** 0.5
 lens = torch.randint(L // 2, L + 1, (N,)); lens[0] = L
-lens = lens.tolist(); T = sum(lens)
+lens = lens.tolist()
+if os.environ.get("WITH_QUERIES", "0") == "1":           # the packed training batch: + 8 (hd 64) / 4 query rows of <= 1280 tokens + a filler row
+    lens += torch.randint(640, 1281, (8 if hd == 64 else 4,)).tolist()
+    lens += [(-sum(lens)) % 256 or 256]
+T = sum(lens)
 q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
 k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
 v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
