@@ -712,6 +712,10 @@ def main():
     ap.add_argument("--no-wgrad-mixed", action="store_true", help="A/B: weight-gradient GEMMs as autograd issues them")
     ap.add_argument("--fold-rope", type=int, default=2, choices=(0, 1, 2),
                     help="A/B: 2 = rotary folded into the attention forward (q) and backward epilogues, 1 = backward only, 0 = separate passes")
+    ap.add_argument("--dkdv-heaviest-first", action="store_true",
+                    help="A/B: round 1's dK/dV work list (heaviest blocks first, ascending sweep) instead of group order with a heaviest-first tail")
+    ap.add_argument("--dkdv-tail", type=float, default=None,
+                    help="A/B: fraction of every XCD's dK/dV work that runs heaviest-first behind the group-ordered part (ops.ATTN_GROUP_TAIL)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-sweep", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
@@ -787,6 +791,11 @@ def main():
     if args.no_wgrad_mixed:
         rankpo_amd.ops.WGRAD_MIXED = False
     rankpo_amd.encoder.FOLD_ROPE = args.fold_rope
+    if args.dkdv_heaviest_first:
+        rankpo_amd.ops.ATTN_SWEEP_DOWN = rankpo_amd.ops.ATTN_SWEEP_DOWN_HD128 = False
+    if args.dkdv_tail is not None:
+        rankpo_amd.ops.ATTN_SWEEP_DOWN = rankpo_amd.ops.ATTN_SWEEP_DOWN_HD128 = True
+        rankpo_amd.ops.ATTN_GROUP_TAIL = args.dkdv_tail
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
                                         negatives_cross_device=multi, unpad=not args.padded).train()
     hook_attn_tables()

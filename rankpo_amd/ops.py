@@ -582,15 +582,16 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
 
 ATTN_KEY_BLOCK_HD128 = 128   # keys per block of the head_dim-128 dK/dV kernel
 ATTN_KEY_BLOCK = 256     # keys per entry of the dK/dV work list (256: one-wave-per-SIMD kernel; 64: the 8-wave kernel)
-# dK/dV schedule: the key blocks of a (sequence, kv head) side by side on one XCD, all sweeping the query slices DOWNWARDS from the
-# last one, so that the group's Q / dO slices are fetched from HBM once and served from that XCD's L2 to the other blocks (round 1's
-# heaviest-first list + ascending sweep: 10 % L2 hits, ~4 x the algorithmic traffic).  Pure group order ends every XCD's list in one
-# group's blocks of very unequal weight (measured: -2.8 % at head_dim 64, +1.8 % at 128 against heaviest-first); with the last
-# ATTN_GROUP_TAIL of each XCD's work in heaviest-first order the launch ends in the lightest blocks: head_dim 128 7.64 -> 7.22 ms,
-# head_dim 64 equal to heaviest-first in time (7.27 vs 7.26 ms) at a fraction of its HBM traffic (tools/fa_tiles_ab.py, round 3).
-ATTN_SWEEP_DOWN = True
+# dK/dV schedule.  False: heaviest blocks of every XCD's eighth first, ascending sweep (round 1).  True: the key blocks of a
+# (sequence, kv head) side by side on one XCD, all sweeping the query slices DOWNWARDS from the last one, so that the group's Q / dO
+# slices are fetched from HBM once and served from that XCD's L2 to the other blocks.  Measured INSIDE the training step, same box
+# (`bench.py --dkdv-heaviest-first` / `--dkdv-tail f`): head_dim 64 heaviest-first 7.93 ms per backward call, group order with a
+# heaviest-first tail of 35 % / 60 % / ~100 % of the work 8.22 / 8.12 / 8.02; head_dim 128 heaviest-first 15.61, pure group order
+# 14.75, tails of 20 % / 35 % 14.75 / 14.87.  (Stand-alone A/Bs on one batch of long rows, tools/fa_tiles_ab.py, ranked the 35 % tail
+# first at both head dims -- 7.22 vs 7.64 ms at head_dim 128 -- and did not carry over to the step: the defaults follow the step.)
+ATTN_SWEEP_DOWN = False
 ATTN_SWEEP_DOWN_HD128 = True
-ATTN_GROUP_TAIL = 0.35
+ATTN_GROUP_TAIL = 0.0          # fraction of every XCD's work that runs heaviest-first BEHIND the group-ordered part (0: pure group order)
 
 
 def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = ATTN_KEY_BLOCK, group_order=None):
@@ -598,12 +599,12 @@ def attn_key_tile_table(lens, device, num_kv_heads: int, block_n: int = ATTN_KEY
     Q / dO rows and are placed on one XCD by the kernel's block -> entry map.  block_n = 256 keys (default, the
     one-wave-per-SIMD dK/dV kernel at head_dim 64), 64 (the 8-wave kernel, A/B) or 128 (`ATTN_KEY_BLOCK_HD128`: the head_dim-128
     dK/dV kernel).  group_order: False = heaviest blocks of an XCD's eighth first, True = groups contiguous, a fraction f = groups
-    contiguous with the last f of the eighth's work heaviest-first (default: ATTN_GROUP_TAIL); whoever builds a table with another block_n than the default passes the same key_block to
+    contiguous with the last f of the eighth's work heaviest-first (an A/B knob: `ATTN_GROUP_TAIL`); whoever builds a table with another block_n than the default passes the same key_block to
     `flash_attn_varlen(_qkv)` as well -- it is an argument of the C call, not an environment switch."""
     if block_n not in (64, 128, 256):
         raise ValueError("attn_key_tile_table: block_n must be 64, 128 or 256")
     if group_order is None:
-        group_order = ATTN_GROUP_TAIL if (ATTN_SWEEP_DOWN_HD128 if block_n == 128 else ATTN_SWEEP_DOWN) else False
+        group_order = (ATTN_GROUP_TAIL or True) if (ATTN_SWEEP_DOWN_HD128 if block_n == 128 else ATTN_SWEEP_DOWN) else False
     return _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order)
 
 

@@ -459,16 +459,16 @@ def test_key_block_table_properties():
 
 
 def test_key_block_table_group_order():
-    """The group-ordered dK/dV work list (pairs with sweep_down): every (sequence, kv head, key block) exactly once, a group on ONE
-    XCD eighth and CONTIGUOUS there with its key blocks ascending (the heaviest first), eighths padded with entries the kernel
-    skips.  The default (`ATTN_GROUP_TAIL`): the same up to the last 35 % of an eighth's work, which runs heaviest-first."""
+    """The group-ordered dK/dV work list (pairs with sweep_down; the default at head_dim 128): every (sequence, kv head, key block)
+    exactly once, a group on ONE XCD eighth and CONTIGUOUS there with its key blocks ascending (the heaviest first), eighths padded
+    with entries the kernel skips.  With a tail fraction f (an A/B knob): the same up to the last f of an eighth's work, which runs
+    heaviest-first."""
     from rankpo_amd import ops
     rs = np.random.RandomState(2)
     for bn, nkv, lens in ((128, 8, rs.randint(1, 4097, size=19).tolist()), (128, 2, [5, 300, 129, 128, 1]), (256, 4, [700, 256, 3])):
-        # the default: group order with a heaviest-first tail -- the same set, groups still on one eighth, the head of every eighth
-        # in group order, its tail in non-increasing work
-        d = ops.attn_key_tile_table(lens, "cpu", nkv, block_n=bn).numpy()
-        g = ops.attn_key_tile_table(lens, "cpu", nkv, block_n=bn, group_order=True).numpy()
+        f = 0.35
+        d = ops.attn_key_tile_table(lens, "cpu", nkv, block_n=bn, group_order=f).numpy()
+        g = ops.attn_key_tile_table(lens, "cpu", nkv, block_n=bn, group_order=True if bn == 256 else None).numpy()   # 128: the default
         assert d.shape == g.shape and sorted(map(tuple, d.tolist())) == sorted(map(tuple, g.tolist()))
         per_ = d.shape[0] // 8
         for x in range(8):
@@ -476,7 +476,7 @@ def test_key_block_table_group_order():
             nreal = int((gc[:, 2] < (1 << 30)).sum())
             assert sorted(map(tuple, dc[:nreal].tolist())) == sorted(map(tuple, gc[:nreal].tolist()))     # the same eighth
             work = np.array([lens[s_] - k_ for s_, _, k_ in gc[:nreal].tolist()], dtype=np.int64)
-            cut = int(np.searchsorted(np.cumsum(work), (1.0 - ops.ATTN_GROUP_TAIL) * work.sum())) if nreal else 0
+            cut = int(np.searchsorted(np.cumsum(work), (1.0 - f) * work.sum())) if nreal else 0
             assert (dc[:cut] == gc[:cut]).all()
             wt = np.array([lens[s_] - k_ for s_, _, k_ in dc[cut:nreal].tolist()], dtype=np.int64)
             assert (np.diff(wt) <= 0).all()
