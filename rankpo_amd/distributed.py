@@ -99,14 +99,20 @@ def rebalance_groups(query: dict, passage: dict, pad_token_id: int = 0):
     B = query["input_ids"].shape[0]
     G = passage["input_ids"].shape[0] // B
     dev = query["input_ids"].device
-    widths = torch.tensor([query["input_ids"].shape[1], passage["input_ids"].shape[1]], dtype=torch.int64, device=dev)
+    if passage["input_ids"].shape[0] != B * G or B == 0:
+        raise ValueError(f"rebalance_groups: {passage['input_ids'].shape[0]} passages are not a whole number of groups for {B} queries")
+    # widths to agree on, and the batch shape every rank must share (max of x and of -x = min: every rank sees a mismatch and raises)
+    widths = torch.tensor([query["input_ids"].shape[1], passage["input_ids"].shape[1], B, -B, G, -G], dtype=torch.int64, device=dev)
     if dist.get_backend() != "nccl" and widths.is_cuda:
         wh = widths.cpu()
         dist.all_reduce(wh, op=dist.ReduceOp.MAX)
         widths = wh
     else:
         dist.all_reduce(widths, op=dist.ReduceOp.MAX)
-    Lq, Lp = (int(x) for x in widths.tolist())
+    Lq, Lp, Bmax, nBmin, Gmax, nGmin = (int(x) for x in widths.tolist())
+    if Bmax != -nBmin or Gmax != -nGmin:
+        raise ValueError(f"rebalance_groups: the ranks hold different batch shapes (queries {-nBmin}..{Bmax}, passages per query "
+                         f"{-nGmin}..{Gmax}); the re-deal needs equal per-rank batches (drop_last)")
 
     def widen(t, width, value):
         if t.shape[1] == width:

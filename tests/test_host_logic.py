@@ -823,6 +823,13 @@ def _rebalance_worker(rank, world, port, ret):
         tot = [None] * world
         dist.all_gather_object(tot, int(q_m.sum() + p_m.sum()))
         ok &= sum(tot) == sum(g[2][0] + g[2][1] for g in gathered)                    # no token lost or invented
+        # unequal per-rank batches: EVERY rank raises (nobody is left waiting inside the gather)
+        nb = B - 1 if rank == 1 else B
+        try:
+            rebalance_groups({k: v[:nb] for k, v in q.items()}, {k: v[:nb * G] for k, v in p.items()})
+            ok = False
+        except ValueError as e:
+            ok &= "different batch shapes" in str(e)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
