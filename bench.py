@@ -712,6 +712,9 @@ def main():
     ap.add_argument("--no-wgrad-mixed", action="store_true", help="A/B: weight-gradient GEMMs as autograd issues them")
     ap.add_argument("--fold-rope", type=int, default=2, choices=(0, 1, 2),
                     help="A/B: 2 = rotary folded into the attention forward (q) and backward epilogues, 1 = backward only, 0 = separate passes")
+    ap.add_argument("--lib", default=None,
+                    help="A/B: another build of librankpo_hip.so (tools/exp/build_variant.sh) instead of the in-tree one, for an A/B of "
+                         "kernel variants INSIDE the training step (stand-alone kernel A/Bs have ranked schedules the step did not)")
     ap.add_argument("--dkdv-heaviest-first", action="store_true",
                     help="A/B: round 1's dK/dV work list (heaviest blocks first, ascending sweep) instead of group order with a heaviest-first tail")
     ap.add_argument("--dkdv-tail", type=float, default=None,
@@ -774,6 +777,8 @@ def main():
 
     import rankpo_amd
     from rankpo_amd import _lib
+    if args.lib:
+        _lib.LIB_PATH = os.path.abspath(args.lib)
     from rankpo_amd.encoder import build_encoder
     from rankpo_amd.train_step import TrainStep
 
