@@ -92,6 +92,11 @@ int rpo_infonce_fwd(const void* q, const void* p, int64_t Q, int64_t P, int64_t 
                     float temperature, int target_mode, void* scores_out, float* lse_out, float* loss_out,
                     void* workspace, size_t workspace_bytes, rpo_stream_t stream);
 
+/* Fault injection for the tests (not on the hot path): sets every arrival-counter slot of the multi-block single-launch
+ * forward (Q <= 64 with several blocks, e.g. the 64 x 384 matrix of 8 ranks) to `word`, as a launch that never finished
+ * would leave it.  The next rpo_infonce_fwd must still write lse and loss (the slots are epoch-stamped). */
+int rpo_infonce_debug_poison_tickets(uint64_t word, rpo_stream_t stream);
+
 /* Backward of (2): gradients of grad_loss[0] * loss with respect to the caller's OWN rows only
  * (q rows [q_row0, q_row0 + q_rows), p rows [p_row0, p_row0 + p_rows)): with cross-device negatives
  * the other rows of the gathered matrices are constants (modeling.py:374-377), so nothing else is

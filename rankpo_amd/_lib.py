@@ -45,6 +45,7 @@ SIGNATURES = {
     "rpo_pool_normalize_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),
     "rpo_pool_normalize_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _f32, _vp, _vp, _vp]),
     "rpo_infonce_workspace_bytes": (_sz, [_i64, _i64, _i64, _i32]),
+    "rpo_infonce_debug_poison_tickets": (C.c_int, [C.c_uint64, _vp]),
     "rpo_infonce_fwd": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _f32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "rpo_infonce_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _f32, _i32, _i64, _i64, _i64, _i64,
                                   _vp, _vp, _vp, _sz, _vp]),

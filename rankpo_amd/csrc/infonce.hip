@@ -665,16 +665,21 @@ __device__ __forceinline__ void skinny_fused_finalize(int tid, int64_t Q, int ng
     if (tid == 0) loss_out[0] = tot / (float)Q;
 }
 
-// Arrival counters of the multi-block launches (one slot per launch, handed out round-robin by the host): zero at module
-// load, and the last block to arrive puts its slot back to zero, so no memset launch precedes the kernel.
-constexpr int kSkinnyTicketSlots = 64;
-__device__ unsigned g_skinny_ticket[kSkinnyTicketSlots];
+// Arrival counters of the multi-block launches: one 64-bit slot per launch, handed out round-robin by the host together with an
+// EPOCH (the launch's sequence number / slot count + 1, never 0): word = epoch << 32 | blocks arrived.  A block whose epoch is
+// not the word's starts the count over, so a slot needs neither a memset in front of the launch nor a reset behind it, and a
+// launch that never finished (a fault, an abort) cannot leave a count behind that a later launch on the slot would inherit
+// (round 3's plain counters did: the slot's next launches then never saw `gridDim.x - 1` and left lse / loss unwritten without
+// an error -- advisor, round 3).  Two launches on ONE slot in flight at the same time would still disturb each other: that takes
+// kSkinnyTicketSlots launches of this kernel in flight at once.
+constexpr int kSkinnyTicketSlots = 1024;
+__device__ unsigned long long g_skinny_ticket[kSkinnyTicketSlots];
 
 template <typename T, int NG>
 __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
     const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
     int scale, int do_stats, int64_t group, T* __restrict__ scores, float2* __restrict__ partial,
-    float* __restrict__ lse_out, float* __restrict__ loss_out, int ticket_slot) {
+    float* __restrict__ lse_out, float* __restrict__ loss_out, int ticket_slot, unsigned ticket_epoch) {
     typedef typename Mma<T>::Frag Frag;
     constexpr int CE = 16 / (int)sizeof(T);   // elements per chunk
     constexpr int SE = 4 * CE;                // elements per 64-byte K segment
@@ -749,12 +754,17 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
     __shared__ int s_last;
     __syncthreads();                                  // the block's stores happen-before thread 0's release below
     if (tid == 0) {
-        unsigned* ticket = g_skinny_ticket + ticket_slot;
+        unsigned long long* ticket = g_skinny_ticket + ticket_slot;
         // release: the block's stores (ordered before this by the barrier) are visible to whoever reads the ticket; acquire: the
-        // last arriver sees every other block's
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t == gridDim.x - 1);
-        if (s_last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the slot's next launch
+        // last arriver sees every other block's.  (A compare-and-swap loop instead of one fetch-add: the stale-epoch case has to
+        // replace the word, not add to it; the loop retries only when another block arrived in between.)
+        unsigned long long seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+        do {
+            const unsigned arrived = (unsigned)(seen >> 32) == ticket_epoch ? (unsigned)seen : 0u;
+            want = ((unsigned long long)ticket_epoch << 32) | (arrived + 1u);
+        } while (!__hip_atomic_compare_exchange_strong(ticket, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+        s_last = ((unsigned)want == gridDim.x);
     }
     __syncthreads();
     if (!s_last) return;
@@ -1298,17 +1308,22 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         const bool one_block = pl.nPb <= kSkinnyMaxFusedGroups && bytes <= 384 * 1024;
         const unsigned nblk = one_block ? 1u : (unsigned)npass;
         // several blocks: the last block to arrive finalizes (one launch; needs the scores in memory for the positives' column)
-        static std::atomic<unsigned> next_slot{0};
-        const int slot = (nblk > 1 && do_stats && scores_out != nullptr)
-                             ? (int)(next_slot.fetch_add(1, std::memory_order_relaxed) % (unsigned)kSkinnyTicketSlots) : -1;
+        static std::atomic<unsigned long long> next_launch{0};
+        int slot = -1;
+        unsigned epoch = 0;
+        if (nblk > 1 && do_stats && scores_out != nullptr) {
+            const unsigned long long seq = next_launch.fetch_add(1, std::memory_order_relaxed);
+            slot = (int)(seq % (unsigned)kSkinnyTicketSlots);
+            epoch = (unsigned)(seq / (unsigned)kSkinnyTicketSlots) + 1u;       // never 0: a zero-initialised slot matches no launch
+        }
         fused_finalize = do_stats && (nblk == 1 || slot >= 0);
         const dim3 grid(nblk), block(kSkinnyThreads);
         if (ng == 4)
             RPO_LAUNCH((sim_skinny_kernel<T, 4>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d, temperature, scale,
-                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out, slot);
+                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out, slot, epoch);
         else
             RPO_LAUNCH((sim_skinny_kernel<T, 1>), grid, block, 0, st, (const T*)q, (const T*)p, Q, P, d, temperature, scale,
-                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out, slot);
+                       do_stats ? 1 : 0, P / Q, (T*)scores_out, partial, lse_out, loss_out, slot, epoch);
     } else {
         RPO_LAUNCH(sim_rowwise_kernel<T>, dim3((unsigned)Q), dim3(256), 0, st, (const T*)q, (const T*)p, Q,
                            P, d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial);
@@ -1368,6 +1383,19 @@ static int check_common(const void* q, const void* p, int64_t Q, int64_t P, int6
 }
 
 }  // namespace
+
+namespace {
+__global__ void skinny_ticket_poison_kernel(unsigned long long word) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < kSkinnyTicketSlots) g_skinny_ticket[i] = word;
+}
+}  // namespace
+
+extern "C" int rpo_infonce_debug_poison_tickets(uint64_t word, rpo_stream_t stream) {
+    hipStream_t st = (hipStream_t)stream;
+    RPO_LAUNCH(skinny_ticket_poison_kernel, dim3((kSkinnyTicketSlots + 255) / 256), dim3(256), 0, st, (unsigned long long)word);
+    return rpo_launch_status();
+}
 
 extern "C" size_t rpo_infonce_workspace_bytes(int64_t Q, int64_t P, int64_t d, int dtype) {
     if (Q <= 0 || P <= 0 || d <= 0) return 0;

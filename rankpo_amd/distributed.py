@@ -97,19 +97,27 @@ def rebalance_groups(query: dict, passage: dict, pad_token_id: int = 0):
     OWN rows do (reference: the sampler's assignment of examples to ranks is random to begin with)."""
     W, r = dist.get_world_size(), dist.get_rank()
     B = query["input_ids"].shape[0]
-    G = passage["input_ids"].shape[0] // B
+    n_pass = passage["input_ids"].shape[0]
+    G = n_pass // B if B else 0
+    # A rank-local problem (an empty batch, passages that are not a whole number of groups) must not raise on THIS rank alone: its
+    # peers would sit in the all-reduce below until the process-group timeout.  The verdict travels in the same all-reduce as the
+    # widths, so every rank raises together.
+    local_ok = B > 0 and G > 0 and n_pass == B * G
     dev = query["input_ids"].device
-    if passage["input_ids"].shape[0] != B * G or B == 0:
-        raise ValueError(f"rebalance_groups: {passage['input_ids'].shape[0]} passages are not a whole number of groups for {B} queries")
     # widths to agree on, and the batch shape every rank must share (max of x and of -x = min: every rank sees a mismatch and raises)
-    widths = torch.tensor([query["input_ids"].shape[1], passage["input_ids"].shape[1], B, -B, G, -G], dtype=torch.int64, device=dev)
+    widths = torch.tensor([query["input_ids"].shape[1], passage["input_ids"].shape[1], B, -B, G, -G, 0 if local_ok else 1],
+                          dtype=torch.int64, device=dev)
     if dist.get_backend() != "nccl" and widths.is_cuda:
         wh = widths.cpu()
         dist.all_reduce(wh, op=dist.ReduceOp.MAX)
         widths = wh
     else:
         dist.all_reduce(widths, op=dist.ReduceOp.MAX)
-    Lq, Lp, Bmax, nBmin, Gmax, nGmin = (int(x) for x in widths.tolist())
+    Lq, Lp, Bmax, nBmin, Gmax, nGmin, any_bad = (int(x) for x in widths.tolist())
+    if any_bad:
+        mine = "" if local_ok else f" (this rank: {n_pass} passages for {B} queries)"
+        raise ValueError(f"rebalance_groups: on at least one rank the passages are not a whole number of groups for its queries, or "
+                         f"the batch is empty{mine}")
     if Bmax != -nBmin or Gmax != -nGmin:
         raise ValueError(f"rebalance_groups: the ranks hold different batch shapes (queries {-nBmin}..{Bmax}, passages per query "
                          f"{-nGmin}..{Gmax}); the re-deal needs equal per-rank batches (drop_last)")

@@ -66,7 +66,7 @@ class RankPOTrainer:
             for p in self.ref_model.parameters():
                 p.requires_grad_(False)
         self._stored_metrics = defaultdict(lambda: defaultdict(list))
-        self._pending_metrics = []           # device tensors awaiting their one host copy
+        self._pending_metrics = None         # (prefix, device SUM of the metric vectors since the last log, count): O(1) memory
 
     # -- knobs -> C struct --------------------------------------------------------------------------
     def _cfg(self) -> ops.RankPOConfig:
@@ -179,8 +179,13 @@ class RankPOTrainer:
             loss, metrics = self.get_batch_loss_metrics(model, inputs, train_eval="train")
             self.store_metrics(metrics, train_eval="train")
             return (loss, metrics)
-        loss, handle = self.get_batch_loss_metrics(model, inputs, train_eval="train", sync_metrics=False)
-        self._pending_metrics.append(handle)
+        loss, (prefix, mvec) = self.get_batch_loss_metrics(model, inputs, train_eval="train", sync_metrics=False)
+        # a running device-side sum (one 9-float add per micro-step): bounded memory however rarely `log` is called
+        if self._pending_metrics is None:
+            self._pending_metrics = (prefix, mvec.detach().clone(), 1)
+        else:
+            _, acc, n = self._pending_metrics
+            self._pending_metrics = (prefix, acc.add_(mvec.detach()), n + 1)
         return loss
 
     # -- rankpo_trainer.py:626-645 --------------------------------------------------------------------
@@ -189,19 +194,22 @@ class RankPOTrainer:
             self._stored_metrics[train_eval][key].append(value)
 
     def _flush_pending(self):
-        """Resolve the device-side metric vectors of the micro-steps since the last log: the mean over the steps is taken on
-        the device first (the mean over ranks and over steps commute), then ONE all-reduce + ONE host copy."""
-        if not self._pending_metrics:
+        """Resolve the device-side metric sum of the micro-steps since the last log: the mean over the steps is taken on
+        the device first (the mean over ranks and over steps commute), then ONE all-reduce + ONE host copy.
+        COLLECTIVE when torch.distributed is up: every rank must get here, see `log`."""
+        if self._pending_metrics is None:
             return
-        n = len(self._pending_metrics)
-        prefix = self._pending_metrics[0][0]
-        mean = torch.stack([m.detach() for _, m in self._pending_metrics]).mean(0)
-        self._pending_metrics = []
-        vals = self.resolve_metrics((prefix, mean))
+        prefix, acc, n = self._pending_metrics
+        self._pending_metrics = None
+        vals = self.resolve_metrics((prefix, acc / n))
         for key, value in vals.items():                       # `log` averages the stored values: n copies of the mean
             self._stored_metrics["train"][key].extend([value] * n)
 
     def log(self, logs: Dict[str, float]) -> Dict[str, float]:
+        """rankpo_trainer.py:626-645.  Call it on EVERY rank, as the HF Trainer loop the reference copies does (its
+        `_maybe_log_save_evaluate` calls `self.log` on all processes; only the printing is rank-0): with more than one rank a
+        training log resolves the deferred metrics with one all-reduce (`_flush_pending`) -- the collective the reference issues
+        inside every micro-step (9 `gather_for_metrics`) lives here instead -- so a loop that logs on rank 0 only would hang in it."""
         train_eval = "train" if "loss" in logs else "eval"
         if train_eval == "train":
             self._flush_pending()

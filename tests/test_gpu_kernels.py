@@ -213,8 +213,8 @@ def test_infonce_forward_backward_shapes(dtype, Q, P, d):
 @pytest.mark.parametrize("Q,P,d", [(64, 384, 2048), (16, 96, 2048), (33, 231, 4096)])
 def test_infonce_many_block_single_launch_finalize(dtype, Q, P, d):
     """The multi-block launches of the skinny kernel (the W = 8 scoring shape of modeling.py:287-314, 64 x 384) finish lse and
-    loss in the SAME launch: the last block to arrive merges the partials.  The arrival counters are reused round-robin and put
-    back to zero by that block; 150 launches walk every slot more than twice, two streams interleave their slots, and every
+    loss in the SAME launch: the last block to arrive merges the partials.  The arrival counters are reused round-robin (epoch-
+    stamped since round 4); 150 launches over two streams interleave their slots, and every
     result must equal the softmax / CE of the scores the launch returned -- the inputs change every launch, so a stale or
     double-counted ticket shows as a loss that was never written (an earlier launch's value) or one taken from incomplete partials."""
     rs = np.random.RandomState(Q + P)
@@ -240,6 +240,28 @@ def test_infonce_many_block_single_launch_finalize(dtype, Q, P, d):
             lse = (m + np.log(np.exp(s - m).sum(-1, keepdims=True)))[:, 0]
             np.testing.assert_allclose(loss.item(), (lse - s[np.arange(Q), tgt]).mean(), rtol=2e-5, atol=2e-6)
     assert first[0].item() == first[1].item()        # same inputs, two launches, two slots: bit-identical
+
+
+@pytest.mark.parametrize("word", [3, (0xDEAD << 32) | 5, (0x7FFFFFFF << 32) | 95, 0xFFFFFFFFFFFFFFFF])
+def test_infonce_single_launch_finalize_survives_stale_arrival_counters(word):
+    """Advisor, round 3: a launch that never finished used to leave a non-zero arrival count in its slot, and every later launch on
+    that slot silently left lse / loss unwritten.  The slots carry the launch's epoch now: whatever a slot holds -- a plain stale
+    count, another epoch's count, one short of the grid (96 blocks at 64 x 384), all ones --
+    the next launches on it write the right lse and loss."""
+    from rankpo_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(5)
+    Q, P, d = 64, 384, 512
+    tgt = np.arange(Q) * (P // Q)
+    assert lib.rpo_infonce_debug_poison_tickets(word, torch.cuda.current_stream().cuda_stream) == 0
+    for it in range(3):
+        q, p = t(unit(rs.randn(Q, d)), torch.bfloat16), t(unit(rs.randn(P, d)), torch.bfloat16)
+        loss, scores = ops().infonce_loss(q, p, T)
+        s = npf(scores)
+        m = s.max(-1, keepdims=True)
+        lse = (m + np.log(np.exp(s - m).sum(-1, keepdims=True)))[:, 0]
+        np.testing.assert_allclose(loss.item(), (lse - s[np.arange(Q), tgt]).mean(), rtol=2e-5, atol=2e-6)
+    assert lib.rpo_infonce_debug_poison_tickets(0, torch.cuda.current_stream().cuda_stream) == 0
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
