@@ -19,9 +19,11 @@ scaled shapes of SURVEY.md §8d where it is MFMA-bound) and `cpu_baseline` (the 
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -224,6 +226,80 @@ class TimedLib:
 
 
 # ----------------------------------------------------------------------------------------------------------
+# first contact with N GPUs: every rank says where it is, and a rank that sits in one phase past its budget ends the job
+# ----------------------------------------------------------------------------------------------------------
+class Watchdog:
+    """Per-rank phase log + dead-man switch.  `phase(name, budget_s)` prints `[bench rR HH:MM:SS] phase: name` to stderr (every
+    rank: when an N-GPU run dies, the last line of each rank says where) and re-arms a timer; a daemon thread ends the process
+    with exit code 3 and a line naming the phase when the phase outlives its budget.  A collective that never completes (a rank
+    that died, a mismatched sequence of collectives, an RCCL bootstrap that cannot reach a peer) otherwise sits until the
+    driver's own limit kills the job without a word; with this -- and the process-group timeout next to it -- the run ends
+    non-zero within minutes, naming the phase.  No re-exec, no signal games: `os._exit` of this process only; under
+    torch.distributed.run the agent then ends the other ranks."""
+
+    def __init__(self, rank, scale=1.0, exit_fn=None):
+        self.rank, self.scale = rank, float(scale)
+        self._lock = threading.Lock()
+        self._name, self._t0, self._budget = "start", time.monotonic(), None
+        self._exit = exit_fn or (lambda code: os._exit(code))
+        self.history = []
+        if self.scale > 0:
+            threading.Thread(target=self._run, name="bench-watchdog", daemon=True).start()
+
+    def phase(self, name, budget_s):
+        now = time.monotonic()
+        with self._lock:
+            self.history.append((self._name, round(now - self._t0, 2)))
+            self._name, self._t0 = name, now
+            self._budget = budget_s * self.scale if self.scale > 0 else None
+        print(f"[bench r{self.rank} {time.strftime('%H:%M:%S')}] phase: {name}"
+              + (f" (budget {budget_s * self.scale:.0f} s)" if self.scale > 0 else ""), file=sys.stderr, flush=True)
+
+    def done(self):
+        with self._lock:
+            self.history.append((self._name, round(time.monotonic() - self._t0, 2)))
+            self._name, self._budget = "done", None
+
+    def _run(self):
+        while True:
+            time.sleep(0.5)
+            with self._lock:
+                name, t0, budget = self._name, self._t0, self._budget
+            if budget is not None and time.monotonic() - t0 > budget:
+                print(f"[bench r{self.rank} {time.strftime('%H:%M:%S')}] WATCHDOG: phase '{name}' has run {time.monotonic() - t0:.0f} s, "
+                      f"past its budget of {budget:.0f} s -- this rank is stuck (or a peer is, and this rank waits for it in a "
+                      f"collective); exiting with code 3", file=sys.stderr, flush=True)
+                self._exit(3)
+                return
+
+
+def llama_step_flops(cfg, lens_per_micro_batch):
+    """Algorithmic FLOP of training micro-steps of a Llama encoder on REAL tokens (forward + backward = 3 x forward for the
+    GEMMs, 3.5 x for causal attention: backward recomputes nothing algorithmically but has 5 products for the forward's 2):
+      required: what the loss needs -- every block but the last on all tokens; the last block's K / V projections on all tokens
+                and everything else of it (q, o, MLP, one-query attention) on the POOLED rows only (last-token pooling,
+                modeling.py:224-230, consumes one row per sequence);
+      model:    the reference's own count: all blocks on all tokens (what HF's LlamaModel executes before pooling).
+    Gradient-checkpoint recomputation, pad tokens and the packed path's filler sequence are not algorithmic and not counted.
+    Embedding lookup / its scatter-add backward: no GEMM.  Returns dict(gemm_required, attn_required, gemm_model, attn_model)."""
+    d, nh = cfg.hidden_size, cfg.num_attention_heads
+    nkv = getattr(cfg, "num_key_value_heads", None) or nh
+    hd = getattr(cfg, "head_dim", None) or d // nh
+    ff, nl = cfg.intermediate_size, cfg.num_hidden_layers
+    kv = 2 * d * nkv * hd                                   # k_proj + v_proj weights
+    blk = d * nh * hd + kv + nh * hd * d + 3 * d * ff       # all linear weights of one block
+    out = dict(gemm_required=0, attn_required=0, gemm_model=0, attn_model=0)
+    for lens in lens_per_micro_batch:
+        n = np.asarray(lens, dtype=np.int64)
+        T, rows, pairs = int(n.sum()), int(len(n)), int((n * (n + 1) // 2).sum())
+        out["gemm_model"] += 6 * T * blk * nl
+        out["gemm_required"] += 6 * (T * blk * (nl - 1) + T * kv + rows * (blk - kv))
+        out["attn_model"] += int(3.5 * 4 * hd * nh * pairs) * nl
+        out["attn_required"] += int(3.5 * 4 * hd * nh * pairs) * (nl - 1) + int(3.5 * 4 * hd * nh * T)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------
 def build_config(arch):
     from rankpo_amd import encoder as PE
     if arch == "llama-3.2-1b":
@@ -262,7 +338,8 @@ def sweep(lib_timed, device):
     lib = _lib.load()
     res = []
     st = torch.cuda.current_stream().cuda_stream
-    for Q, d in ((2048, 2048), (4096, 2048), (8192, 2048), (16384, 2048), (4096, 4096)):
+    # SURVEY.md 8d asks Q = P in {1024, 4096, 16384} x d in {2048, 4096}; 2048^2 and 8192^2 at d = 2048 complete the curve
+    for Q, d in ((1024, 2048), (2048, 2048), (4096, 2048), (8192, 2048), (16384, 2048), (1024, 4096), (4096, 4096), (16384, 4096)):
         P = Q
         q = torch.nn.functional.normalize(torch.randn(Q, d, device=device), dim=-1).to(torch.bfloat16)
         p = torch.nn.functional.normalize(torch.randn(P, d, device=device), dim=-1).to(torch.bfloat16)
@@ -398,19 +475,20 @@ def cpu_baseline(model, cfg, temperature, sample=(20, 42, 8, 3), repeats=3, note
 PARITY_GRADS = ("embed_tokens.weight", "layers.0.self_attn.q_proj.weight", "layers.0.self_attn.k_proj.weight")
 
 
-def oracle_step(w, cd, batch, temperature):
+def oracle_step(w, cd, batch, temperature, block_checkpoint=False):
     """One float32 training micro-step of the oracle (oracle/encoder_ref.py: contrastive_step + backward) on a dict of
-    float32 leaf weights: what `step_parity` compares against and what `cpu_baseline` times."""
+    float32 leaf weights: what `step_parity` compares against and what `cpu_baseline` times.  `block_checkpoint`: the same
+    arithmetic with every block recomputed in backward instead of stored (the headline-size parity leg, on the device)."""
     from oracle import encoder_ref as E
     for t in w.values():
         t.grad = None
-    loss, scores, q, p = E.contrastive_step(w, cd, batch, temperature)
+    loss, scores, q, p = E.contrastive_step(w, cd, batch, temperature, block_checkpoint=block_checkpoint)
     loss.backward()
-    grads = {k: w[k].grad.clone() for k in PARITY_GRADS if k in w}
+    grads = {k: w[k].grad.clone() for k in PARITY_GRADS if k in w and w[k].grad is not None}
     return dict(loss=float(loss.detach()), scores=scores.detach().float(), q=q.detach(), p=p.detach(), grads=grads)
 
 
-def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
+def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype, block_checkpoint=False):
     """Step-loss parity on identical tokens: the cpu_baseline sample through (i) the product's fast path
     (packed tokens, hand-written attention, fused ops, storage dtype of the run) and two CONTROLS in the same storage dtype on
     the GPU: (ii) the oracle's own eager arithmetic (HF eager semantics, modeling.py:219), and (iii) the same encoder with
@@ -450,7 +528,7 @@ def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
         finally:
             model.model.hand_attention = True
     wd = {k: v.detach().to(device, dtype).requires_grad_(k in names) for k, v in model.model.state_dict().items()}
-    loss_c, s_c = E.contrastive_step(wd, cfg.to_dict(), dev_batch, temperature, dtype=dtype)[:2]
+    loss_c, s_c = E.contrastive_step(wd, cfg.to_dict(), dev_batch, temperature, dtype=dtype, block_checkpoint=block_checkpoint)[:2]
     got_c = torch.autograd.grad(loss_c, [wd[n] for n in names]) if names else ()
     controls["control_stock_eager"] = stats(loss_c.detach(), s_c.detach(), dict(zip(names, got_c)))
     ctrl = {k: max(c[k] for c in controls.values()) for k in controls["control_stock_eager"] if k != "loss"}
@@ -473,12 +551,98 @@ def step_parity(model, cfg, temperature, sample_batch, ref, device, dtype):
         cf, ce = controls["control_stock_flash"], controls["control_stock_eager"]
         failed += [f"controls_disagree:{k}" for k in cf if k not in ("loss", "loss_abs_err") and not cf[k] <= 2.5 * ce[k] + 1e-5]
     rnd = lambda d: {k: round(v, 7) for k, v in d.items()}
+    # the loss rule, spelled out with this run's numbers: the loss is a mean over Q rows of (logsumexp_j s_ij - s_i,target) with
+    # s = cos / T, so a cosine error e moves a logit by e / T and the loss by up to that; the controls' OWN loss errors scatter
+    # (the row errors partly cancel in the mean), which is why the tolerance takes the larger of the two terms
+    loss_rule = {"fast_path_loss_abs_err": fast["loss_abs_err"],
+                 "control_loss_abs_err": {k: c["loss_abs_err"] for k, c in controls.items()},
+                 "control_cos_rms_err_over_T": ctrl["cos_rms_err"] / temperature,
+                 "tolerance": tol["loss_abs_err"],
+                 "tolerance_is": "1.5 x max(largest control loss error, largest control cosine RMS error / T)",
+                 "fast_over_largest_control_loss_err": fast["loss_abs_err"] / max(ctrl["loss_abs_err"], 1e-12)}
+    loss_rule = {k: ({kk: round(vv, 7) for kk, vv in v.items()} if isinstance(v, dict) else round(v, 7) if isinstance(v, float) else v)
+                 for k, v in loss_rule.items()}
     return {"oracle_f32_loss": round(ref["loss"], 6), "fast_path": rnd(fast), **{k: rnd(v) for k, v in controls.items()},
-            "tolerance": rnd(tol), "pass": not failed, "failed": failed,
+            "tolerance": rnd(tol), "loss_rule": loss_rule, "pass": not failed, "failed": failed,
             "rule": "fast-path error <= 1.5 x the larger error of the stock paths in the same storage dtype (eager attention; "
                     "PyTorch's flash-attention kernels), all against the float32 oracle on the same tokens and weights "
                     "(loss: 1.5 x max(control loss error, control cosine RMS error / T)); and the stock-flash control (product encoder "
                     "code + PyTorch's attention) within 2.5 x of the eager control (oracle code) on every statistic but the loss"}
+
+
+def headline_parity(model, cfg, temperature, Lq, Lp, device, dtype, w_host=None, note=lambda m: None, seed=77):
+    """Step-loss parity AT THE SIZE THE METRIC IS QUOTED ON (BASELINE.json configs[1]; reference modeling.py:206-238, 281-314):
+    2 queries of <= Lq tokens + 6 passages of <= Lp tokens (G = 3, one FULL-LENGTH row each, the others of random length in
+    [L/2, L]) through ALL blocks of the benchmarked model, with the weights the timed steps left behind.  The float32 oracle is
+    oracle/encoder_ref.py's own code executed on the device (torch float32 matmul, TF32-style shortcuts off, every block under
+    torch.utils.checkpoint: same arithmetic, recomputed instead of stored -- on 8 host cores one such step takes ~10 minutes);
+    that execution is PINNED first to the host execution of the same code on the full-length query row (`oracle_pin`).  Then the
+    rule of `step_parity` with its two bf16 controls.  The short sample next to it keeps the oracle on the host end to end."""
+    from oracle import encoder_ref as E
+    assert not torch.backends.cuda.matmul.allow_tf32
+    t_start = time.perf_counter()
+    g = torch.Generator().manual_seed(seed)
+    lo, hi = (1000, cfg.vocab_size - 1000) if cfg.vocab_size > 4000 else (1, cfg.vocab_size)
+    pad = cfg.pad_token_id if cfg.pad_token_id is not None else 0
+
+    def mk(N, L):
+        lens = torch.randint(L // 2, L + 1, (N,), generator=g)
+        lens[0] = L
+        m = (torch.arange(L)[None, :] < lens[:, None]).long()
+        ids = torch.randint(lo, hi, (N, L), generator=g)
+        return {"input_ids": ids * m + pad * (1 - m), "attention_mask": m}
+    batch = {"query": mk(2, Lq), "passage": mk(6, Lp)}
+    tot = int(batch["query"]["attention_mask"].sum() + batch["passage"]["attention_mask"].sum())
+    if tot % 256 == 0:                      # the filler sequence of the packed path must have something to do
+        m = batch["query"]["attention_mask"]
+        last = int(m[1].sum()) - 1
+        m[1, last] = 0
+        batch["query"]["input_ids"][1, last] = pad
+        tot -= 1
+    cd = cfg.to_dict()
+    sd = model.model.state_dict()
+    torch.cuda.empty_cache()                # the timed steps' cached activation blocks go back: the oracle needs ~40 GB in one piece
+    w_dev = {k: v.detach().to(device, torch.float32).requires_grad_(k in PARITY_GRADS) for k, v in sd.items()}
+    # (1) pin: oracle code on the device (f32) == oracle code on the host (f32), full-length query row, all blocks
+    row = {k: v[:1] for k, v in batch["query"].items()}
+    if w_host is None:
+        w_host = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        e_host = E.embed({k: v.detach() for k, v in w_host.items()}, cd, row)
+        t_host = time.perf_counter() - t0
+        e_dev = E.embed(w_dev, cd, {k: v.to(device) for k, v in row.items()}).cpu()
+    pin = float((e_host - e_dev).abs().max())
+    note(f"headline parity: oracle on device vs on host, one {Lq}-token row through {cfg.num_hidden_layers} blocks: max |diff| {pin:.2e} "
+         f"(host {t_host:.1f} s)")
+    # (2) the float32 oracle step on the device, block-checkpointed
+    dev_batch = {k: {kk: vv.to(device) for kk, vv in v.items()} for k, v in batch.items()}
+    t0 = time.perf_counter()
+    ref = oracle_step(w_dev, cd, dev_batch, temperature, block_checkpoint=True)
+    torch.cuda.synchronize()
+    t_oracle = time.perf_counter() - t0
+    ref = {"loss": ref["loss"], "scores": ref["scores"].cpu(), "q": ref["q"].cpu(), "p": ref["p"].cpu(),
+           "grads": {k: v.cpu() for k, v in ref["grads"].items()}}
+    for t in w_dev.values():
+        t.grad = None
+    del w_dev
+    torch.cuda.empty_cache()
+    note(f"headline parity: float32 oracle step on the device {t_oracle:.1f} s; fast path + two bf16 controls ...")
+    rep = step_parity(model, cfg, temperature, batch, ref, device, dtype, block_checkpoint=True)
+    torch.cuda.empty_cache()
+    pin_tol = 1e-4                          # float32 round-off of two summation orders through all blocks; the bf16 errors judged are >= 3e-4
+    if not pin <= pin_tol:
+        rep["pass"] = False
+        rep["failed"] = rep["failed"] + [f"oracle_pin:{pin:.2e}>{pin_tol:.0e}"]
+    lens = [int(x) for x in torch.cat([batch["query"]["attention_mask"].sum(-1), batch["passage"]["attention_mask"].sum(-1)])]
+    rep["sample"] = {"queries": 2, "passages": 6, "row_lengths": lens, "longest_row": max(lens), "tokens": tot,
+                     "blocks": cfg.num_hidden_layers, "weights": "the benchmarked model after the timed steps"}
+    rep["oracle"] = ("oracle/encoder_ref.py executed on the device in float32 (no TF32), blocks checkpointed; pinned to its host "
+                     "execution on the full-length query row")
+    rep["oracle_pin"] = {"max_abs_diff_unit_embedding": float(f"{pin:.3g}"), "tolerance": pin_tol, "row_tokens": Lq,
+                         "host_seconds": round(t_host, 2)}
+    rep["seconds"] = round(time.perf_counter() - t_start, 1)
+    return rep
 
 
 class _StdoutToStderr:
@@ -575,7 +739,7 @@ class CommProbe:
         return [1e3 * (b - a) for a, b in pairs]
 
 
-def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=None, balance=None):
+def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=None, balance=None, segments=None):
     """The N > 1 part of the JSON line (also emitted by the world-1 `--force-dist` rehearsal and, on gloo, by
     `--rehearse-launch`): what the communicator saw and what the collectives cost, measured in this run.  Collective calls:
     every rank must call this."""
@@ -619,7 +783,10 @@ def comm_block(probe, device, reducer, last_loss, elapsed, steps, flat_param=Non
         "rebalance": (None if not balance else {
             "micro_steps": len(balance),
             "max_over_mean_as_sampled": rnd(mean([max(b["cost_before"]) * len(b["cost_before"]) / sum(b["cost_before"]) for b in balance]), 4),
-            "max_over_mean_as_run": rnd(mean([max(b["cost_after"]) * len(b["cost_after"]) / sum(b["cost_after"]) for b in balance]), 4)}),
+            "max_over_mean_as_run": rnd(mean([max(b["cost_after"]) * len(b["cost_after"]) / sum(b["cost_after"]) for b in balance]), 4),
+            # the timed region's segments (bench.py --balance auto with N > 1: first half re-dealt, second half as sampled), each
+            # bracketed by a barrier, max over ranks: the mechanism's effect measured inside ONE run
+            **({"segments": segments} if segments else {})}),
         "timer": ("HIP events on the launch stream around EmbeddingGather.wait / FlatGradAllReducer.finish" if probe.use_events
                   else "host clock (CPU rehearsal)"),
     }
@@ -653,14 +820,18 @@ def self_launch(n):
     return subprocess.run(cmd, env=env).returncode
 
 
-def rehearse_launch(rank, world):
-    """What every rank does around the timed region, without a GPU: process group up (gloo), barrier, MAX over ranks, and the
-    `comm` block of the N > 1 line built by the same code from a toy replica (one all-gather + a bucketed gradient mean per
-    step through the product's own EmbeddingGather / FlatGradAllReducer)."""
+def rehearse_launch(rank, world, args):
+    """What every rank does around the timed region, without a GPU: process group up (gloo, with the bench's timeout), barrier,
+    MAX over ranks, and the `comm` block of the N > 1 line built by the same code from a toy replica (one all-gather + a
+    bucketed gradient mean per step through the product's own EmbeddingGather / FlatGradAllReducer), under the same per-rank
+    phase log and watchdog as the real run (`--rehearse-stall R`: rank R stops answering in step 1)."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29655")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wd = Watchdog(rank, args.watchdog_scale)
+    wd.phase("process group init (gloo)", args.pg_timeout + 60)
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=args.pg_timeout))
     dist.barrier()
+    wd.phase("rehearsal steps", 40)
     t = torch.tensor([float(rank + 1)], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     from rankpo_amd.distributed import EmbeddingGather, FlatGradAllReducer, rebalance_groups
@@ -676,6 +847,8 @@ def rehearse_launch(rank, world):
         Lq, Lp = 4 + rank, 8 + 4 * rank
         qm = (torch.arange(Lq)[None, :] < torch.tensor([[Lq], [2]])).long()
         pm = (torch.arange(Lp)[None, :] < torch.tensor([[Lp], [3], [Lp - 1], [1]])).long()
+        if i == 1 and rank == args.rehearse_stall:
+            time.sleep(3600)                                       # a rank that stopped answering (the watchdog test)
         _, _, info = rebalance_groups({"input_ids": qm * 7, "attention_mask": qm}, {"input_ids": pm * 9, "attention_mask": pm})
         bal.append(info)
         x = torch.full((6, 16), float(rank + i + 1))
@@ -690,12 +863,15 @@ def rehearse_launch(rank, world):
                 p_ -= 0.1 * scale * p_.grad
         red_.zero_()
     probe.enabled = False
+    wd.phase("comm block", 60)
     flat = torch.cat([p_.detach().reshape(-1) for p_ in lin.parameters()])
     comm = comm_block(probe, torch.device("cpu"), red_, loss, time.perf_counter() - t0, steps, flat_param=flat, balance=bal)
     if rank == 0:
         print(json.dumps({"rehearsal": "launch", "n_gpus": world, "max_over_ranks": t.item(), "comm": comm}), flush=True)
+    wd.phase("final barrier", 60)
     dist.barrier()
     dist.destroy_process_group()
+    wd.done()
 
 
 def main():
@@ -743,6 +919,18 @@ def main():
                          "the numbers it prints are not a measurement")
     ap.add_argument("--rehearse-launch", action="store_true",
                     help="CPU rehearsal of the N-rank launch only: gloo process group, barrier, max-over-ranks, one JSON line")
+    ap.add_argument("--rehearse-stall", type=int, default=-1,
+                    help="with --rehearse-launch: this rank stops answering in the second step (a test of the watchdog: the job "
+                         "must end non-zero, naming the phase, instead of hanging)")
+    ap.add_argument("--pg-timeout", type=float, default=180.0,
+                    help="seconds a collective may take before torch.distributed aborts the process group (default 180; "
+                         "torch's own default is 10 minutes for nccl, 30 for gloo: longer than a driver's patience)")
+    ap.add_argument("--watchdog-scale", type=float, default=1.0,
+                    help="multiplies every phase budget of the per-rank watchdog (0 = no watchdog, phases are still logged)")
+    ap.add_argument("--headline-parity", default="auto", choices=("auto", "on", "off"),
+                    help="N = 1: second step-parity sample at the headline size (2 queries <= q_len + 6 passages <= p_len tokens "
+                         "through ALL blocks, float32 oracle on the device pinned to the host); auto = on for the Llama-3.2-1B "
+                         "workloads, where it fits beside the training state")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -757,9 +945,11 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run "
                          f"--nproc-per-node {args.gpus}, or run `python bench.py --gpus {args.gpus}` outside torchrun")
     if args.rehearse_launch:
-        return rehearse_launch(rank, world)
+        return rehearse_launch(rank, world, args)
     if args.share_gpu:
         local_rank = local_rank % max(1, torch.cuda.device_count())
+    wd = Watchdog(rank, args.watchdog_scale)
+    wd.phase("device", 300)                      # the first HIP call of a fresh box pages the runtime in
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     multi = world > 1 or args.force_dist
@@ -767,13 +957,19 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")
+        # a collective that cannot complete aborts the process group after --pg-timeout seconds (torch's own default would sit
+        # for 10 minutes); the watchdog's budget for this phase lies behind it, so torch's message -- which names the
+        # collective -- comes first when both apply
+        wd.phase(f"process group init ({'gloo' if args.share_gpu else 'nccl = RCCL'}, world {world})", args.pg_timeout + 120)
+        pg_timeout = datetime.timedelta(seconds=args.pg_timeout)
         with _StdoutToStderr():
             if args.share_gpu:
-                dist.init_process_group("gloo", rank=rank, world_size=world)
+                dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
             else:
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device, timeout=pg_timeout)
             dist.barrier()                       # creates the RCCL communicator now (banner goes to stderr)
             torch.cuda.synchronize()
+    wd.phase("build model", 600)
 
     import rankpo_amd
     from rankpo_amd import _lib
@@ -804,16 +1000,32 @@ def main():
     model = rankpo_amd.ModelForTraining(encoder=enc, temperature=temperature, use_inbatch_neg=True,
                                         negatives_cross_device=multi, unpad=not args.padded).train()
     hook_attn_tables()
+    wd.phase("synthetic batches", 300)
     gas = max(1, args.gas)
     nb = (args.steps + args.warmup) * gas
     batches = [synth_batch(cfg, B, K, Lq, Lp, 1234 + rank * 1000 + i, device) for i in range(nb)]
-    tok_real = [int(b["query"]["attention_mask"].sum()) + int(b["passage"]["attention_mask"].sum()) for b in batches]
+    # real (unpadded) row lengths of every micro-batch, on the host: token counts, the step's algorithmic FLOP, the ranks' costs
+    batch_lens = [torch.cat([b["query"]["attention_mask"].sum(-1), b["passage"]["attention_mask"].sum(-1)]).tolist() for b in batches]
+    tok_real = [int(sum(l)) for l in batch_lens]
     tok_pad = B * Lq + B * (1 + K) * Lp
     ckpt = args.ckpt_layers
     partition = multi and args.partition_optimizer == "on"
     es = 2 if dtype == torch.bfloat16 else 4
     nl = cfg.num_hidden_layers
     nparam = sum(p.numel() for p in enc.parameters())
+
+    # HBM this rank can really use: what the device reports free NOW -- after RCCL created its communicator and buffers, with
+    # whatever else lives on the card -- plus what this process already holds (the bf16 parameters), MIN over the ranks, so that
+    # every rank derives the same checkpointing plan (round 3 budgeted 0.72 of the nominal 288 GB whatever was free)
+    free_now, total_hbm = torch.cuda.mem_get_info(device)
+    hbm_usable = free_now + torch.cuda.memory_reserved(device)
+    if multi:
+        hu = torch.tensor([float(hbm_usable)], dtype=torch.float64, device=device if not args.share_gpu else "cpu")
+        dist.all_reduce(hu, op=dist.ReduceOp.MIN)
+        hbm_usable = int(hu.item())
+        if args.share_gpu:
+            hbm_usable //= world                 # the rehearsal's ranks share one card
+    hbm_usable = min(hbm_usable, total_hbm)
 
     def free_blocks(part):
         # activation bytes kept per token per un-checkpointed block: x, norm(x), q, k, v, attn out, x', norm(x'),
@@ -823,9 +1035,8 @@ def main():
         per_tok = int(0.8 * es * (6.5 * cfg.hidden_size + 2 * cfg.intermediate_size))
         toks = tok_pad     # budget for the worst case (every row at full length), also in packed mode
         per_layer = toks * per_tok
-        total = torch.cuda.get_device_properties(device).total_memory
         state = nparam * (es * 2 + ((12 + es) / max(1, world) if part else 12))
-        budget = 0.72 * total - state - toks * cfg.hidden_size * es * nl - 2 * per_layer
+        budget = 0.72 * hbm_usable - state - toks * cfg.hidden_size * es * nl - 2 * per_layer
         return max(0, min(nl, int(budget // per_layer)))
     if multi and args.partition_optimizer == "auto":
         partition = world > 1 and free_blocks(False) < nl
@@ -847,12 +1058,16 @@ def main():
         probe = CommProbe(use_events=True)
         probe.install()
     balance = multi and (args.balance == "on" or (args.balance == "auto" and world > 1))
+    # `auto` with more than one rank: the FIRST half of the timed steps runs with the re-deal, the second half without, inside
+    # this one run -- a single N-GPU record then carries the mechanism's gain (or loss) instead of a default nobody measured
+    split_balance = multi and args.balance == "auto" and world > 1 and args.steps >= 2
+    bal_state = {"on": balance}
     bal_log = []
     pad_id = cfg.pad_token_id if cfg.pad_token_id is not None else 0
 
     def dealt(b):
         """This rank's micro-batch, after the global batch's groups were re-dealt by packed-token cost (inside the timed step)."""
-        if not balance:
+        if not bal_state["on"]:
             return b
         from rankpo_amd.distributed import rebalance_groups
         q, p, info = rebalance_groups(b["query"], b["passage"], pad_id)
@@ -880,19 +1095,77 @@ def main():
 
     note(f"model + {nb} synthetic batches ready ({arch}, world {world}); warmup {args.warmup} steps")
     losses = []
+    mem_guard = {"hbm_usable_GiB": round(hbm_usable / 2 ** 30, 1), "hbm_total_GiB": round(total_hbm / 2 ** 30, 1),
+                 "checkpointed_blocks_planned": (nl if ckpt < 0 else ckpt), "retries": 0}
     if not args.padded and args.warmup > 0:
         # Packed mode changes the activation sizes every step.  One untimed step on a full-length batch first sizes
         # the caching allocator for the worst case (later, smaller steps reuse/split those blocks instead of
         # calling hipMalloc inside the timed region) and proves that the worst case fits in HBM.
         full = {k: {"input_ids": v["input_ids"], "attention_mask": torch.ones_like(v["attention_mask"])}
                 for k, v in batches[0].items()}
-        ts.step(full if gas == 1 else [full] * gas)
-        torch.cuda.synchronize()
-        note(f"allocator pre-sized on a full-length batch, peak mem {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB")
+        wd.phase("allocator pre-size step (full-length batch)", 900)
+        while True:
+            # Memory guard: the plan above is an estimate.  If the worst-case step does not fit (out of memory), or fits with
+            # less than 6 % of the usable HBM to spare on some rank, checkpoint more blocks and take the step again rather
+            # than die in the timed region (cfg 5 at N = 1 peaked at 93 % in round 3).  Every rank must take the same
+            # decision: the verdict is all-reduced (MAX); an OOM of one rank inside a step that holds collectives cannot be
+            # agreed on afterwards, so with more than one rank it stays fatal (the watchdog names the phase).
+            oom = False
+            try:
+                ts.step(full if gas == 1 else [full] * gas)
+                torch.cuda.synchronize()
+            except torch.OutOfMemoryError:
+                if world > 1 and not args.share_gpu:
+                    raise
+                oom = True
+            peak = torch.cuda.max_memory_allocated(device)
+            tight = oom or peak > 0.94 * hbm_usable
+            if multi:
+                tg = torch.tensor([1.0 if tight else 0.0], device=device)
+                dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+                tight = bool(tg.item() > 0)
+            now_ckpt = nl if ckpt < 0 else ckpt
+            can_more = hasattr(enc, "layers") and now_ckpt < nl
+            note(f"allocator pre-sized on a full-length batch: peak mem {peak / 2**30:.1f} GiB of {hbm_usable / 2**30:.1f} usable"
+                 + (" -- OUT OF MEMORY" if oom else "") + (f"; tight: checkpointing more blocks ({now_ckpt} of {nl} so far)" if tight and can_more else ""))
+            if not tight or not can_more:
+                if oom:
+                    raise SystemExit(f"bench: the worst-case step does not fit in {hbm_usable / 2**30:.1f} GiB of HBM with every block checkpointed")
+                break
+            ckpt = min(nl, now_ckpt + max(1, nl // 4))
+            model.gradient_checkpointing_enable(layers=ckpt)
+            mem_guard["retries"] += 1
+            ts.opt.reducer.zero_()
+            torch.cuda.empty_cache()
+            torch.cuda.reset_peak_memory_stats(device)
+        mem_guard.update(checkpointed_blocks_run=(nl if ckpt < 0 else ckpt),
+                         presize_peak_GiB=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
+                         presize_peak_over_usable=round(torch.cuda.max_memory_allocated(device) / hbm_usable, 3))
+    t_step = None
     for i in range(args.warmup):
+        wd.phase(f"warm-up step {i}", 600)
+        tw = time.perf_counter()
         losses.append(ts.step(micro(i)))
         torch.cuda.synchronize()
-        note(f"warmup step {i} done, loss {float(losses[-1]):.4f}, peak mem {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB")
+        t_step = time.perf_counter() - tw
+        note(f"warmup step {i} done in {t_step:.2f} s, loss {float(losses[-1]):.4f}, peak mem {torch.cuda.max_memory_allocated(device) / 2**30:.1f} GiB")
+    # the ranks' costs as the batches were sampled, for every timed micro-step (host data, one object gather BEFORE the timed
+    # region): what the un-dealt half of a split run is judged by without adding a collective or a host sync to its steps
+    cost_sampled = None
+    if multi:
+        from rankpo_amd.distributed import sequence_cost
+        mine = [float(sequence_cost(torch.tensor(l, dtype=torch.float64)).sum()) for l in batch_lens]
+        allc = [None] * world
+        dist.all_gather_object(allc, mine)
+        cost_sampled = [[allc[r][i] for r in range(world)] for i in range(nb)]
+    # segments of the timed region: (re-deal on?, first step, one past the last step)
+    first, last = args.warmup, args.warmup + args.steps
+    if split_balance:
+        mid = first + (args.steps + 1) // 2
+        segments = [(True, first, mid), (False, mid, last)]
+    else:
+        segments = [(balance, first, last)]
+    wd.phase(f"timed steps ({args.steps})", max(300.0, 60.0 + 4.0 * args.steps * (t_step or 30.0)))
     torch.cuda.synchronize()
     if multi:
         dist.barrier()
@@ -901,25 +1174,53 @@ def main():
     if probe is not None:
         probe.enabled = True
     t0 = time.perf_counter()
-    for i in range(args.warmup, args.warmup + args.steps):
-        losses.append(ts.step(micro(i)))
-    torch.cuda.synchronize()
-    t_local = time.perf_counter() - t0          # this rank's own K steps (before it waits for the slowest rank)
-    if multi:
-        dist.barrier()
-    torch.cuda.synchronize()
+    seg_times, t_local = [], 0.0
+    for si, (on, a, b) in enumerate(segments):
+        bal_state["on"] = on
+        ts0 = time.perf_counter()
+        for i in range(a, b):
+            losses.append(ts.step(micro(i)))
+        torch.cuda.synchronize()
+        t_local += time.perf_counter() - ts0        # this rank's own steps (before it waits for the slowest rank)
+        if multi:
+            dist.barrier()
+        torch.cuda.synchronize()
+        seg_times.append(time.perf_counter() - ts0)
     elapsed = time.perf_counter() - t0
     timed.enabled = False
-    note(f"timed {args.steps} steps in {elapsed:.3f} s")
+    bal_state["on"] = balance
+    note(f"timed {args.steps} steps in {elapsed:.3f} s" + (f" (re-deal on: {seg_times[0]:.3f} s, off: {seg_times[1]:.3f} s)" if split_balance else ""))
     comm = None
     if multi:
+        wd.phase("comm block", 300)
         probe.enabled = False
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tmax = torch.tensor([elapsed] + seg_times, dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = tmax.item()
-        comm = comm_block(probe, device, ts.opt.reducer, losses[-1], t_local, args.steps, flat_param=ts.opt.flat_param, balance=bal_log)
+        elapsed, seg_times = tmax[0].item(), tmax[1:].tolist()
+        mom = lambda rows: (sum(max(c) * len(c) / sum(c) for c in rows) / len(rows)) if rows else None
+        seg_rep = []
+        for (on, a, b), st in zip(segments, seg_times):
+            sampled = [cost_sampled[i] for i in range(a * gas, b * gas)]
+            seg_rep.append({"redeal": bool(on), "steps": b - a, "ms_per_step": round(1e3 * st / max(1, b - a), 3),
+                            "pairs_per_s": round(world * B * (1 + K) * gas * (b - a) / st, 3),
+                            "max_over_mean_cost_as_sampled": round(mom(sampled), 4),
+                            # the most loaded rank's packed tokens per step, as sampled: the two halves run different batches
+                            "cost_max_rank_mean_as_sampled": round(sum(max(c) for c in sampled) / len(sampled), 1)})
+        comm = comm_block(probe, device, ts.opt.reducer, losses[-1], t_local, args.steps, flat_param=ts.opt.flat_param, balance=bal_log,
+                          segments=seg_rep if (split_balance or balance) else None)
     pairs = world * B * (1 + K) * gas * args.steps
     peak_mem = torch.cuda.max_memory_allocated(device) / 2 ** 30
+    # algorithmic FLOP of the timed steps, all ranks (the re-deal moves groups between ranks, the global sum stays)
+    flops = None
+    if "llama" in arch:
+        fl = llama_step_flops(cfg, batch_lens[args.warmup * gas:(args.warmup + args.steps) * gas])
+        if rankpo_wl and getattr(trainer, "ref_model", None) is not None:
+            fl = {k: v + v // 3 for k, v in fl.items()}          # a reference model adds one forward (none here: reference_free)
+        keys = sorted(fl)
+        ft = torch.tensor([float(fl[k]) for k in keys], dtype=torch.float64, device=device)
+        if multi:
+            dist.all_reduce(ft, op=dist.ReduceOp.SUM)
+        flops = dict(zip(keys, ft.tolist()))
 
     if rank == 0:
         kernels = [] if args.no_kernel_timing else timed.summary()
@@ -942,6 +1243,7 @@ def main():
                        "padding": "padded batches" if args.padded else "pad tokens skipped (packed varlen encoder)",
                        "tokens_per_step_per_gpu": {"padded": tok_pad, "real_mean": int(sum(tok_real) / len(tok_real))},
                        "weights": "random init (seed 0)",
+                       "memory_guard": mem_guard,
                        "dropout": {"hidden": float(getattr(cfg, "hidden_dropout_prob", 0.0) or 0.0),
                                    "attention": float(getattr(cfg, "attention_probs_dropout_prob", getattr(cfg, "attention_dropout", 0.0)) or 0.0)}},
             "loss_first": round(float(losses[0]), 5), "loss_last": round(float(losses[-1]), 5),
@@ -979,13 +1281,45 @@ def main():
                                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": top["frac_hbm"], "traffic": traffic,
                                    "traffic_source": tsrc, "avg_us": top["avg_us"], "algo_bytes": top["algo_bytes"]}
             out["kernels"] = kernels
+        if flops is not None:
+            # north_star: "pairs/sec ... with achieved fraction of bf16 MFMA roofline" -- the WHOLE step against the dense bf16 peak
+            # of the GPUs it ran on.  `frac` uses the FLOP the loss requires (last block on the pooled rows only); the
+            # reference-model count (every block on every token, what HF's LlamaModel executes) is next to it.
+            req = flops["gemm_required"] + flops["attn_required"]
+            mod = flops["gemm_model"] + flops["attn_model"]
+            hand_ms = sum(k_["total_ms"] for k_ in kernels) / args.steps if kernels else None
+            step_ms = 1e3 * elapsed / args.steps
+            out["step_roofline"] = {
+                "bound": "mfma", "unit": "TFLOP/s", "peak": MFMA_BF16_PEAK_TFLOPS * world,
+                "achieved": round(req / elapsed / 1e12, 1), "frac": round(req / elapsed / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+                "algo_flops_per_step": int(req / args.steps), "gemm_flops_per_step": int(flops["gemm_required"] / args.steps),
+                "attention_flops_per_step": int(flops["attn_required"] / args.steps),
+                "gemm_share_of_flops": round(flops["gemm_required"] / req, 4),
+                "model_flops_per_step": int(mod / args.steps), "achieved_model_flops": round(mod / elapsed / 1e12, 1),
+                "frac_model_flops": round(mod / elapsed / 1e12 / (MFMA_BF16_PEAK_TFLOPS * world), 4),
+                "counting": "real (unpadded) tokens of the timed steps, all ranks; GEMMs 6 x tokens x linear weights (forward + "
+                            "backward), causal attention 3.5 x 4 hd nh sum len (len + 1) / 2 per block; algo = every block but the "
+                            "last on all tokens + the last block's K/V projections on all tokens and the rest of it on the pooled "
+                            "rows only; model = all blocks on all tokens (the reference's HF encoder).  Not counted: checkpoint "
+                            "recomputation, pad tokens, the packed path's filler sequence, embedding lookups, the optimizer"}
+            if hand_ms is not None and world == 1:
+                # rank 0's HIP-event brackets: hand-written entry points vs everything else on the stream (hipBLASLt GEMMs +
+                # PyTorch glue); the GEMM rate is a lower bound because the remainder is not only GEMM time
+                lib_ms = step_ms - hand_ms
+                out["step_roofline"].update({
+                    "hand_written_kernel_ms_per_step": round(hand_ms, 2), "library_and_glue_ms_per_step": round(lib_ms, 2),
+                    "library_gemm_TFLOPs_at_least": round(flops["gemm_required"] / args.steps / (lib_ms * 1e-3) / 1e12, 1),
+                    "gemm_share_of_step_time_at_most": round(lib_ms / step_ms, 4)})
         if world == 1 and not args.no_sweep:
+            wd.phase("roofline sweep (similarity + InfoNCE kernel)", 600)
             out["roofline_sweep"] = sweep(timed, device)
             note("sweep done")
         if world == 1 and not args.no_cpu_baseline:
+            wd.phase("cpu baseline (oracle on the host cores)", 1200)
             note("cpu baseline (oracle on host cores) ...")
             dt, times, toks, (cores, cores_how), sample_batch, ref, fit = cpu_baseline(
                 model, cfg, temperature, note=note, long_sample=(256, 1024, 2, 1) if Lp >= 1024 else None)
+            wd.phase("step parity (short sample, oracle on the host)", 900)
             note("step parity: fast path and stock-eager control vs the float32 oracle ...")
             # the timed steps ran with the configuration's dropout (BERT family: HF's 0.1, as the reference trains it); the
             # oracle has none, so the parity leg -- outside the timed region -- compares with every nn.Dropout at p = 0
@@ -1025,13 +1359,28 @@ def main():
                                                    f"port {leg['port_median_s']} s per step; the reference cannot travel to the GPU box")})
             except Exception:
                 pass
+            # second sample: the headline's own size (BASELINE.json configs[1]): full-length rows through ALL blocks
+            want_hp = args.headline_parity == "on" or (args.headline_parity == "auto" and arch == "llama-3.2-1b"
+                                                       and dtype == torch.bfloat16)
+            if want_hp and "llama" in arch:
+                wd.phase("step parity (headline size: full-length rows, all blocks, oracle on the device)", 1200)
+                del ref
+                hp = headline_parity(model, cfg, temperature, Lq, Lp, device, dtype, note=note)
+                out["step_loss_parity"] = {"pass": bool(out["step_loss_parity"]["pass"] and hp["pass"]),
+                                           "failed": out["step_loss_parity"]["failed"] + ["headline:" + f for f in hp["failed"]],
+                                           "short_sample": out["step_loss_parity"], "headline_sample": hp,
+                                           "samples": "short_sample: the cpu_baseline rows (oracle on the host end to end); "
+                                                      "headline_sample: one full-length query and passage row among 2 + 6 rows "
+                                                      "through all blocks (oracle on the device, pinned to the host)"}
             if not out["step_loss_parity"]["pass"]:
                 print(json.dumps(out), flush=True)
                 raise SystemExit("step_loss_parity FAILED: " + ", ".join(out["step_loss_parity"]["failed"]))
         print(json.dumps(out), flush=True)
     if multi:
+        wd.phase("final barrier", 300 if world > 1 else 2400)
         dist.barrier()
         dist.destroy_process_group()
+    wd.done()
 
 
 if __name__ == "__main__":

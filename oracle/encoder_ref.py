@@ -54,8 +54,13 @@ def _softmax(s):
     return torch.softmax(s.float(), dim=-1).to(s.dtype) if s.dtype in _LOW else torch.softmax(s, dim=-1)
 
 
-def llama_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: torch.Tensor, dtype=torch.float32):
-    """last_hidden_state [N, L, d] of a Llama stack with causal + key-padding masking (HF eager semantics)."""
+def llama_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: torch.Tensor, dtype=torch.float32,
+                  block_checkpoint=False):
+    """last_hidden_state [N, L, d] of a Llama stack with causal + key-padding masking (HF eager semantics).
+    block_checkpoint: every block under torch.utils.checkpoint (non-reentrant) -- the SAME arithmetic, recomputed in backward
+    instead of stored: eager attention keeps a [N, heads, L, L] probability tensor per block (12.9 GB in float32 for six
+    4096-token rows of the Llama-3.2-1B shape), which is what lets bench.py run all 16 blocks of the headline model through this
+    code on the device (tests/test_encoder_parity.py: results bit-identical with and without)."""
     W = lambda k: w[k].to(dtype)
     d, nh = cfg["hidden_size"], cfg["num_attention_heads"]
     nkv = cfg.get("num_key_value_heads") or nh
@@ -72,7 +77,7 @@ def llama_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: t
     neg = torch.finfo(dtype).min
     allow = torch.ones(L, L, dtype=torch.bool, device=dev).tril()[None, None] & attention_mask.bool()[:, None, None, :]
     bias = torch.zeros(N, 1, L, L, dtype=dtype, device=dev).masked_fill(~allow, neg)
-    for i in range(cfg["num_hidden_layers"]):
+    def block(x, i):
         p = f"layers.{i}."
         h = _rms(x, W(p + "input_layernorm.weight"), eps)
         q = (h @ W(p + "self_attn.q_proj.weight").T).view(N, L, nh, hd).transpose(1, 2)
@@ -88,7 +93,14 @@ def llama_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: t
         h = _rms(x, W(p + "post_attention_layernorm.weight"), eps)
         g = h @ W(p + "mlp.gate_proj.weight").T
         u = h @ W(p + "mlp.up_proj.weight").T
-        x = x + (torch.nn.functional.silu(g) * u) @ W(p + "mlp.down_proj.weight").T
+        return x + (torch.nn.functional.silu(g) * u) @ W(p + "mlp.down_proj.weight").T
+
+    for i in range(cfg["num_hidden_layers"]):
+        if block_checkpoint and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+            x = checkpoint(block, x, i, use_reentrant=False)
+        else:
+            x = block(x, i)
     return _rms(x, W("norm.weight"), eps)
 
 
@@ -128,15 +140,16 @@ def bert_forward(w: dict, cfg: dict, input_ids: torch.Tensor, attention_mask: to
     return x
 
 
-def encoder_forward(w, cfg, input_ids, attention_mask, dtype=torch.float32):
+def encoder_forward(w, cfg, input_ids, attention_mask, dtype=torch.float32, block_checkpoint=False):
     arch = (cfg.get("architectures") or ["Llama"])[0]
-    fn = llama_forward if "Llama" in arch else bert_forward
-    return fn(w, cfg, input_ids, attention_mask, dtype)
+    if "Llama" in arch:
+        return llama_forward(w, cfg, input_ids, attention_mask, dtype, block_checkpoint=block_checkpoint)
+    return bert_forward(w, cfg, input_ids, attention_mask, dtype)
 
 
-def embed(w, cfg, inputs, normalize=True, dtype=torch.float32, force_last=False):
+def embed(w, cfg, inputs, normalize=True, dtype=torch.float32, force_last=False, block_checkpoint=False):
     """ModelForTraining.embed (modeling.py:206-238) / RankPOTrainer.single_forward (rankpo_trainer.py:392-418)."""
-    h = encoder_forward(w, cfg, inputs["input_ids"], inputs["attention_mask"], dtype)
+    h = encoder_forward(w, cfg, inputs["input_ids"], inputs["attention_mask"], dtype, block_checkpoint=block_checkpoint)
     m = inputs["attention_mask"]
     arch = (cfg.get("architectures") or ["Llama"])[0]
     if force_last or "Llama" in arch:
@@ -149,10 +162,11 @@ def embed(w, cfg, inputs, normalize=True, dtype=torch.float32, force_last=False)
     return e
 
 
-def contrastive_step(w, cfg, batch, temperature, use_inbatch_neg=True, normalize=True, dtype=torch.float32):
+def contrastive_step(w, cfg, batch, temperature, use_inbatch_neg=True, normalize=True, dtype=torch.float32,
+                     block_checkpoint=False):
     """Full ModelForTraining.forward training branch (modeling.py:278-314) -> (loss, scores, q, p) with autograd."""
-    q = embed(w, cfg, batch["query"], normalize, dtype)
-    p = embed(w, cfg, batch["passage"], normalize, dtype)
+    q = embed(w, cfg, batch["query"], normalize, dtype, block_checkpoint=block_checkpoint)
+    p = embed(w, cfg, batch["passage"], normalize, dtype, block_checkpoint=block_checkpoint)
     Q = q.shape[0]
     G = p.shape[0] // Q
     if use_inbatch_neg:

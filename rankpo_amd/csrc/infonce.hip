@@ -674,6 +674,9 @@ __device__ __forceinline__ void skinny_fused_finalize(int tid, int64_t Q, int ng
 // kSkinnyTicketSlots launches of this kernel in flight at once.
 constexpr int kSkinnyTicketSlots = 1024;
 __device__ unsigned long long g_skinny_ticket[kSkinnyTicketSlots];
+// the launches' sequence numbers: ONE counter for the whole library (a function-local static of the templated launcher would be
+// one per storage dtype, and an f32 and a bf16 launch would then share a (slot, epoch) pair)
+static std::atomic<unsigned long long> g_skinny_next_launch{0};
 
 template <typename T, int NG>
 __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
@@ -1308,11 +1311,10 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         const bool one_block = pl.nPb <= kSkinnyMaxFusedGroups && bytes <= 384 * 1024;
         const unsigned nblk = one_block ? 1u : (unsigned)npass;
         // several blocks: the last block to arrive finalizes (one launch; needs the scores in memory for the positives' column)
-        static std::atomic<unsigned long long> next_launch{0};
         int slot = -1;
         unsigned epoch = 0;
         if (nblk > 1 && do_stats && scores_out != nullptr) {
-            const unsigned long long seq = next_launch.fetch_add(1, std::memory_order_relaxed);
+            const unsigned long long seq = g_skinny_next_launch.fetch_add(1, std::memory_order_relaxed);
             slot = (int)(seq % (unsigned)kSkinnyTicketSlots);
             epoch = (unsigned)(seq / (unsigned)kSkinnyTicketSlots) + 1u;       // never 0: a zero-initialised slot matches no launch
         }

@@ -158,6 +158,27 @@ def test_gradient_checkpointing_is_exact():
     assert torch.allclose(g0, enc.layers[0].mlp.up_proj.weight.grad, atol=1e-6)
 
 
+def test_oracle_block_checkpoint_is_the_same_arithmetic():
+    """bench.py runs all 16 blocks of the headline model through the oracle's code on the device with every block under
+    torch.utils.checkpoint (eager attention's [N, heads, L, L] probabilities would not fit otherwise): loss, scores and every
+    weight gradient must be BIT-identical to the plain run -- the option stores less, it computes the same."""
+    torch.manual_seed(9)
+    cfg = PE.llama_config(pad_token_id=0, **LLAMA_CFGS[1])
+    w0 = E.state_dict_to_f32(PE.LlamaEncoder(cfg))
+    rs = np.random.RandomState(9)
+    qi, qm = _batch(rs, 3, 11, 96)
+    pi, pm = _batch(rs, 6, 19, 96)
+    batch = {"query": {"input_ids": qi, "attention_mask": qm}, "passage": {"input_ids": pi, "attention_mask": pm}}
+    res = []
+    for ck in (False, True):
+        w = {k: v.clone().requires_grad_(True) for k, v in w0.items()}
+        loss, scores, _, _ = E.contrastive_step(w, cfg.to_dict(), batch, 0.02, block_checkpoint=ck)
+        loss.backward()
+        res.append((loss.detach(), scores.detach(), {k: v.grad for k, v in w.items()}))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    assert all(torch.equal(res[0][2][k], res[1][2][k]) for k in w0)
+
+
 @pytest.mark.parametrize("arch", ["llama", "bert"])
 @pytest.mark.parametrize("mode", ["inbatch", "noinbatch"])
 def test_oracle_step_vs_reference_end_to_end(golden, arch, mode):

@@ -105,8 +105,14 @@ def test_two_ranks_end_to_end_on_one_gpu():
         assert comm["optimizer_state_partitioned"] == bool(extra)
         # the global batch's groups were re-dealt to the ranks by packed-token cost before every micro-step (the loss equality
         # above holds WITH the re-deal: the global batch is unchanged)
+        # `--balance auto` with two ranks: the first half of the timed steps (2 of 3) runs with the re-deal, the rest as sampled,
+        # and the line carries both halves' step times (bracketed by barriers inside the one run)
         rb = comm["rebalance"]
-        assert rb["micro_steps"] == 3 * (2 if extra else 1) and 1.0 <= rb["max_over_mean_as_run"] <= rb["max_over_mean_as_sampled"]
+        assert rb["micro_steps"] == 2 * (2 if extra else 1) and 1.0 <= rb["max_over_mean_as_run"] <= rb["max_over_mean_as_sampled"]
+        on, off = rb["segments"]
+        assert (on["redeal"], on["steps"], off["redeal"], off["steps"]) == (True, 2, False, 1)
+        assert on["ms_per_step"] > 0 and off["ms_per_step"] > 0 and on["max_over_mean_cost_as_sampled"] >= 1.0
+        assert out["config"]["memory_guard"]["retries"] == 0 and out["step_roofline"]["frac"] > 0
         assert np.isfinite(out["loss_last"]) and out["loss_first"] != out["loss_last"]
 
 

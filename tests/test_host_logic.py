@@ -703,6 +703,44 @@ def test_gloo_optimizer_state_partition(world):
     assert all(ret.get(r) for r in range(world)), dict(ret)
 
 
+def test_bench_watchdog_names_the_phase_when_a_rank_stalls():
+    """First contact with N GPUs must not end as a silent kill at the driver's limit: every rank logs its phases to stderr, the
+    process group carries a timeout, and a per-rank watchdog ends the job NON-ZERO, naming the phase, when a phase outlives its
+    budget.  Rehearsal on gloo: rank 1 stops answering in the second step; rank 0 then sits in the batch re-deal's all-reduce.
+    The job must end well inside the collective timeout (60 s here), with the stuck phase in the output."""
+    import subprocess
+    import sys
+    import time
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    t0 = time.time()
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--rehearse-launch", "--rehearse-stall", "1", "--watchdog-scale", "0.25",
+                        "--pg-timeout", "60"], capture_output=True, text=True, timeout=240, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0, r.stderr[-2000:]
+    assert "WATCHDOG: phase 'rehearsal steps'" in r.stderr and "exiting with code 3" in r.stderr, r.stderr[-3000:]
+    assert "[bench r0 " in r.stderr and "[bench r1 " in r.stderr and "phase: process group init (gloo)" in r.stderr     # every rank logs
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]                # no result line from a job that hung
+    assert took < 120, took
+    # the watchdog itself: a phase inside its budget is left alone, `done()` disarms it
+    import importlib
+    B = importlib.import_module("bench")
+    fired = []
+    wd = B.Watchdog(0, scale=1.0, exit_fn=fired.append)
+    wd.phase("quick", 0.2)
+    wd.phase("slow", 30.0)
+    time.sleep(1.2)
+    assert not fired
+    wd.phase("stuck", 0.3)
+    time.sleep(1.5)
+    assert fired == [3]
+    wd2 = B.Watchdog(0, scale=1.0, exit_fn=fired.append)
+    wd2.phase("ends", 0.3)
+    wd2.done()
+    time.sleep(1.2)
+    assert fired == [3] and [n for n, _ in wd2.history] == ["start", "ends"]
+
+
 def test_generated_dkdv128_bodies_are_in_sync():
     """rankpo_amd/csrc/attention_dkdv128_gen.inc (the hand-placed slice bodies of fa_bwd_dkdv128_kernel and its literal-register
     statements) is generated text: it must be what tools/gen/gen_dkdv128_body.py emits today (edit the generator, not the file)."""
