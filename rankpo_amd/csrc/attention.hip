@@ -334,6 +334,18 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                 }
             }
             // ---- online softmax (per query = per lane column), P^T fragments
+#if defined(RPO_FA_EXP_NOSOFTMAX)
+            // TIMING ABLATION (round 4, never shipped; tools/exp/build_variant.sh fwdnosm -DRPO_FA_EXP_NOSOFTMAX): the key-tile loop
+            // without its vector arithmetic -- no row maximum, no exp2, no rescale; the scores are packed as they leave the MFMA.
+            // What is left is the MFMA + LDS + DMA + barrier skeleton: the time a PERFECT overlap of the softmax under the matrix
+            // pipe (a software pipeline across key tiles) could reach at best.  Results are garbage.
+            short8_t pfrag[2][2];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                pfrag[0][n] = pack_frag(s[0][n], s[1][n]);
+                pfrag[1][n] = pack_frag(s[2][n], s[3][n]);
+            }
+#else
             float mnew[2];
 #pragma unroll
             for (int n = 0; n < 2; ++n) {
@@ -370,6 +382,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                 pfrag[0][n] = pack_frag(s[0][n], s[1][n]);
                 pfrag[1][n] = pack_frag(s[2][n], s[3][n]);
             }
+#endif
             RPO_FSTAMP(tf);
             RPO_FSTAMP_ADD(4, te, tf);
             // ---- O^T += V^T P^T   (A = V^T via the transposed LDS reads, same key order as the P fragments).
@@ -2381,6 +2394,16 @@ constexpr int kDkdv4Lds = kSlRing * kSlImg;                  // 67584 B
           "v"(NLRD), "v"(DLANE)                                                                                \
         : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "vcc", "memory")
 
+#ifdef RPO_D4_EXP_DQ_ATOMICS
+// PRICING EXPERIMENT (round 4, never shipped; tools/exp/build_variant.sh dqatomics -DRPO_D4_EXP_DQ_ATOMICS): what the dQ sum of a
+// one-kernel, five-product backward (cdna_hip_programming.md, Appendix B 'Attention backward': dQ by global_atomic_add_f32 from the
+// 256-key block) would add to THIS kernel before a single extra MFMA: after every slice each wave issues the block's share of
+// the f32 adds -- 8 query rows x 256 contiguous bytes (one dQ row of the head) -- into a [T, nh, 64] float buffer, adding 0.0
+// (dK / dV stay what they are, the parity tests still pass); the LDS-DMA ring's counted waits are widened by the 24 atomics
+// that sit between a stage and its wait.
+__device__ float* g_exp_dq32 = nullptr;
+#endif
+
 template <bool DOWN>
 __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
@@ -2751,11 +2774,21 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
     };
     bool hot = false;      // v[128:175] hold the row fragments / row constants of slice `it` (prefetched by the previous body)
     int cur = 0, sl = 0;
+#ifdef RPO_D4_EXP_DQ_ATOMICS
+    int exp_hq = hk * group;
+#endif
     for (int it = 0; it < niter; ++it) {
         if constexpr (DOWN) sl = nsl - 1 - (it >> gshift);
         // slices <= it + 1 have landed (the body prefetches from the next image).  Steady state (slices still being staged):
         // exactly two later stages are in flight, one compare instead of the general ladder
         if (st_n < niter) {
+#ifdef RPO_D4_EXP_DQ_ATOMICS
+            // + the 8 atomics of each of the iterations it - 3, it - 2, it - 1 (younger than the stage that must have landed)
+            if (it >= 3) {
+                if (wave == 0) asm volatile("s_waitcnt vmcnt(30)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(28)" ::: "memory");
+            } else
+#endif
             if (wave == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
@@ -2878,9 +2911,27 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
         } else {
             hot = false;
         }
+#ifdef RPO_D4_EXP_DQ_ATOMICS
+        {
+            const int hq_it = DOWN ? hk * group + (it & (group - 1)) : exp_hq;
+            const int row0 = min(qb + 8 * wave, len > 8 ? len - 8 : 0);
+            uint64_t dst = (uint64_t)(g_exp_dq32 + ((t0 + row0) * (int64_t)nh + hq_it) * kFaHD);
+            const unsigned lane4 = 4u * (unsigned)lane;
+            const float zero = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                asm volatile("global_atomic_add_f32 %0, %1, %2" : : "v"(lane4), "v"(zero), "s"(dst) : "memory");
+                dst += (uint64_t)nh * kFaHD * 4u;
+            }
+        }
+#endif
         cur = (cur + 1) & (kSlRing - 1);
         if constexpr (!DOWN) {
+#ifdef RPO_D4_EXP_DQ_ATOMICS
+            if (++sl == nsl) { sl = 0; ++exp_hq; }
+#else
             if (++sl == nsl) sl = 0;
+#endif
         }
     }
     // epilogue: dK[key][16 c + 4 g + r] = scale * dka, dV likewise (unscaled); the wave owns its keys: no reduction
@@ -3856,6 +3907,16 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     if (rc != RPO_OK) return rc;
     const unsigned dkdv_grid = (unsigned)(((n_k_tiles + 7) / 8) * 8);
     const bool use_v1 = key_block == 64;
+#ifdef RPO_D4_EXP_DQ_ATOMICS
+    {
+        static float* exp_buf = nullptr;                       // experiment only: one buffer for the largest batch the tools use
+        if (!exp_buf) {
+            (void)hipMalloc((void**)&exp_buf, ((size_t)262144 + 64) * 32 * 64 * 4);
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp_dq32), &exp_buf, sizeof(exp_buf));
+        }
+        if ((size_t)total_tokens > 262144 || num_heads > 32) return RPO_ERR_UNSUPPORTED;
+    }
+#endif
     static const bool attr_set = [] {
         (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kDmaLds);
         (void)hipFuncSetAttribute((const void*)fa_bwd_dkdv4_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, kDkdv4Lds);

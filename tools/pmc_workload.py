@@ -161,6 +161,35 @@ def attention(tag, nh, nkv, hd, N, L, seed):
         algo_flops=10 * hd * pairs * nh)
 
 
+def last_query(nh, nkv, hd, N, L, seed):
+    """The last block's one-query-per-sequence attention (rpo_lastq_attn_fwd / _bwd) at the cfg-2 step's shape: 56 sequences (8
+    queries <= 1280 + 48 passages <= 4096 tokens), K / V rows read once (and written once as dK / dV in the backward)."""
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.cat([torch.randint(1280 // 2, 1281, (8,), generator=g), torch.randint(L // 2, L + 1, (N,), generator=g)]).tolist()
+    T = sum(lens)
+    n = len(lens)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    q = torch.randn(n, nh, hd, device=DEV).to(bf).requires_grad_(True)
+    kv = torch.randn(T, 2 * nkv * hd, device=DEV).to(bf).requires_grad_(True)
+    scale = 1.0 / hd ** 0.5
+    state = {}
+
+    def fwd():
+        state["o"] = ops.last_query_attn(q, kv, cu, nkv, hd, scale)
+    shape = f"{n} sequences, T = {T}, {nh} q heads / {nkv} kv heads, head_dim {hd}: one query per sequence"
+    kvb = 2 * T * nkv * hd * 2
+    run("rpo_lastq_attn_fwd", ["lastq_fwd_kernel"], shape, kvb + 2 * n * nh * hd * 2 + 4 * n * nh, fwd, algo_flops=4 * T * nh * hd)
+    go = torch.randn_like(state["o"])
+
+    def bwd():
+        fwd()                                                   # (autograd graph per call; the forward is profiled under its own name)
+        state["o"].backward(go)
+        q.grad = kv.grad = None
+    run("rpo_lastq_attn_bwd", ["lastq_bwd_kernel"], shape, 2 * kvb + 4 * n * nh * hd * 2 + 4 * n * nh, bwd, algo_flops=10 * T * nh * hd)
+    report["rpo_lastq_attn_bwd"]["event_us_includes"] = "one forward launch per call (autograd); the PMC rows are per kernel"
+
+
+last_query(32, 8, 64, 48, 4096, 2)
 attention("", 32, 8, 64, 48, 4096, 0)                # cfg 2: the passage tower of one step
 attention("@hd128", 32, 8, 128, 24, 4096, 1)         # cfg 5 (Llama-3-8B architecture)
 torch.cuda.synchronize()
