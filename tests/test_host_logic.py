@@ -741,6 +741,28 @@ def test_bench_watchdog_names_the_phase_when_a_rank_stalls():
     assert fired == [3] and [n for n, _ in wd2.history] == ["start", "ends"]
 
 
+def test_bench_lib_switch_really_switches(tmp_path):
+    """`bench.py --lib other.so` is the in-step A/B of kernel builds.  Round 3's version set `_lib.LIB_PATH` after the package import
+    had loaded and cached the in-tree build: every call still went to the in-tree library and the "A/B" compared it with itself
+    (found in round 4 when a build that adds 2.3 ms to the backward measured no difference).  `select_library` must return, and make
+    `_lib.load()` return, the OTHER file."""
+    import importlib
+    import shutil
+    from rankpo_amd import _lib
+    B = importlib.import_module("bench")
+    in_tree, cached = _lib.LIB_PATH, _lib.load()
+    other = str(tmp_path / "librankpo_hip_other.so")
+    shutil.copy(in_tree, other)
+    try:
+        lib = B.select_library(other)
+        assert os.path.samefile(lib._name, other) and _lib.load() is lib and lib is not cached
+        assert lib.rpo_version() >= 100
+        with pytest.raises(SystemExit):
+            B.select_library(str(tmp_path / "missing.so"))
+    finally:
+        _lib.LIB_PATH, _lib._lib = in_tree, cached
+
+
 def test_generated_dkdv128_bodies_are_in_sync():
     """rankpo_amd/csrc/attention_dkdv128_gen.inc (the hand-placed slice bodies of fa_bwd_dkdv128_kernel and its literal-register
     statements) is generated text: it must be what tools/gen/gen_dkdv128_body.py emits today (edit the generator, not the file)."""
