@@ -110,12 +110,15 @@ __device__ __forceinline__ void store_scores4(T* row_ptr, int64_t col, int64_t n
 // ------------------------------------------------------------------------------------------------
 // Big tile kernel
 // ------------------------------------------------------------------------------------------------
-constexpr int kTileP = 128, kTileQ = 128, kTileRowBytes = 128;
+// Tile = TP passages x TQ queries, 4 waves as 2 x 2, TP / 2 x TQ / 2 scores^T per wave.  128 x 128 is the efficient shape
+// (16 MFMAs per 8 LDS fragment reads); a grid of few such tiles leaves most of the 256 CUs idle -- Q = P = 1024 is 64 tiles --
+// so the host picks 128 x 64 or 64 x 64 when the larger tile would not give every CU two blocks (round 4: SURVEY 8d's
+// 1024^2 sweep points and every mid-size shape between the skinny kernel and the 256 x 256 kernel).
+constexpr int kTileP = 128, kTileQ = 128, kTileRowBytes = 128;   // the LARGEST tile (grid-size limits)
 constexpr int kTileThreads = 256;
-constexpr int kTileBufBytes = kTileP * kTileRowBytes;          // 16 KiB per operand per buffer
-constexpr int kTileLdsBytes = 4 * kTileBufBytes;               // A0 A1 B0 B1 = 64 KiB
+constexpr int tile_lds_bytes(int TP, int TQ) { return 2 * (TP + TQ) * kTileRowBytes; }   // A0 A1 B0 B1: 64 KiB at 128 x 128
 
-template <typename T>
+template <typename T, int TP, int TQ>
 __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
     int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt) {
@@ -123,6 +126,8 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     typedef typename Mma<T>::Frag Frag;
     constexpr int KE = kTileRowBytes / (int)sizeof(T);   // K elements per tile row (64 bf16 / 32 f32)
     constexpr int CE = 16 / (int)sizeof(T);              // elements per 16-byte chunk
+    constexpr int MA = TP / 32, NB = TQ / 32;            // 16-row fragments per wave along passages / queries
+    constexpr int kABuf = TP * kTileRowBytes, kBBuf = TQ * kTileRowBytes;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,39 +147,38 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     const int gsz = min(nPt - first_p, GROUP);
     const int pt = first_p + (wg % width) % gsz;
     const int qt = (wg % width) / gsz;
-    const int64_t p0 = (int64_t)pt * kTileP, q0 = (int64_t)qt * kTileQ;
+    const int64_t p0 = (int64_t)pt * TP, q0 = (int64_t)qt * TQ;
 
     // staging: instruction i of wave w fills tile rows (4i + w)*8 .. +7 (1 KiB, lane-linear in LDS);
     // lane l carries row (l >> 3), physical chunk (l & 7) = logical chunk (l & 7) ^ (row & 7).
     const int srow = lane >> 3;
     const int lchunk = (lane & 7) ^ srow;
-    const T* a_src[4];
-    const T* b_src[4];
+    const T* a_src[MA];
+    const T* b_src[NB];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (4 * i + wave) * 8 + srow;
-        const int64_t pr = min(p0 + r, P - 1), qr = min(q0 + r, Q - 1);   // clamp: edge rows are masked later
-        a_src[i] = p + pr * d + lchunk * CE;
-        b_src[i] = q + qr * d + lchunk * CE;
-    }
+    for (int i = 0; i < MA; ++i)          // clamp: edge rows are masked later
+        a_src[i] = p + min(p0 + (4 * i + wave) * 8 + srow, P - 1) * d + lchunk * CE;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) b_src[i] = q + min(q0 + (4 * i + wave) * 8 + srow, Q - 1) * d + lchunk * CE;
     auto stage = [&](int t, int buf) {
         const int64_t k0 = (int64_t)t * KE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            char* a_dst = smem + buf * kTileBufBytes + (4 * i + wave) * 1024;
-            char* b_dst = smem + (2 + buf) * kTileBufBytes + (4 * i + wave) * 1024;
+        for (int i = 0; i < MA; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)a_dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)b_dst, 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)(smem + buf * kABuf + (4 * i + wave) * 1024),
+                                             16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(b_src[i] + k0),
+                (__attribute__((address_space(3))) void*)(smem + 2 * kABuf + buf * kBBuf + (4 * i + wave) * 1024), 16, 0, 0);
     };
 
-    float4_t acc[4][4];
+    float4_t acc[MA][NB];
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+    for (int m = 0; m < MA; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+        for (int n = 0; n < NB; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (int)(d / KE);
     const int frow = lane & 15;
@@ -184,39 +188,39 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
         if (t + 1 < nk) stage(t + 1, cur ^ 1);
-        const char* Ab = smem + cur * kTileBufBytes + (wp * 64 + frow) * kTileRowBytes;
-        const char* Bb = smem + (2 + cur) * kTileBufBytes + (wq * 64 + frow) * kTileRowBytes;
+        const char* Ab = smem + cur * kABuf + (wp * (TP / 2) + frow) * kTileRowBytes;
+        const char* Bb = smem + 2 * kABuf + cur * kBBuf + (wq * (TQ / 2) + frow) * kTileRowBytes;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = (((ks * 4 + g) ^ (lane & 7)) << 4);
-            Frag a[4], b[4];
+            Frag a[MA], b[NB];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) a[m] = *reinterpret_cast<const Frag*>(Ab + m * 16 * kTileRowBytes + coff);
+            for (int m = 0; m < MA; ++m) a[m] = *reinterpret_cast<const Frag*>(Ab + m * 16 * kTileRowBytes + coff);
 #pragma unroll
-            for (int n = 0; n < 4; ++n) b[n] = *reinterpret_cast<const Frag*>(Bb + n * 16 * kTileRowBytes + coff);
+            for (int n = 0; n < NB; ++n) b[n] = *reinterpret_cast<const Frag*>(Bb + n * 16 * kTileRowBytes + coff);
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MA; ++m)
 #pragma unroll
-                for (int n = 0; n < 4; ++n) Mma<T>::mma(a[m], b[n], acc[m][n]);
+                for (int n = 0; n < NB; ++n) Mma<T>::mma(a[m], b[n], acc[m][n]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
 
     // ---- epilogue: acc[m][n][j] = <p_{pbase + 16m + 4g + j}, q_{qbase + 16n + (lane&15)}>
-    const int64_t pbase = p0 + wp * 64 + g * 4;
-    const int64_t qbase = q0 + wq * 64 + frow;
+    const int64_t pbase = p0 + wp * (TP / 2) + g * 4;
+    const int64_t qbase = q0 + wq * (TQ / 2) + frow;
     const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
     const float inv_t = 1.0f / temperature;
-    float2* s_stat = reinterpret_cast<float2*>(smem);   // [wq][64] from the wp == 1 waves (LDS is free now)
+    float2* s_stat = reinterpret_cast<float2*>(smem);   // [wq][TQ / 2] from the wp == 1 waves (LDS is free now)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+    for (int n = 0; n < NB; ++n) {
         const int64_t qi = qbase + 16 * n;
         const bool qv = qi < Q;
         float mx = RPO_NEG_INF;
-        float v[4][4];
+        float v[MA][4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < MA; ++m) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 v[m][j] = finish_score<T>(acc[m][n][j], temperature, inv_t, scale);
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
         if (do_stats) {
             float sum = 0.f;
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < MA; ++m)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (pbase + 16 * m + j < P) sum += exp_sub(v[m][j], mx * RPO_LOG2E);
@@ -236,7 +240,7 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
                 const float om = __shfl_xor(mx, o, 64), ol = __shfl_xor(sum, o, 64);
                 softmax_merge(mx, sum, om, ol);
             }
-            if (wp == 1 && g == 0) s_stat[wq * 64 + 16 * n + frow] = make_float2(mx, sum);
+            if (wp == 1 && g == 0) s_stat[wq * (TQ / 2) + 16 * n + frow] = make_float2(mx, sum);
             acc[0][n][0] = mx;   // keep for the cross-wave merge below
             acc[0][n][1] = sum;
         }
@@ -245,10 +249,10 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
         __syncthreads();
         if (wp == 0 && g == 0) {
 #pragma unroll
-            for (int n = 0; n < 4; ++n) {
+            for (int n = 0; n < NB; ++n) {
                 const int64_t qi = qbase + 16 * n;
                 float mx = acc[0][n][0], sum = acc[0][n][1];
-                const float2 o = s_stat[wq * 64 + 16 * n + frow];
+                const float2 o = s_stat[wq * (TQ / 2) + 16 * n + frow];
                 softmax_merge(mx, sum, o.x, o.y);
                 if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
             }
@@ -1190,6 +1194,7 @@ struct Plan {
     int path;
     int nPb;          // passage column blocks (partials per row)
     int nPt, nQt;     // tile grid
+    int tp, tq;       // PATH_TILE: tile shape (passages x queries)
     int nFin;         // finalize blocks
     size_t off_partial, off_blocksum, off_raw, total;
 };
@@ -1216,10 +1221,19 @@ static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) 
         // the 256 x 256 kernel runs one block per CU: take it only when its grid can fill most of the 256 CUs
         const bool big = dtype == RPO_DT_BF16 &&
                          rpo_cdiv(P, kBigTile) * rpo_cdiv(Q, kBigTile) >= 192;
-        const int tile = big ? kBigTile : kTileP;
         pl.path = big ? PATH_TILE256 : PATH_TILE;
-        pl.nPt = (int)rpo_cdiv(P, tile);
-        pl.nQt = (int)rpo_cdiv(Q, tile);
+        pl.tp = pl.tq = big ? kBigTile : kTileP;
+        if (!big) {
+            // the largest tile that still gives every CU two blocks (the kernel's occupancy); else the smallest.  The query side
+            // shrinks first: a wave's row segments of the score matrix stay 64 passages = 128 bytes (bf16) long
+            const int64_t want = 2 * 256;
+            if (rpo_cdiv(P, 128) * rpo_cdiv(Q, 128) < want) {
+                pl.tq = 64;
+                if (rpo_cdiv(P, 128) * rpo_cdiv(Q, 64) < want) pl.tp = 64;
+            }
+        }
+        pl.nPt = (int)rpo_cdiv(P, pl.tp);
+        pl.nQt = (int)rpo_cdiv(Q, pl.tq);
         pl.nPb = pl.nPt;
     }
     pl.nFin = (int)rpo_cdiv(Q, kFinThreads);
@@ -1262,13 +1276,22 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
     if (pl.path == PATH_TILE) {
         static bool attr_set = false;   // idempotent; a race only repeats the same call
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kTileLdsBytes);
+            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      tile_lds_bytes(128, 128));
+            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      tile_lds_bytes(128, 64));
             attr_set = true;
         }
-        RPO_LAUNCH(sim_tile_kernel<T>, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kTileThreads), kTileLdsBytes,
-                           st, (const T*)q, (const T*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
-                           (T*)scores_out, partial, pl.nPt, pl.nQt);
+        const dim3 grid((unsigned)(pl.nPt * pl.nQt)), block(kTileThreads);
+        if (pl.tp == 128 && pl.tq == 128)
+            RPO_LAUNCH((sim_tile_kernel<T, 128, 128>), grid, block, tile_lds_bytes(128, 128), st, (const T*)q, (const T*)p, Q, P, d,
+                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
+        else if (pl.tp == 128)
+            RPO_LAUNCH((sim_tile_kernel<T, 128, 64>), grid, block, tile_lds_bytes(128, 64), st, (const T*)q, (const T*)p, Q, P, d,
+                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
+        else
+            RPO_LAUNCH((sim_tile_kernel<T, 64, 64>), grid, block, tile_lds_bytes(64, 64), st, (const T*)q, (const T*)p, Q, P, d,
+                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
     } else if (pl.path == PATH_TILE256) {
         if constexpr (sizeof(T) == 2) {
             static bool attr_set256 = false;
@@ -1380,7 +1403,7 @@ static int check_common(const void* q, const void* p, int64_t Q, int64_t P, int6
     if (!(temperature > 0.f)) return RPO_ERR_INVALID_ARG;
     if (target_mode == RPO_TARGET_FIRST && P % Q != 0) return RPO_ERR_INVALID_ARG;  // .view(Q, G, -1)
     if (Q > INT32_MAX || P > INT32_MAX || d > INT32_MAX) return RPO_ERR_UNSUPPORTED;
-    if (rpo_cdiv(P, kTileP) * rpo_cdiv(Q, kTileQ) > INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    if (rpo_cdiv(P, 64) * rpo_cdiv(Q, 64) > INT32_MAX) return RPO_ERR_UNSUPPORTED;
     return RPO_OK;
 }
 

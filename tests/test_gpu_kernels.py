@@ -157,6 +157,10 @@ SHAPES = [
     (130, 390, 192),    # tile, ragged edges
     (128, 128, 64),     # tile, single K step (bf16)
     (100, 700, 96),     # Q > 64 with d % 64 != 0 -> rowwise (bf16) / tile (f32)
+    # tile kernel, one shape per tile size the host picks (largest tile that still gives every CU two blocks, round 4)
+    (2048, 4096, 64),   # 128 x 128 tiles (512 of them)
+    (1536, 3072, 64),   # 128 passages x 64 queries
+    (1024, 1024, 128),  # 64 x 64 (SURVEY 8d's smallest sweep point, at a quarter of its depth)
     (512, 512, 64),     # 256x256 phased tile kernel (bf16), single K step
     (512, 1536, 256),   # 256x256 kernel, 4 K steps
     (600, 1800, 192),   # 256x256 kernel, ragged edges in both dimensions, odd K-step count
