@@ -116,9 +116,29 @@ __device__ __forceinline__ void store_scores4(T* row_ptr, int64_t col, int64_t n
 // 1024^2 sweep points and every mid-size shape between the skinny kernel and the 256 x 256 kernel).
 constexpr int kTileP = 128, kTileQ = 128, kTileRowBytes = 128;   // the LARGEST tile (grid-size limits)
 constexpr int kTileThreads = 256;
-constexpr int tile_lds_bytes(int TP, int TQ) { return 2 * (TP + TQ) * kTileRowBytes; }   // A0 A1 B0 B1: 64 KiB at 128 x 128
+// K loop: a ring of S stages of (A | B) K-steps filled by LDS-DMA, S - 1 of them in flight, ONE raw barrier per K-step, counted
+// s_waitcnt vmcnt.  A small tile's K-step is ~100 ns of MFMAs against ~1 us of load latency, and the grids that get small tiles
+// have one block per CU, so nothing else hides it: with the two-stage ring of rounds 1-3 the 64 x 64 tile ran at one K-step per
+// memory round trip (29 us for 32 K-steps at Q = P = 1024, d = 2048).  S = 2 at 128 x 128 (64 KiB, two blocks per CU, as before),
+// 3 at 128 x 64 (72 KiB, two blocks), 8 at 64 x 64 (128 KiB, one block).
+constexpr int tile_lds_bytes(int TP, int TQ, int S) { return S * (TP + TQ) * kTileRowBytes; }
 
-template <typename T, int TP, int TQ>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_imm() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+// all but the `later` youngest STAGES of this wave have landed (IPS DMA instructions per stage); later <= J
+template <int J, int IPS>
+struct WaitStages {
+    static __device__ __forceinline__ void go(int later) {
+        if (later >= J) wait_vmcnt_imm<J * IPS>();
+        else WaitStages<J - 1, IPS>::go(later);
+    }
+};
+template <int IPS>
+struct WaitStages<0, IPS> {
+    static __device__ __forceinline__ void go(int) { wait_vmcnt_imm<0>(); }
+};
+
+template <typename T, int TP, int TQ, int S>
 __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
     int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt) {
@@ -127,7 +147,8 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     constexpr int KE = kTileRowBytes / (int)sizeof(T);   // K elements per tile row (64 bf16 / 32 f32)
     constexpr int CE = 16 / (int)sizeof(T);              // elements per 16-byte chunk
     constexpr int MA = TP / 32, NB = TQ / 32;            // 16-row fragments per wave along passages / queries
-    constexpr int kABuf = TP * kTileRowBytes, kBBuf = TQ * kTileRowBytes;
+    constexpr int kABuf = TP * kTileRowBytes, kStage = (TP + TQ) * kTileRowBytes;
+    static_assert((S - 1) * (MA + NB) <= 63, "vmcnt is a 6-bit counter");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -165,13 +186,13 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
 #pragma unroll
         for (int i = 0; i < MA; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(smem + buf * kABuf + (4 * i + wave) * 1024),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * kStage + (4 * i + wave) * 1024),
                                              16, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
             __builtin_amdgcn_global_load_lds(
                 (const __attribute__((address_space(1))) void*)(b_src[i] + k0),
-                (__attribute__((address_space(3))) void*)(smem + 2 * kABuf + buf * kBBuf + (4 * i + wave) * 1024), 16, 0, 0);
+                (__attribute__((address_space(3))) void*)(smem + buf * kStage + kABuf + (4 * i + wave) * 1024), 16, 0, 0);
     };
 
     float4_t acc[MA][NB];
@@ -182,14 +203,18 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
 
     const int nk = (int)(d / KE);
     const int frow = lane & 15;
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < S - 1; ++t)
+        if (t < nk) stage(t, t);
+    int cur = 0, nxt = S - 1;                                // ring slots of K-step t and of K-step t + S - 1
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        if (t + 1 < nk) stage(t + 1, cur ^ 1);
-        const char* Ab = smem + cur * kABuf + (wp * (TP / 2) + frow) * kTileRowBytes;
-        const char* Bb = smem + 2 * kABuf + cur * kBBuf + (wq * (TQ / 2) + frow) * kTileRowBytes;
+        // K-step t has landed: this wave issued min(S - 2, nk - 1 - t) younger stages; every wave says so at the barrier, which
+        // also tells that everybody is done reading K-step t - 1, whose slot the next DMA overwrites
+        WaitStages<S - 2, MA + NB>::go(min(S - 2, nk - 1 - t));
+        __builtin_amdgcn_s_barrier();
+        if (t + S - 1 < nk) stage(t + S - 1, nxt);
+        const char* Ab = smem + cur * kStage + (wp * (TP / 2) + frow) * kTileRowBytes;
+        const char* Bb = smem + cur * kStage + kABuf + (wq * (TQ / 2) + frow) * kTileRowBytes;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             const int coff = (((ks * 4 + g) ^ (lane & 7)) << 4);
@@ -203,9 +228,10 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
 #pragma unroll
                 for (int n = 0; n < NB; ++n) Mma<T>::mma(a[m], b[n], acc[m][n]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        cur = cur + 1 == S ? 0 : cur + 1;
+        nxt = nxt + 1 == S ? 0 : nxt + 1;
     }
+    __syncthreads();                                         // the ring is free: the epilogue reuses its first bytes
 
     // ---- epilogue: acc[m][n][j] = <p_{pbase + 16m + 4g + j}, q_{qbase + 16n + (lane&15)}>
     const int64_t pbase = p0 + wp * (TP / 2) + g * 4;
@@ -1276,21 +1302,23 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
     if (pl.path == PATH_TILE) {
         static bool attr_set = false;   // idempotent; a race only repeats the same call
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T, 128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      tile_lds_bytes(128, 128));
-            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T, 128, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      tile_lds_bytes(128, 64));
+            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T, 128, 128, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      tile_lds_bytes(128, 128, 2));
+            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T, 128, 64, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      tile_lds_bytes(128, 64, 3));
+            (void)hipFuncSetAttribute((const void*)sim_tile_kernel<T, 64, 64, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      tile_lds_bytes(64, 64, 8));
             attr_set = true;
         }
         const dim3 grid((unsigned)(pl.nPt * pl.nQt)), block(kTileThreads);
         if (pl.tp == 128 && pl.tq == 128)
-            RPO_LAUNCH((sim_tile_kernel<T, 128, 128>), grid, block, tile_lds_bytes(128, 128), st, (const T*)q, (const T*)p, Q, P, d,
-                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
+            RPO_LAUNCH((sim_tile_kernel<T, 128, 128, 2>), grid, block, tile_lds_bytes(128, 128, 2), st, (const T*)q, (const T*)p, Q, P,
+                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
         else if (pl.tp == 128)
-            RPO_LAUNCH((sim_tile_kernel<T, 128, 64>), grid, block, tile_lds_bytes(128, 64), st, (const T*)q, (const T*)p, Q, P, d,
-                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
+            RPO_LAUNCH((sim_tile_kernel<T, 128, 64, 3>), grid, block, tile_lds_bytes(128, 64, 3), st, (const T*)q, (const T*)p, Q, P,
+                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
         else
-            RPO_LAUNCH((sim_tile_kernel<T, 64, 64>), grid, block, tile_lds_bytes(64, 64), st, (const T*)q, (const T*)p, Q, P, d,
+            RPO_LAUNCH((sim_tile_kernel<T, 64, 64, 8>), grid, block, tile_lds_bytes(64, 64, 8), st, (const T*)q, (const T*)p, Q, P, d,
                        temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
     } else if (pl.path == PATH_TILE256) {
         if constexpr (sizeof(T) == 2) {
