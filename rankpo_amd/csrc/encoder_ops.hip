@@ -467,11 +467,21 @@ int launch_norm_bwd(const void* dy, const void* xn, const void* w, const float* 
 
 }  // namespace
 
-extern "C" int rpo_add_rmsnorm_waves(int64_t rows) {
-    // number of waves (= rows of dw_partial) the two kernels below use for `rows` rows: a multiple of 4, <= 8192
-    int64_t w = rows < 8192 ? rows : 8192;
+#ifndef RPO_NORM_FWD_CAP
+#define RPO_NORM_FWD_CAP 8192
+#endif
+#ifndef RPO_NORM_BWD_CAP
+#define RPO_NORM_BWD_CAP 8192
+#endif
+static int norm_waves(int64_t rows, int64_t cap) {
+    int64_t w = rows < cap ? rows : cap;
     w = (w + 3) / 4 * 4;
     return (int)(w < 4 ? 4 : w);
+}
+
+extern "C" int rpo_add_rmsnorm_waves(int64_t rows) {
+    // number of waves (= rows of dw_partial) the BACKWARD kernel uses for `rows` rows: a multiple of 4, <= the cap
+    return norm_waves(rows, RPO_NORM_BWD_CAP);
 }
 
 extern "C" int rpo_add_rmsnorm_fwd(const void* x, const void* delta, const void* weight, float eps, void* x_out,
@@ -487,7 +497,7 @@ extern "C" int rpo_add_rmsnorm_fwd(const void* x, const void* delta, const void*
     // (round 3, measured and dropped: ONE row per wave, as many waves as rows -- the forward has no per-wave output that would
     // bound its wave count -- moved 5.71 TB/s at d = 2048 against 5.98 for this capped loop, 5.06 against 4.96 at d = 4096:
     // tools/norm_ab.py)
-    const int nw = rpo_add_rmsnorm_waves(rows);
+    const int nw = norm_waves(rows, RPO_NORM_FWD_CAP);       // (the forward writes no per-wave partials: its count is its own)
     if (dtype == RPO_DT_BF16) return launch_norm_fwd<bf16_t>(x, delta, weight, eps, x_out, y_out, rstd_out, rows, d, nw, st);
     if (dtype == RPO_DT_F32) return launch_norm_fwd<float>(x, delta, weight, eps, x_out, y_out, rstd_out, rows, d, nw, st);
     return RPO_ERR_INVALID_ARG;
