@@ -114,7 +114,7 @@ __device__ __forceinline__ void store_scores4(T* row_ptr, int64_t col, int64_t n
 // (16 MFMAs per 8 LDS fragment reads); a grid of few such tiles leaves most of the 256 CUs idle -- Q = P = 1024 is 64 tiles --
 // so the host picks 128 x 64 or 64 x 64 when the larger tile would not give every CU two blocks (round 4: SURVEY 8d's
 // 1024^2 sweep points and every mid-size shape between the skinny kernel and the 256 x 256 kernel).
-constexpr int kTileP = 128, kTileQ = 128, kTileRowBytes = 128;   // the LARGEST tile (grid-size limits)
+constexpr int kTileP = 128, kTileRowBytes = 128;   // kTileP: the LARGEST tile edge
 constexpr int kTileThreads = 256;
 // K loop: a ring of S stages of (A | B) K-steps filled by LDS-DMA, S - 1 of them in flight, ONE raw barrier per K-step, counted
 // s_waitcnt vmcnt.  A small tile's K-step is ~100 ns of MFMAs against ~1 us of load latency, and the grids that get small tiles

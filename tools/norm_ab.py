@@ -17,16 +17,21 @@ for rows, d in ((155136, 2048), (155136, 4096)):
     x = torch.randn(rows, d, device=DEV).to(torch.bfloat16); dl = torch.randn_like(x); w = torch.randn(d, device=DEV).to(torch.bfloat16)
     dy = torch.randn_like(x); dres = torch.randn_like(x)
     outs = {}
+    # ONE set of buffers for every arm (separate allocations measured up to 15 % apart on identical code: placement), the arms'
+    # order rotated every round
+    nwmax = max(l.rpo_add_rmsnorm_waves(rows) for l in libs.values())
+    xo, y, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    rstd = torch.empty(rows, device=DEV); dwp = torch.empty(nwmax, d, device=DEV)
     for n, l in libs.items():
-        nw = l.rpo_add_rmsnorm_waves(rows)
-        xo, y, dx = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-        rstd = torch.empty(rows, device=DEV); dwp = torch.empty(nw, d, device=DEV)
-        f = lambda l=l, xo=xo, y=y, rstd=rstd: l.rpo_add_rmsnorm_fwd(x.data_ptr(), dl.data_ptr(), w.data_ptr(), 1e-5, xo.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, d, 1, st)
-        b = lambda l=l, xo=xo, dx=dx, rstd=rstd, dwp=dwp: l.rpo_add_rmsnorm_bwd(dy.data_ptr(), xo.data_ptr(), w.data_ptr(), rstd.data_ptr(), dres.data_ptr(), dx.data_ptr(), dwp.data_ptr(), rows, d, 1, st)
-        outs[n] = (f, b, xo, y, dx, dwp)
+        f = lambda l=l: l.rpo_add_rmsnorm_fwd(x.data_ptr(), dl.data_ptr(), w.data_ptr(), 1e-5, xo.data_ptr(), y.data_ptr(), rstd.data_ptr(), rows, d, 1, st)
+        b = lambda l=l: l.rpo_add_rmsnorm_bwd(dy.data_ptr(), xo.data_ptr(), w.data_ptr(), rstd.data_ptr(), dres.data_ptr(), dx.data_ptr(), dwp.data_ptr(), rows, d, 1, st)
+        outs[n] = (f, b)
     res = {n: {"fwd": [], "bwd": []} for n in libs}
-    for rnd in range(6):
-        for n, (f, b, *_) in outs.items():
+    names = list(libs)
+    for rnd in range(2 * len(names) + 1):
+        order = names[rnd % len(names):] + names[:rnd % len(names)]
+        for n in order:
+            f, b = outs[n]
             for key, fn in (("fwd", f), ("bwd", b)):
                 assert fn() == 0
                 torch.cuda.synchronize()
@@ -38,6 +43,4 @@ for rows, d in ((155136, 2048), (155136, 4096)):
     for n in libs:
         fw, bw = np.median(res[n]["fwd"]), np.median(res[n]["bwd"])
         print(f"[{rows}, {d}] {n}: fwd {fw * 1e3:.1f} us = {4 * rows * d * 2 / fw / 1e9:.2f} TB/s ; bwd {bw * 1e3:.1f} us = {4 * rows * d * 2 / bw / 1e9:.2f} TB/s")
-    names = list(libs)
-    for n in names[1:]:
-        print("   identical:", all(torch.equal(a, b) for a, b in zip(outs[names[0]][2:], outs[n][2:])))
+        print(f"      min fwd {min(res[n]['fwd']) * 1e3:.1f} / bwd {min(res[n]['bwd']) * 1e3:.1f} us")
