@@ -108,6 +108,90 @@ __device__ __forceinline__ void store_scores4(T* row_ptr, int64_t col, int64_t n
 }
 
 // ------------------------------------------------------------------------------------------------
+// Single-launch finalize of the tile kernels (round 4).  Rounds 1-3 followed every tile launch with ce_finalize_kernel: a second
+// launch costs ~4-7 us behind the first on one stream -- 10 % of the 4096^2 x 2048 sweep point, a quarter of the 1024^2 ones.
+// Now the LAST block to arrive of each query tile merges that tile's rows (partials in passage-block order: the same lse as
+// ce_finalize_kernel to the bit), writes lse, sums its rows' losses in fixed order and publishes the sum; the last QUERY TILE to
+// finish adds the tile sums in index order and writes the loss: two levels of arrival counters, deterministic.
+// Counters: epoch-stamped 64-bit words (word = epoch << 32 | arrivals; an arriver whose epoch is not the word's starts over), so
+// a slot needs neither a memset in front of the launch nor a reset behind it and a launch that never finished leaves nothing a
+// later one could inherit.  A launch owns one RANGE of kFinRangeSlots words (nQt first-level + 1 second-level), ranges handed
+// out round-robin with epoch = launch number / kFinRanges + 1; two launches on one range in flight at once would disturb each
+// other, which takes kFinRanges tile launches in flight at the same time.
+// Visibility (MI355X_MICROARCH.md, cross-workgroup hand-off): every storing block's stores precede a workgroup barrier, ONE lane then
+// arrives with an agent-scope acquire-release atomic; the block whose arrival came last reads, behind a barrier that lane joins,
+// with agent-scope loads.
+// ------------------------------------------------------------------------------------------------
+constexpr int kFinRanges = 16, kFinRangeSlots = 128;
+__device__ unsigned long long g_tile_ticket[kFinRanges * kFinRangeSlots];
+static std::atomic<unsigned long long> g_tile_next_launch{0};
+
+struct FusedFin {          // slot < 0: no fused finalize (ce_finalize_kernel follows)
+    float* lse;
+    float* loss;
+    float* tilesum;        // [nQt] in the caller's workspace
+    int64_t group;         // P / Q: the positive of row i is column i * group (modeling.py:301-302)
+    int slot;
+    unsigned epoch;
+};
+
+// arrival `n` of `expected` on an epoch-stamped counter; true for the last arriver
+__device__ __forceinline__ bool ticket_arrive(unsigned long long* ticket, unsigned epoch, unsigned expected) {
+    unsigned long long seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+    do {
+        const unsigned arrived = (unsigned)(seen >> 32) == epoch ? (unsigned)seen : 0u;
+        want = ((unsigned long long)epoch << 32) | (arrived + 1u);
+    } while (!__hip_atomic_compare_exchange_strong(ticket, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return (unsigned)want == expected;
+}
+
+// Called by ALL threads of a tile block after its partial[] stores.  TQ rows per query tile, NW waves per block.
+template <typename T, int TQ, int NW>
+__device__ __forceinline__ void tile_fused_finalize(const FusedFin& f, const float2* __restrict__ partial, const T* __restrict__ scores,
+                                                    int64_t Q, int64_t P, int nPt, int nQt, int qt, int64_t q0) {
+    __shared__ int s_last;
+    __shared__ float s_red[NW];
+    const int tid = threadIdx.x;
+    __syncthreads();                                        // the block's partial / score stores happen-before thread 0's release
+    if (tid == 0) s_last = ticket_arrive(g_tile_ticket + f.slot + qt, f.epoch, (unsigned)nPt) ? 1 : 0;
+    __syncthreads();
+    if (!s_last) return;
+    float rowloss = 0.f;
+    const int64_t i = q0 + tid;
+    if (tid < TQ && i < Q) {
+        float m = RPO_NEG_INF, l = 0.f;
+        const unsigned long long* pw = reinterpret_cast<const unsigned long long*>(partial);
+        for (int b = 0; b < nPt; ++b) {
+            const unsigned long long w = __hip_atomic_load(pw + (int64_t)b * Q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            softmax_merge(m, l, __uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
+        }
+        const float lse = m + logf(l);
+        f.lse[i] = lse;
+        const T* sp = scores + i * P + i * f.group;          // the positive's score as stored (another block may have written it)
+        float tgt;
+        if constexpr (sizeof(T) == 2) {
+            tgt = __uint_as_float((unsigned)__hip_atomic_load(reinterpret_cast<const unsigned short*>(sp), __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_AGENT) << 16);
+        } else {
+            tgt = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(sp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        rowloss = lse - tgt;
+    }
+    const float ts = block_sum<NW>(rowloss, s_red);
+    if (tid != 0) return;
+    if (nQt == 1) {
+        f.loss[0] = ts / (float)Q;
+        return;
+    }
+    __hip_atomic_store(f.tilesum + qt, ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ticket_arrive(g_tile_ticket + f.slot + nQt, f.epoch, (unsigned)nQt)) {
+        float tot = 0.f;
+        for (int b = 0; b < nQt; ++b) tot += __hip_atomic_load(f.tilesum + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        f.loss[0] = tot / (float)Q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Big tile kernel
 // ------------------------------------------------------------------------------------------------
 // Tile = TP passages x TQ queries, 4 waves as 2 x 2, TP / 2 x TQ / 2 scores^T per wave.  128 x 128 is the efficient shape
@@ -141,7 +225,7 @@ struct WaitStages<0, IPS> {
 template <typename T, int TP, int TQ, int S>
 __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
-    int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt) {
+    int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt, FusedFin fin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mma<T>::Frag Frag;
     constexpr int KE = kTileRowBytes / (int)sizeof(T);   // K elements per tile row (64 bf16 / 32 f32)
@@ -283,6 +367,7 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
                 if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
             }
         }
+        if (fin.slot >= 0) tile_fused_finalize<T, TQ, kTileThreads / 64>(fin, partial, scores, Q, P, nPt, nQt, qt, q0);
     }
 }
 
@@ -323,7 +408,7 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
 __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
     int scale, int do_stats, bf16_t* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt,
-    int stagger, int dbg) {
+    int stagger, int dbg, FusedFin fin) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef short8_t Frag;
     constexpr int KE = 64;   // bf16 elements per K-step
@@ -613,6 +698,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                 if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
             }
         }
+        if (fin.slot >= 0) tile_fused_finalize<bf16_t, kBigTile, kBigThreads / 64>(fin, partial, scores, Q, P, nPt, nQt, qt, q0);
     }
 }
 
@@ -791,13 +877,7 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
         // release: the block's stores (ordered before this by the barrier) are visible to whoever reads the ticket; acquire: the
         // last arriver sees every other block's.  (A compare-and-swap loop instead of one fetch-add: the stale-epoch case has to
         // replace the word, not add to it; the loop retries only when another block arrived in between.)
-        unsigned long long seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
-        do {
-            const unsigned arrived = (unsigned)(seen >> 32) == ticket_epoch ? (unsigned)seen : 0u;
-            want = ((unsigned long long)ticket_epoch << 32) | (arrived + 1u);
-        } while (!__hip_atomic_compare_exchange_strong(ticket, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
-                                                       __HIP_MEMORY_SCOPE_AGENT));
-        s_last = ((unsigned)want == gridDim.x);
+        s_last = ticket_arrive(ticket, ticket_epoch, gridDim.x) ? 1 : 0;
     }
     __syncthreads();
     if (!s_last) return;
@@ -1267,8 +1347,8 @@ static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) 
     pl.off_partial = off;
     off += (size_t)pl.nPb * (size_t)Q * sizeof(float2);
     off = (off + 255) & ~(size_t)255;
-    pl.off_blocksum = off;
-    off += (size_t)pl.nFin * sizeof(float);
+    pl.off_blocksum = off;                              // ce_finalize's block sums [nFin] / the fused finalize's tile sums [nQt]
+    off += (size_t)(pl.nFin > pl.nQt ? pl.nFin : pl.nQt) * sizeof(float);
     off = (off + 255) & ~(size_t)255;
     pl.off_raw = off;                                   // RPO_TARGET_FIRST raw dots [Q, P/Q]
     off += (size_t)P * sizeof(float);
@@ -1299,6 +1379,14 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
     }
     float2* partial = do_stats ? (float2*)(wsb + pl.off_partial) : nullptr;
     bool fused_finalize = false;      // the forward kernel wrote lse and loss itself (single-block skinny launch)
+    FusedFin fin{lse_out, loss_out, nullptr, P / Q, -1, 0u};
+    if ((pl.path == PATH_TILE || pl.path == PATH_TILE256) && do_stats && scores_out != nullptr && pl.nQt + 1 <= kFinRangeSlots) {
+        const unsigned long long seq = g_tile_next_launch.fetch_add(1, std::memory_order_relaxed);
+        fin.slot = (int)(seq % (unsigned)kFinRanges) * kFinRangeSlots;
+        fin.epoch = (unsigned)(seq / (unsigned)kFinRanges) + 1u;          // never 0: a zero-initialised word matches no launch
+        fin.tilesum = (float*)(wsb + pl.off_blocksum);
+        fused_finalize = true;
+    }
     if (pl.path == PATH_TILE) {
         static bool attr_set = false;   // idempotent; a race only repeats the same call
         if (!attr_set) {
@@ -1313,13 +1401,13 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         const dim3 grid((unsigned)(pl.nPt * pl.nQt)), block(kTileThreads);
         if (pl.tp == 128 && pl.tq == 128)
             RPO_LAUNCH((sim_tile_kernel<T, 128, 128, 2>), grid, block, tile_lds_bytes(128, 128, 2), st, (const T*)q, (const T*)p, Q, P,
-                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
+                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt, fin);
         else if (pl.tp == 128)
             RPO_LAUNCH((sim_tile_kernel<T, 128, 64, 3>), grid, block, tile_lds_bytes(128, 64, 3), st, (const T*)q, (const T*)p, Q, P,
-                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
+                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt, fin);
         else
             RPO_LAUNCH((sim_tile_kernel<T, 64, 64, 8>), grid, block, tile_lds_bytes(64, 64, 8), st, (const T*)q, (const T*)p, Q, P, d,
-                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
+                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt, fin);
     } else if (pl.path == PATH_TILE256) {
         if constexpr (sizeof(T) == 2) {
             static bool attr_set256 = false;
@@ -1330,7 +1418,7 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
             }
             RPO_LAUNCH(sim_tile256_kernel, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kBigThreads), kBigLdsBytes, st,
                        (const bf16_t*)q, (const bf16_t*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
-                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0);
+                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0, fin);
         }
     } else if (pl.path == PATH_SKINNY) {
         const int ng = Q <= 16 ? 4 : 1;
