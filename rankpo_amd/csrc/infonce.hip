@@ -118,9 +118,13 @@ __device__ __forceinline__ void store_scores4(T* row_ptr, int64_t col, int64_t n
 // later one could inherit.  A launch owns one RANGE of kFinRangeSlots words (nQt first-level + 1 second-level), ranges handed
 // out round-robin with epoch = launch number / kFinRanges + 1; two launches on one range in flight at once would disturb each
 // other, which takes kFinRanges tile launches in flight at the same time.
-// Visibility (MI355X_MICROARCH.md, cross-workgroup hand-off): every storing block's stores precede a workgroup barrier, ONE lane then
-// arrives with an agent-scope acquire-release atomic; the block whose arrival came last reads, behind a barrier that lane joins,
-// with agent-scope loads.
+// Visibility (MI355X_MICROARCH.md, cross-workgroup hand-off, the `sc1` form): the handed-off bytes -- the softmax partials, the
+// positives' scores (copied into a side array `tgt[Q]` by the block that holds them) and the tile sums -- are stored WRITE-THROUGH
+// (agent-scope relaxed atomic stores = `global_store ... sc1`), every storing wave waits `vmcnt(0)`, a workgroup barrier, then ONE
+// lane arrives with a RELAXED agent-scope atomic.  No release fence: an agent release is `buffer_wbl2`, a write-back of the whole
+// XCD's L2 -- per BLOCK, with 128 KB of freshly stored scores each, that took the 16384^2 x 2048 point from 0.96 to 1.42 ms (the
+// first version of this code arrived acquire-release).  Only the LAST arriver pays an agent acquire (one L1 invalidate per query
+// tile) and reads with `sc1` loads behind a barrier its arriving lane joins.
 // ------------------------------------------------------------------------------------------------
 constexpr int kFinRanges = 16, kFinRangeSlots = 128;
 __device__ unsigned long long g_tile_ticket[kFinRanges * kFinRangeSlots];
@@ -130,6 +134,7 @@ struct FusedFin {          // slot < 0: no fused finalize (ce_finalize_kernel fo
     float* lse;
     float* loss;
     float* tilesum;        // [nQt] in the caller's workspace
+    float* tgt;            // [Q] in the caller's workspace: the positives' scores, written through by the blocks that hold them
     int64_t group;         // P / Q: the positive of row i is column i * group (modeling.py:301-302)
     int slot;
     unsigned epoch;
@@ -144,16 +149,55 @@ __device__ __forceinline__ bool ticket_arrive(unsigned long long* ticket, unsign
     } while (!__hip_atomic_compare_exchange_strong(ticket, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     return (unsigned)want == expected;
 }
+// the same with NO ordering of its own: for producers whose handed-off bytes were stored write-through and waited for
+__device__ __forceinline__ bool ticket_arrive_relaxed(unsigned long long* ticket, unsigned epoch, unsigned expected) {
+    unsigned long long seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+    do {
+        const unsigned arrived = (unsigned)(seen >> 32) == epoch ? (unsigned)seen : 0u;
+        want = ((unsigned long long)epoch << 32) | (arrived + 1u);
+    } while (!__hip_atomic_compare_exchange_strong(ticket, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    return (unsigned)want == expected;
+}
+__device__ __forceinline__ void store_partial_wt(float2* p, float mx, float sum) {          // one 8-byte write-through store
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
+                       (unsigned long long)__float_as_uint(mx) | ((unsigned long long)__float_as_uint(sum) << 32), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+}
 
-// Called by ALL threads of a tile block after its partial[] stores.  TQ rows per query tile, NW waves per block.
-template <typename T, int TQ, int NW>
+// Called by ALL threads of a tile block after its score and (write-through) partial[] stores.  TQ rows per query tile, TP passage
+// columns per tile, NW waves per block.
+template <typename T, int TP, int TQ, int NW>
 __device__ __forceinline__ void tile_fused_finalize(const FusedFin& f, const float2* __restrict__ partial, const T* __restrict__ scores,
-                                                    int64_t Q, int64_t P, int nPt, int nQt, int qt, int64_t q0) {
+                                                    int64_t Q, int64_t P, int nPt, int nQt, int qt, int64_t q0, int64_t p0) {
     __shared__ int s_last;
     __shared__ float s_red[NW];
     const int tid = threadIdx.x;
-    __syncthreads();                                        // the block's partial / score stores happen-before thread 0's release
-    if (tid == 0) s_last = ticket_arrive(g_tile_ticket + f.slot + qt, f.epoch, (unsigned)nPt) ? 1 : 0;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's score / partial stores have left
+    __syncthreads();
+    // the positives this block holds (row i <-> column i * group): copy them, write-through, where the finalizer will look.  The
+    // block reads its OWN scores (its XCD's L2 has them; sc1 = past this CU's L1, which may hold the address from an earlier launch)
+    {
+        const int64_t i = q0 + tid, c = i * f.group;
+        if (tid < TQ && i < Q && c >= p0 && c < p0 + TP) {
+            float v;
+            if constexpr (sizeof(T) == 2)
+                v = __uint_as_float((unsigned)__hip_atomic_load(reinterpret_cast<const unsigned short*>(scores + i * P + c), __ATOMIC_RELAXED,
+                                                                __HIP_MEMORY_SCOPE_AGENT) << 16);
+            else
+                v = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(scores + i * P + c), __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT));
+            __hip_atomic_store(f.tgt + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+        s_last = ticket_arrive_relaxed(g_tile_ticket + f.slot + qt, f.epoch, (unsigned)nPt) ? 1 : 0;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
     __syncthreads();
     if (!s_last) return;
     float rowloss = 0.f;
@@ -167,15 +211,7 @@ __device__ __forceinline__ void tile_fused_finalize(const FusedFin& f, const flo
         }
         const float lse = m + logf(l);
         f.lse[i] = lse;
-        const T* sp = scores + i * P + i * f.group;          // the positive's score as stored (another block may have written it)
-        float tgt;
-        if constexpr (sizeof(T) == 2) {
-            tgt = __uint_as_float((unsigned)__hip_atomic_load(reinterpret_cast<const unsigned short*>(sp), __ATOMIC_RELAXED,
-                                                              __HIP_MEMORY_SCOPE_AGENT) << 16);
-        } else {
-            tgt = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(sp), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        }
-        rowloss = lse - tgt;
+        rowloss = lse - __hip_atomic_load(f.tgt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const float ts = block_sum<NW>(rowloss, s_red);
     if (tid != 0) return;
@@ -184,7 +220,10 @@ __device__ __forceinline__ void tile_fused_finalize(const FusedFin& f, const flo
         return;
     }
     __hip_atomic_store(f.tilesum + qt, ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ticket_arrive(g_tile_ticket + f.slot + nQt, f.epoch, (unsigned)nQt)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ticket_arrive_relaxed(g_tile_ticket + f.slot + nQt, f.epoch, (unsigned)nQt)) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         float tot = 0.f;
         for (int b = 0; b < nQt; ++b) tot += __hip_atomic_load(f.tilesum + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         f.loss[0] = tot / (float)Q;
@@ -364,10 +403,13 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
                 float mx = acc[0][n][0], sum = acc[0][n][1];
                 const float2 o = s_stat[wq * (TQ / 2) + 16 * n + frow];
                 softmax_merge(mx, sum, o.x, o.y);
-                if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
+                if (qi < Q) {
+                    if (fin.slot >= 0) store_partial_wt(partial + (int64_t)pt * Q + qi, mx, sum);
+                    else partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
+                }
             }
         }
-        if (fin.slot >= 0) tile_fused_finalize<T, TQ, kTileThreads / 64>(fin, partial, scores, Q, P, nPt, nQt, qt, q0);
+        if (fin.slot >= 0) tile_fused_finalize<T, TP, TQ, kTileThreads / 64>(fin, partial, scores, Q, P, nPt, nQt, qt, q0, p0);
     }
 }
 
@@ -695,10 +737,14 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                 float mx = acc[0][n][0], sum = acc[0][n][1];
                 const float2 o = s_stat[wq * 64 + 16 * n + frow];
                 softmax_merge(mx, sum, o.x, o.y);
-                if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
+                if (qi < Q) {
+                    if (fin.slot >= 0) store_partial_wt(partial + (int64_t)pt * Q + qi, mx, sum);
+                    else partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
+                }
             }
         }
-        if (fin.slot >= 0) tile_fused_finalize<bf16_t, kBigTile, kBigThreads / 64>(fin, partial, scores, Q, P, nPt, nQt, qt, q0);
+        if (fin.slot >= 0)
+            tile_fused_finalize<bf16_t, kBigTile, kBigTile, kBigThreads / 64>(fin, partial, scores, Q, P, nPt, nQt, qt, q0, p0);
     }
 }
 
@@ -1379,12 +1425,13 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
     }
     float2* partial = do_stats ? (float2*)(wsb + pl.off_partial) : nullptr;
     bool fused_finalize = false;      // the forward kernel wrote lse and loss itself (single-block skinny launch)
-    FusedFin fin{lse_out, loss_out, nullptr, P / Q, -1, 0u};
+    FusedFin fin{lse_out, loss_out, nullptr, nullptr, P / Q, -1, 0u};
     if ((pl.path == PATH_TILE || pl.path == PATH_TILE256) && do_stats && scores_out != nullptr && pl.nQt + 1 <= kFinRangeSlots) {
         const unsigned long long seq = g_tile_next_launch.fetch_add(1, std::memory_order_relaxed);
         fin.slot = (int)(seq % (unsigned)kFinRanges) * kFinRangeSlots;
         fin.epoch = (unsigned)(seq / (unsigned)kFinRanges) + 1u;          // never 0: a zero-initialised word matches no launch
         fin.tilesum = (float*)(wsb + pl.off_blocksum);
+        fin.tgt = (float*)(wsb + pl.off_raw);            // [P] floats of workspace the in-batch mode does not use otherwise; Q <= P
         fused_finalize = true;
     }
     if (pl.path == PATH_TILE) {
