@@ -108,129 +108,6 @@ __device__ __forceinline__ void store_scores4(T* row_ptr, int64_t col, int64_t n
 }
 
 // ------------------------------------------------------------------------------------------------
-// Single-launch finalize of the tile kernels (round 4).  Rounds 1-3 followed every tile launch with ce_finalize_kernel: a second
-// launch costs ~4-7 us behind the first on one stream -- 10 % of the 4096^2 x 2048 sweep point, a quarter of the 1024^2 ones.
-// Now the LAST block to arrive of each query tile merges that tile's rows (partials in passage-block order: the same lse as
-// ce_finalize_kernel to the bit), writes lse, sums its rows' losses in fixed order and publishes the sum; the last QUERY TILE to
-// finish adds the tile sums in index order and writes the loss: two levels of arrival counters, deterministic.
-// Counters: epoch-stamped 64-bit words (word = epoch << 32 | arrivals; an arriver whose epoch is not the word's starts over), so
-// a slot needs neither a memset in front of the launch nor a reset behind it and a launch that never finished leaves nothing a
-// later one could inherit.  A launch owns one RANGE of kFinRangeSlots words (nQt first-level + 1 second-level), ranges handed
-// out round-robin with epoch = launch number / kFinRanges + 1; two launches on one range in flight at once would disturb each
-// other, which takes kFinRanges tile launches in flight at the same time.
-// Visibility (MI355X_MICROARCH.md, cross-workgroup hand-off, the `sc1` form): the handed-off bytes -- the softmax partials, the
-// positives' scores (copied into a side array `tgt[Q]` by the block that holds them) and the tile sums -- are stored WRITE-THROUGH
-// (agent-scope relaxed atomic stores = `global_store ... sc1`), every storing wave waits `vmcnt(0)`, a workgroup barrier, then ONE
-// lane arrives with a RELAXED agent-scope atomic.  No release fence: an agent release is `buffer_wbl2`, a write-back of the whole
-// XCD's L2 -- per BLOCK, with 128 KB of freshly stored scores each, that took the 16384^2 x 2048 point from 0.96 to 1.42 ms (the
-// first version of this code arrived acquire-release).  Only the LAST arriver pays an agent acquire (one L1 invalidate per query
-// tile) and reads with `sc1` loads behind a barrier its arriving lane joins.
-// ------------------------------------------------------------------------------------------------
-constexpr int kFinRanges = 16, kFinRangeSlots = 128;
-__device__ unsigned long long g_tile_ticket[kFinRanges * kFinRangeSlots];
-static std::atomic<unsigned long long> g_tile_next_launch{0};
-
-struct FusedFin {          // slot < 0: no fused finalize (ce_finalize_kernel follows)
-    float* lse;
-    float* loss;
-    float* tilesum;        // [nQt] in the caller's workspace
-    float* tgt;            // [Q] in the caller's workspace: the positives' scores, written through by the blocks that hold them
-    int64_t group;         // P / Q: the positive of row i is column i * group (modeling.py:301-302)
-    int slot;
-    unsigned epoch;
-};
-
-// arrival `n` of `expected` on an epoch-stamped counter; true for the last arriver
-__device__ __forceinline__ bool ticket_arrive(unsigned long long* ticket, unsigned epoch, unsigned expected) {
-    unsigned long long seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
-    do {
-        const unsigned arrived = (unsigned)(seen >> 32) == epoch ? (unsigned)seen : 0u;
-        want = ((unsigned long long)epoch << 32) | (arrived + 1u);
-    } while (!__hip_atomic_compare_exchange_strong(ticket, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    return (unsigned)want == expected;
-}
-// the same with NO ordering of its own: for producers whose handed-off bytes were stored write-through and waited for
-__device__ __forceinline__ bool ticket_arrive_relaxed(unsigned long long* ticket, unsigned epoch, unsigned expected) {
-    unsigned long long seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
-    do {
-        const unsigned arrived = (unsigned)(seen >> 32) == epoch ? (unsigned)seen : 0u;
-        want = ((unsigned long long)epoch << 32) | (arrived + 1u);
-    } while (!__hip_atomic_compare_exchange_strong(ticket, &seen, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    return (unsigned)want == expected;
-}
-__device__ __forceinline__ void store_partial_wt(float2* p, float mx, float sum) {          // one 8-byte write-through store
-    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p),
-                       (unsigned long long)__float_as_uint(mx) | ((unsigned long long)__float_as_uint(sum) << 32), __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// Called by ALL threads of a tile block after its score and (write-through) partial[] stores.  TQ rows per query tile, TP passage
-// columns per tile, NW waves per block.
-template <typename T, int TP, int TQ, int NW>
-__device__ __forceinline__ void tile_fused_finalize(const FusedFin& f, const float2* __restrict__ partial, const T* __restrict__ scores,
-                                                    int64_t Q, int64_t P, int nPt, int nQt, int qt, int64_t q0, int64_t p0) {
-    __shared__ int s_last;
-    __shared__ float s_red[NW];
-    const int tid = threadIdx.x;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's score / partial stores have left
-    __syncthreads();
-    // the positives this block holds (row i <-> column i * group): copy them, write-through, where the finalizer will look.  The
-    // block reads its OWN scores (its XCD's L2 has them; sc1 = past this CU's L1, which may hold the address from an earlier launch)
-    {
-        const int64_t i = q0 + tid, c = i * f.group;
-        if (tid < TQ && i < Q && c >= p0 && c < p0 + TP) {
-            float v;
-            if constexpr (sizeof(T) == 2)
-                v = __uint_as_float((unsigned)__hip_atomic_load(reinterpret_cast<const unsigned short*>(scores + i * P + c), __ATOMIC_RELAXED,
-                                                                __HIP_MEMORY_SCOPE_AGENT) << 16);
-            else
-                v = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(scores + i * P + c), __ATOMIC_RELAXED,
-                                                      __HIP_MEMORY_SCOPE_AGENT));
-            __hip_atomic_store(f.tgt + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-        s_last = ticket_arrive_relaxed(g_tile_ticket + f.slot + qt, f.epoch, (unsigned)nPt) ? 1 : 0;
-        if (s_last) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    }
-    __syncthreads();
-    if (!s_last) return;
-    float rowloss = 0.f;
-    const int64_t i = q0 + tid;
-    if (tid < TQ && i < Q) {
-        float m = RPO_NEG_INF, l = 0.f;
-        const unsigned long long* pw = reinterpret_cast<const unsigned long long*>(partial);
-        for (int b = 0; b < nPt; ++b) {
-            const unsigned long long w = __hip_atomic_load(pw + (int64_t)b * Q + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            softmax_merge(m, l, __uint_as_float((unsigned)w), __uint_as_float((unsigned)(w >> 32)));
-        }
-        const float lse = m + logf(l);
-        f.lse[i] = lse;
-        rowloss = lse - __hip_atomic_load(f.tgt + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    const float ts = block_sum<NW>(rowloss, s_red);
-    if (tid != 0) return;
-    if (nQt == 1) {
-        f.loss[0] = ts / (float)Q;
-        return;
-    }
-    __hip_atomic_store(f.tilesum + qt, ts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ticket_arrive_relaxed(g_tile_ticket + f.slot + nQt, f.epoch, (unsigned)nQt)) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        float tot = 0.f;
-        for (int b = 0; b < nQt; ++b) tot += __hip_atomic_load(f.tilesum + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f.loss[0] = tot / (float)Q;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Big tile kernel
 // ------------------------------------------------------------------------------------------------
 // Tile = TP passages x TQ queries, 4 waves as 2 x 2, TP / 2 x TQ / 2 scores^T per wave.  128 x 128 is the efficient shape
@@ -264,7 +141,7 @@ struct WaitStages<0, IPS> {
 template <typename T, int TP, int TQ, int S>
 __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
     const T* __restrict__ q, const T* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
-    int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt, FusedFin fin) {
+    int scale, int do_stats, T* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef typename Mma<T>::Frag Frag;
     constexpr int KE = kTileRowBytes / (int)sizeof(T);   // K elements per tile row (64 bf16 / 32 f32)
@@ -403,13 +280,9 @@ __global__ __launch_bounds__(kTileThreads, 2) void sim_tile_kernel(
                 float mx = acc[0][n][0], sum = acc[0][n][1];
                 const float2 o = s_stat[wq * (TQ / 2) + 16 * n + frow];
                 softmax_merge(mx, sum, o.x, o.y);
-                if (qi < Q) {
-                    if (fin.slot >= 0) store_partial_wt(partial + (int64_t)pt * Q + qi, mx, sum);
-                    else partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
-                }
+                if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
             }
         }
-        if (fin.slot >= 0) tile_fused_finalize<T, TP, TQ, kTileThreads / 64>(fin, partial, scores, Q, P, nPt, nQt, qt, q0, p0);
     }
 }
 
@@ -450,7 +323,7 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
 __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
     int scale, int do_stats, bf16_t* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt,
-    int stagger, int dbg, FusedFin fin) {
+    int stagger, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef short8_t Frag;
     constexpr int KE = 64;   // bf16 elements per K-step
@@ -737,14 +610,9 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                 float mx = acc[0][n][0], sum = acc[0][n][1];
                 const float2 o = s_stat[wq * 64 + 16 * n + frow];
                 softmax_merge(mx, sum, o.x, o.y);
-                if (qi < Q) {
-                    if (fin.slot >= 0) store_partial_wt(partial + (int64_t)pt * Q + qi, mx, sum);
-                    else partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
-                }
+                if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
             }
         }
-        if (fin.slot >= 0)
-            tile_fused_finalize<bf16_t, kBigTile, kBigTile, kBigThreads / 64>(fin, partial, scores, Q, P, nPt, nQt, qt, q0, p0);
     }
 }
 
@@ -923,7 +791,13 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
         // release: the block's stores (ordered before this by the barrier) are visible to whoever reads the ticket; acquire: the
         // last arriver sees every other block's.  (A compare-and-swap loop instead of one fetch-add: the stale-epoch case has to
         // replace the word, not add to it; the loop retries only when another block arrived in between.)
-        s_last = ticket_arrive(ticket, ticket_epoch, gridDim.x) ? 1 : 0;
+        unsigned long long seen = __hip_atomic_load(ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), want;
+        do {
+            const unsigned arrived = (unsigned)(seen >> 32) == ticket_epoch ? (unsigned)seen : 0u;
+            want = ((unsigned long long)ticket_epoch << 32) | (arrived + 1u);
+        } while (!__hip_atomic_compare_exchange_strong(ticket, &seen, want, __ATOMIC_ACQ_REL, __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT));
+        s_last = ((unsigned)want == gridDim.x);
     }
     __syncthreads();
     if (!s_last) return;
@@ -1393,8 +1267,8 @@ static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) 
     pl.off_partial = off;
     off += (size_t)pl.nPb * (size_t)Q * sizeof(float2);
     off = (off + 255) & ~(size_t)255;
-    pl.off_blocksum = off;                              // ce_finalize's block sums [nFin] / the fused finalize's tile sums [nQt]
-    off += (size_t)(pl.nFin > pl.nQt ? pl.nFin : pl.nQt) * sizeof(float);
+    pl.off_blocksum = off;
+    off += (size_t)pl.nFin * sizeof(float);
     off = (off + 255) & ~(size_t)255;
     pl.off_raw = off;                                   // RPO_TARGET_FIRST raw dots [Q, P/Q]
     off += (size_t)P * sizeof(float);
@@ -1425,15 +1299,6 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
     }
     float2* partial = do_stats ? (float2*)(wsb + pl.off_partial) : nullptr;
     bool fused_finalize = false;      // the forward kernel wrote lse and loss itself (single-block skinny launch)
-    FusedFin fin{lse_out, loss_out, nullptr, nullptr, P / Q, -1, 0u};
-    if ((pl.path == PATH_TILE || pl.path == PATH_TILE256) && do_stats && scores_out != nullptr && pl.nQt + 1 <= kFinRangeSlots) {
-        const unsigned long long seq = g_tile_next_launch.fetch_add(1, std::memory_order_relaxed);
-        fin.slot = (int)(seq % (unsigned)kFinRanges) * kFinRangeSlots;
-        fin.epoch = (unsigned)(seq / (unsigned)kFinRanges) + 1u;          // never 0: a zero-initialised word matches no launch
-        fin.tilesum = (float*)(wsb + pl.off_blocksum);
-        fin.tgt = (float*)(wsb + pl.off_raw);            // [P] floats of workspace the in-batch mode does not use otherwise; Q <= P
-        fused_finalize = true;
-    }
     if (pl.path == PATH_TILE) {
         static bool attr_set = false;   // idempotent; a race only repeats the same call
         if (!attr_set) {
@@ -1448,13 +1313,13 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         const dim3 grid((unsigned)(pl.nPt * pl.nQt)), block(kTileThreads);
         if (pl.tp == 128 && pl.tq == 128)
             RPO_LAUNCH((sim_tile_kernel<T, 128, 128, 2>), grid, block, tile_lds_bytes(128, 128, 2), st, (const T*)q, (const T*)p, Q, P,
-                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt, fin);
+                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
         else if (pl.tp == 128)
             RPO_LAUNCH((sim_tile_kernel<T, 128, 64, 3>), grid, block, tile_lds_bytes(128, 64, 3), st, (const T*)q, (const T*)p, Q, P,
-                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt, fin);
+                       d, temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
         else
             RPO_LAUNCH((sim_tile_kernel<T, 64, 64, 8>), grid, block, tile_lds_bytes(64, 64, 8), st, (const T*)q, (const T*)p, Q, P, d,
-                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt, fin);
+                       temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
     } else if (pl.path == PATH_TILE256) {
         if constexpr (sizeof(T) == 2) {
             static bool attr_set256 = false;
@@ -1465,7 +1330,7 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
             }
             RPO_LAUNCH(sim_tile256_kernel, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kBigThreads), kBigLdsBytes, st,
                        (const bf16_t*)q, (const bf16_t*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
-                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0, fin);
+                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0);
         }
     } else if (pl.path == PATH_SKINNY) {
         const int ng = Q <= 16 ? 4 : 1;
