@@ -1305,6 +1305,16 @@ constexpr int kDkdv4Lds = kSlRing * kSlImg;                  // 67584 B
         : "v"(ATD[0]), "v"(ATD[1]), "v"(ATD[2]), "v"(ATD[3]), "v"(ATQ[0]), "v"(ATQ[1]), "v"(ATQ[2]), "v"(ATQ[3]), \
           "v"(PF[3]), "v"(DS[3])                                                                            \
         : "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191")
+#ifdef RPO_D4_EXP_DQ_ATOMICS
+// PRICING EXPERIMENT (round 4, never shipped; tools/exp/build_variant.sh dqatomics -DRPO_D4_EXP_DQ_ATOMICS): what the dQ sum of a
+// one-kernel, five-product backward (cdna_hip_programming.md, Appendix B 'Attention backward': dQ by global_atomic_add_f32 from the
+// 256-key block) would add to THIS kernel before a single extra MFMA: after every slice each wave issues the block's share of
+// the f32 adds -- 8 query rows x 256 contiguous bytes (one dQ row of the head) -- into a [T, nh, 64] float buffer, adding 0.0
+// (dK / dV stay what they are, the parity tests still pass); the LDS-DMA ring's counted waits are widened by the 24 atomics
+// that sit between a stage and its wait.
+__device__ float* g_exp_dq32 = nullptr;
+#endif
+
 // generated by tools/gen/gen_dkdv4_body.py (register map and operand list there); 238 instructions
 #define RPO_D4_SLICE_BODY_LOAD(RA0, RA1, LRD, TP0, TP1, TP2, TP3, SCL, NRA0, NRA1, NLRD)                    \
     asm volatile(                                                                                               \
@@ -2393,16 +2403,6 @@ constexpr int kDkdv4Lds = kSlRing * kSlImg;                  // 67584 B
         : "v"(RA0), "v"(RA1), "v"(LRD), "v"(TP0), "v"(TP1), "v"(TP2), "v"(TP3), "s"(SCL), "v"(NRA0), "v"(NRA1),   \
           "v"(NLRD), "v"(DLANE)                                                                                \
         : "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140", "v141", "v142", "v143", "v144", "v145", "v146", "v147", "v148", "v149", "v150", "v151", "v152", "v153", "v154", "v155", "v156", "v157", "v158", "v159", "v160", "v161", "v162", "v163", "v164", "v165", "v166", "v167", "v168", "v169", "v170", "v171", "v172", "v173", "v174", "v175", "v176", "v177", "v178", "v179", "v180", "v181", "v182", "v183", "v184", "v185", "v186", "v187", "v188", "v189", "v190", "v191", "v192", "v193", "v194", "v195", "v196", "v197", "v198", "v199", "v200", "v201", "v202", "v203", "v204", "v205", "v206", "v207", "v208", "v209", "v210", "v211", "v212", "v213", "v214", "v215", "v216", "v217", "v218", "v219", "v220", "v221", "v222", "v223", "v224", "v225", "v226", "v227", "v228", "v229", "v230", "v231", "v232", "v233", "v234", "v235", "v236", "v237", "v238", "v239", "v240", "v241", "v242", "v243", "v244", "v245", "v246", "v247", "v248", "v249", "v250", "v251", "v252", "v253", "v254", "v255", "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", "vcc", "memory")
-
-#ifdef RPO_D4_EXP_DQ_ATOMICS
-// PRICING EXPERIMENT (round 4, never shipped; tools/exp/build_variant.sh dqatomics -DRPO_D4_EXP_DQ_ATOMICS): what the dQ sum of a
-// one-kernel, five-product backward (cdna_hip_programming.md, Appendix B 'Attention backward': dQ by global_atomic_add_f32 from the
-// 256-key block) would add to THIS kernel before a single extra MFMA: after every slice each wave issues the block's share of
-// the f32 adds -- 8 query rows x 256 contiguous bytes (one dQ row of the head) -- into a [T, nh, 64] float buffer, adding 0.0
-// (dK / dV stay what they are, the parity tests still pass); the LDS-DMA ring's counted waits are widened by the 24 atomics
-// that sit between a stage and its wait.
-__device__ float* g_exp_dq32 = nullptr;
-#endif
 
 template <bool DOWN>
 __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
