@@ -763,6 +763,39 @@ def test_bench_lib_switch_really_switches(tmp_path):
         _lib.LIB_PATH, _lib._lib = in_tree, cached
 
 
+def test_step_flops_count_matches_a_spelled_out_count():
+    """`bench.llama_step_flops` (the numerator of `step_roofline`): against a count written out term by term for a small Llama
+    shape -- GEMMs 2 FLOP per weight and token forward, x 3 with backward; causal attention 4 hd FLOP per (query, key <= query) pair
+    and head forward, x 3.5 with backward; `required` runs the last block's q / o / MLP on the pooled rows only."""
+    import importlib
+    from types import SimpleNamespace
+    B = importlib.import_module("bench")
+    cfg = SimpleNamespace(hidden_size=64, num_attention_heads=4, num_key_value_heads=2, head_dim=16, intermediate_size=96,
+                          num_hidden_layers=3)
+    lens = [[5, 9, 2], [7]]
+    d, nh, nkv, hd, ff, nl = 64, 4, 2, 16, 96, 3
+    qo = 2 * d * nh * hd                      # q_proj + o_proj weights
+    kv = 2 * d * nkv * hd
+    mlp = 3 * d * ff
+    T = sum(map(sum, lens))
+    rows = sum(map(len, lens))
+    pairs = sum(n * (n + 1) // 2 for b in lens for n in b)
+    want_model_gemm = 3 * 2 * T * (qo + kv + mlp) * nl
+    want_req_gemm = 3 * 2 * (T * (qo + kv + mlp) * (nl - 1) + T * kv + rows * (qo + mlp))
+    attn_block = int(3.5 * 4 * hd * nh * sum(n * (n + 1) // 2 for n in lens[0])) + int(3.5 * 4 * hd * nh * sum(n * (n + 1) // 2 for n in lens[1]))
+    got = B.llama_step_flops(cfg, lens)
+    assert got["gemm_model"] == want_model_gemm and got["gemm_required"] == want_req_gemm
+    assert got["attn_model"] == attn_block * nl
+    assert got["attn_required"] == attn_block * (nl - 1) + sum(int(3.5 * 4 * hd * nh * sum(b)) for b in lens)
+    assert pairs > 0 and got["gemm_required"] < got["gemm_model"] and got["attn_required"] < got["attn_model"]
+    # the headline shape: ~948 TFLOP per cfg-2 step (DESIGN.md section 4), from the mean lengths of the synthetic batches
+    from rankpo_amd import encoder as PE
+    c2 = PE.llama_3_2_1b_config()
+    one = [[960] * 8 + [3072] * 48]
+    f = B.llama_step_flops(c2, one)
+    assert 0.8e15 < f["gemm_required"] + f["attn_required"] < 1.1e15
+
+
 def test_generated_dkdv128_bodies_are_in_sync():
     """rankpo_amd/csrc/attention_dkdv128_gen.inc (the hand-placed slice bodies of fa_bwd_dkdv128_kernel and its literal-register
     statements) is generated text: it must be what tools/gen/gen_dkdv128_body.py emits today (edit the generator, not the file)."""
