@@ -303,6 +303,9 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n) s[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+#ifdef RPO_FA_EXP_SETPRIO      // A/B build (round 4: round 3's in-step measurement of this went through a --lib that switched nothing)
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -312,6 +315,9 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                     for (int n = 0; n < 2; ++n) s[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[n][ks], s[m][n], 0, 0, 0);
                 }
             }
+#ifdef RPO_FA_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             RPO_FSTAMP(te);
             RPO_FSTAMP_ADD(3, td, te);
 #if RPO_FA_STAGE_POS == 1
@@ -394,6 +400,9 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                          : "memory");
             const short8_t vt0[4] = {join_tr(x0, x1), join_tr(x2, x3), join_tr(x4, x5), join_tr(x6, x7)};
             const short8_t vt1[4] = {join_tr(y0, y1), join_tr(y2, y3), join_tr(y4, y5), join_tr(y6, y7)};
+#ifdef RPO_FA_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
             for (int c = 0; c < 4; ++c)
 #pragma unroll
@@ -409,6 +418,9 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
                 lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfrag[0][n], lacc[n], 0, 0, 0);
                 lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfrag[1][n], lacc[n], 0, 0, 0);
             }
+#ifdef RPO_FA_EXP_SETPRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
             RPO_FSTAMP(tg);
             RPO_FSTAMP_ADD(5, tf, tg);
 #if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
