@@ -727,7 +727,7 @@ def test_bench_watchdog_names_the_phase_when_a_rank_stalls():
     B = importlib.import_module("bench")
     fired = []
     wd = B.Watchdog(0, scale=1.0, exit_fn=fired.append)
-    wd.phase("quick", 0.2)
+    wd.phase("quick", 5.0)
     wd.phase("slow", 30.0)
     time.sleep(1.2)
     assert not fired
