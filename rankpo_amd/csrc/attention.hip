@@ -80,6 +80,12 @@ constexpr int kKvTile = 2 * kFaBN * 128;                          // 16 KiB
                  : "v"(ADDR)                                                                                         \
                  : "memory")
 
+#define RPO_TR2(OUT0, OUT1, ADDR, OFF0, OFF1)                                                                       \
+    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:" #OFF0 "\n\tds_read_b64_tr_b16 %1, %2 offset:" #OFF1             \
+                 : "=&v"(OUT0), "=&v"(OUT1)                                                                          \
+                 : "v"(ADDR)                                                                                         \
+                 : "memory")
+
 __device__ __forceinline__ short8_t join_tr(const u32x2& lo, const u32x2& hi) {
     typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
     const u32x4 w = {lo[0], lo[1], hi[0], hi[1]};
@@ -958,12 +964,6 @@ constexpr int kFaDkdvThreads = 512;
 // Rows past the end of the sequence are clamped to its last row: their P and dS are masked to exactly 0.
 constexpr int kDmaTile = 2 * kFaBM * 128 + 2 * kFaBM * 4;        // 33792 B
 constexpr int kDmaLds = 3 * kDmaTile;                             // 101376 B (one block per CU)
-
-#define RPO_TR2(OUT0, OUT1, ADDR, OFF0, OFF1)                                                                       \
-    asm volatile("ds_read_b64_tr_b16 %0, %2 offset:" #OFF0 "\n\tds_read_b64_tr_b16 %1, %2 offset:" #OFF1             \
-                 : "=&v"(OUT0), "=&v"(OUT1)                                                                          \
-                 : "v"(ADDR)                                                                                         \
-                 : "memory")
 
 
 __global__ __launch_bounds__(kFaDkdvThreads, 1) void fa_bwd_dkdv_kernel(
