@@ -126,7 +126,7 @@ def _algo(name, a):
     if name == "rpo_swiglu_fwd":
         n = a[3] * a[4]
         return 3 * n * _es(a[7]), 5 * n
-    if name == "rpo_swiglu_bwd":
+    if name in ("rpo_swiglu_bwd", "rpo_swiglu_bwd_t"):
         n = a[6] * a[7]
         return (6 if a[5] is not None else 5) * n * _es(a[12]), 13 * n
     if name == "rpo_rope":
@@ -913,6 +913,10 @@ def main():
     ap.add_argument("--no-fill", action="store_true", help="A/B: no filler sequence rounding the packed token count to 256")
     ap.add_argument("--no-linear-tn", action="store_true", help="A/B: torch's own operand layout for the input-gradient GEMMs")
     ap.add_argument("--no-wgrad-mixed", action="store_true", help="A/B: weight-gradient GEMMs as autograd issues them")
+    ap.add_argument("--no-prod-t", action="store_true",
+                    help="A/B: SwiGLU backward writes the recomputed product row-major (round 2-3) instead of transposed (ops.SWIGLU_PROD_T)")
+    ap.add_argument("--wgrad-split", type=int, default=None,
+                    help="A/B: chunks of the token reduction for the q|k|v and o weight gradients (ops.WGRAD_SPLIT_T; 1 = one GEMM)")
     ap.add_argument("--fold-rope", type=int, default=2, choices=(0, 1, 2),
                     help="A/B: 2 = rotary folded into the attention forward (q) and backward epilogues, 1 = backward only, 0 = separate passes")
     ap.add_argument("--lib", default=None,
@@ -1018,6 +1022,10 @@ def main():
         rankpo_amd.ops.LINEAR_TN = False
     if args.no_wgrad_mixed:
         rankpo_amd.ops.WGRAD_MIXED = False
+    if args.no_prod_t:
+        rankpo_amd.ops.SWIGLU_PROD_T = False
+    if args.wgrad_split is not None:
+        rankpo_amd.ops.WGRAD_SPLIT_T = args.wgrad_split
     rankpo_amd.encoder.FOLD_ROPE = args.fold_rope
     if args.dkdv_heaviest_first:
         rankpo_amd.ops.ATTN_SWEEP_DOWN = rankpo_amd.ops.ATTN_SWEEP_DOWN_HD128 = False

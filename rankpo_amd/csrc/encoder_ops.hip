@@ -102,6 +102,71 @@ __global__ __launch_bounds__(kEwThreads) void rope_kernel(const T* xin, T* x, in
     }
 }
 
+// The same backward pass with the recomputed product written TRANSPOSED, prod_t [cols, rows] (round 4).  Why: the weight gradient of
+// the down projection, dW [d, ff] = dY[T, d]^T prod[T, ff], runs at 1.37 PFLOP/s in the layout round 2 gave it (dY^T contiguous
+// along the tokens, prod strided) and at 1.57 with BOTH operands contiguous along the token reduction (tools/probe_wgrad.py: 3.70 ->
+// 3.23 ms per block at T = 151 552) -- which needs prod^T, and this kernel is the one that writes the product anyway: the same
+// bytes, stored through an LDS tile as whole 128-byte lines of the transposed matrix (the 64 x 64 tile of transpose_kernel,
+// measured the faster one there).  dg / du stay row-major (the input-gradient GEMM reads them that way).
+template <typename T>
+__global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const T* __restrict__ g, const T* __restrict__ u, const T* __restrict__ dout,
+                                                           T* __restrict__ dg, T* __restrict__ du, T* __restrict__ prod_t, int64_t rows,
+                                                           int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu,
+                                                           int64_t ld_pt) {
+    constexpr int V = Elem<T>::kVec;
+    constexpr int TS = 64;
+    constexpr int LDT = TS + 8 / (int)sizeof(T);
+    constexpr int VPR = TS / V;
+    __shared__ __attribute__((aligned(16))) T tile[TS][LDT];
+    const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < TS * VPR / 256; ++i) {
+        const int idx = t + 256 * i;
+        const int row = idx / VPR, cv = (idx % VPR) * V;
+        const int64_t r = r0 + row, c = c0 + cv;
+        __attribute__((aligned(16))) T pv[V];
+        if (r < rows && c < cols) {                      // cols is a multiple of V: a vector is inside or outside as a whole
+            Vec16<T> a, b, d, og, ou;
+            a.load_nt(g + r * ld_gu + c);
+            b.load_nt(u + r * ld_gu + c);
+            d.load_nt(dout + r * ld_dout + c);
+#pragma unroll
+            for (int k = 0; k < V; ++k) {
+                const float sg = sigmoid_f(a.v[k]);
+                const float silu = a.v[k] * sg;
+                og.v[k] = d.v[k] * b.v[k] * (sg + silu * (1.0f - sg));
+                ou.v[k] = d.v[k] * silu;
+                Elem<T>::st(&pv[k], silu * b.v[k]);            // the forward product, same arithmetic and rounding as swiglu_fwd_kernel
+            }
+            og.store_nt(dg + r * ld_dgu + c);
+            ou.store_nt(du + r * ld_dgu + c);
+        } else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) pv[k] = T(0);
+        }
+        *reinterpret_cast<uint4_t*>(&tile[row][cv]) = *reinterpret_cast<const uint4_t*>(pv);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TS * VPR / 256; ++i) {
+        const int idx = t + 256 * i;
+        const int oc = idx / VPR, rv = (idx % VPR) * V;          // output row = column c0 + oc; tokens r0 + rv .. + V - 1
+        const int64_t c = c0 + oc, r = r0 + rv;
+        if (c >= cols || r >= rows) continue;
+        __attribute__((aligned(16))) T v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = tile[rv + e][oc];
+        if (r + V <= rows) {
+            __builtin_nontemporal_store(*reinterpret_cast<const uint4_t*>(v), reinterpret_cast<uint4_t*>(prod_t + c * ld_pt + r));
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e)
+                if (r + e < rows) prod_t[c * ld_pt + r + e] = v[e];
+        }
+    }
+}
+
 inline unsigned ew_grid(int64_t nvec) { return (unsigned)rpo_cdiv(nvec, kEwThreads); }
 
 }  // namespace
@@ -221,6 +286,31 @@ extern "C" int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, vo
         RPO_LAUNCH(swiglu_bwd_kernel<float>, dim3(ew_grid(nvec)), dim3(kEwThreads), 0, st, (const float*)g,
                    (const float*)u, (const float*)dout, (float*)dg, (float*)du, (float*)prod_out, rows, (int)(cols / V), ld_gu,
                    ld_dout, ld_dgu, ld_prod);
+    else
+        return RPO_ERR_INVALID_ARG;
+    return rpo_launch_status();
+}
+
+extern "C" int rpo_swiglu_bwd_t(const void* g, const void* u, const void* dout, void* dg, void* du, void* prod_t_out,
+                                int64_t rows, int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int64_t ld_prod_t,
+                                int dtype, rpo_stream_t stream) {
+    if (!g || !u || !dout || !dg || !du || !prod_t_out || rows <= 0 || cols <= 0) return RPO_ERR_INVALID_ARG;
+    const int V = dtype == RPO_DT_BF16 ? 8 : 4;
+    if (cols % V != 0 || ld_gu % V != 0 || ld_dout % V != 0 || ld_dgu % V != 0 || ld_prod_t % V != 0 || ld_prod_t < rows ||
+        !rpo_aligned16(g) || !rpo_aligned16(u) || !rpo_aligned16(dout) || !rpo_aligned16(dg) || !rpo_aligned16(du) ||
+        !rpo_aligned16(prod_t_out))
+        return RPO_ERR_UNSUPPORTED;
+    // the transposed product may not overlay its inputs (a tile's product is written after OTHER tiles may still read dout)
+    const int64_t gx = rpo_cdiv(cols, 64), gy = rpo_cdiv(rows, 64);
+    if (gy > 65535 || gx > INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)gx, (unsigned)gy);
+    if (dtype == RPO_DT_BF16)
+        RPO_LAUNCH(swiglu_bwd_t_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)u, (const bf16_t*)dout,
+                   (bf16_t*)dg, (bf16_t*)du, (bf16_t*)prod_t_out, rows, cols, ld_gu, ld_dout, ld_dgu, ld_prod_t);
+    else if (dtype == RPO_DT_F32)
+        RPO_LAUNCH(swiglu_bwd_t_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (const float*)u, (const float*)dout,
+                   (float*)dg, (float*)du, (float*)prod_t_out, rows, cols, ld_gu, ld_dout, ld_dgu, ld_prod_t);
     else
         return RPO_ERR_INVALID_ARG;
     return rpo_launch_status();

@@ -274,6 +274,8 @@ def _swiglu_fwd(lib, gu, prod, rows, ff):
 
 LINEAR_TN = True      # input-gradient GEMMs against a transposed copy of the weight (`_LinearTN`); bench.py --no-linear-tn
 WGRAD_MIXED = True    # weight-gradient GEMMs with the smaller operand transposed first (`wgrad`); bench.py --no-wgrad-mixed
+SWIGLU_PROD_T = True  # SwiGLU backward writes the recomputed product transposed for the down projection's weight gradient; bench.py --no-prod-t
+WGRAD_SPLIT_T = 4     # chunks of the token reduction for the small-output weight gradients (0 / 1: one GEMM); bench.py --wgrad-split
 
 
 def transpose2d(x):
@@ -302,6 +304,15 @@ def wgrad(dy2, x2):
             return dy2.t() @ transpose2d(x2).t()          # x is the smaller operand
         if k >= 2 * n:
             return transpose2d(dy2) @ x2                   # dy is the smaller operand
+        # Round 4: q|k|v [3072, 2048] and o [2048, 2048] are 96 / 64 output tiles of 256 x 256 on 256 CUs, and hipBLASLt runs
+        # them at 0.78-1.16 PFLOP/s in EVERY operand layout (tools/probe_wgrad.py).  The token reduction cut into S chunks as
+        # ONE batched GEMM with float32 partial products, summed afterwards, fills the chip: 1.88 -> 1.71 ms and 1.29 -> 1.12 ms
+        # at T = 151 552 (tools/probe_wgrad_splitk.py); the float32 partials are rounded to bf16 once, as the single GEMM's
+        # accumulator is (relative difference to it 8e-5: summation order).
+        T, S = dy2.shape[0], WGRAD_SPLIT_T
+        if S > 1 and T >= 32768 and T % S == 0 and n * k <= 8 * 1024 * 1024 and dy2.is_contiguous() and x2.is_contiguous():
+            part = torch.bmm(dy2.view(S, T // S, n).transpose(1, 2), x2.view(S, T // S, k), out_dtype=torch.float32)
+            return part.sum(0).to(dy2.dtype)
     return dy2.t() @ x2
 
 
@@ -370,6 +381,20 @@ class _SwiGLUDown(torch.autograd.Function):
             dprod = dy @ weight
         dgu = torch.empty_like(gu)                            # [dg | du]: the gradient of the fused projection output
         want_dw = ctx.needs_input_grad[1]
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        n = dy2.shape[1]
+        # Round 4: the recomputed product written TRANSPOSED [ff, T], so that the weight gradient dW [n, ff] = dY^T prod has BOTH
+        # operands contiguous along the token reduction (hipBLASLt: 1.57 instead of 1.37 PFLOP/s on the down projection's shape,
+        # tools/probe_wgrad.py) -- the same bytes stored, through an LDS tile (csrc/encoder_ops.hip, swiglu_bwd_t_kernel)
+        if (want_dw and SWIGLU_PROD_T and WGRAD_MIXED and gu.dtype == torch.bfloat16 and ff >= 2 * n and rows >= 4096
+                and rows % 8 == 0):
+            prod_t = torch.empty((ff, rows), dtype=gu.dtype, device=gu.device)
+            with torch.cuda.device(gu.device):
+                check(lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),
+                                           dgu.data_ptr() + ff * es, prod_t.data_ptr(), rows, ff, 2 * ff, ff, 2 * ff, rows,
+                                           _dt(gu), _stream(gu)), "rpo_swiglu_bwd_t")
+            del dprod
+            return dgu, torch.nn.functional.linear(transpose2d(dy2), prod_t)      # [n, T] x [ff, T]^T -> [n, ff]
         with torch.cuda.device(gu.device):
             check(lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),
                                      dgu.data_ptr() + ff * es, dprod.data_ptr() if want_dw else None, rows, ff, 2 * ff,
@@ -377,7 +402,7 @@ class _SwiGLUDown(torch.autograd.Function):
         dW = None
         if want_dw:
             prod = dprod                                      # overwritten in place by the kernel
-            dW = wgrad(dy.reshape(-1, dy.shape[-1]), prod.reshape(-1, ff))
+            dW = wgrad(dy2, prod.reshape(-1, ff))
         return dgu, dW
 
 

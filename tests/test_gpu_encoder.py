@@ -46,6 +46,51 @@ def test_swiglu_down_matches_torch(dtype):
     assert torch.equal(gu3.grad, gu.grad)
 
 
+@pytest.mark.parametrize("T,ff,d", [(4096, 1024, 256), (4104, 520, 128), (8192, 8192, 2048)])
+def test_swiglu_down_transposed_product_path(T, ff, d):
+    """Round 4: on large token counts the SwiGLU backward writes the recomputed product TRANSPOSED [ff, T] and the down
+    projection's weight gradient runs with both operands contiguous along the tokens (ops.SWIGLU_PROD_T; reference: the plain
+    autograd of HF LlamaMLP's `down_proj(act_fn(gate_proj(x)) * up_proj(x))`).  The transposed product must be bit-for-bit the
+    transpose of the row-major one (same arithmetic, same rounding), dg / du bit-identical, the weight gradient equal to the
+    row-major path's to the GEMM's summation order; ragged edges: T and ff that are no multiples of the 64 x 64 tile."""
+    from rankpo_amd import ops, _lib
+    from rankpo_amd.ops import _dt, _stream
+    torch.manual_seed(3)
+    dtype = torch.bfloat16
+    gu = torch.randn(T, 2 * ff, device=DEV).to(dtype)
+    dprod = torch.randn(T, ff, device=DEV).to(dtype)
+    lib = _lib.load()
+    es = 2
+    dgu_a, dgu_b = torch.empty_like(gu), torch.empty_like(gu)
+    prod = dprod.clone()
+    assert lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * es, prod.data_ptr(), dgu_a.data_ptr(), dgu_a.data_ptr() + ff * es,
+                              prod.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, ff, _dt(gu), _stream(gu)) == 0
+    prod_t = torch.full((ff, T), float("nan"), dtype=dtype, device=DEV)
+    assert lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu_b.data_ptr(), dgu_b.data_ptr() + ff * es,
+                                prod_t.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, T, _dt(gu), _stream(gu)) == 0
+    assert torch.equal(dgu_a, dgu_b)
+    assert torch.equal(prod_t, prod.t())
+    # through the autograd op: both paths, same inputs
+    W = (torch.randn(d, ff, device=DEV) * 0.05).to(dtype)
+    gy = torch.randn(T, d, device=DEV).to(dtype)
+    res = {}
+    for flag in (True, False):
+        ops.SWIGLU_PROD_T = flag
+        try:
+            g1 = gu.clone().requires_grad_(True)
+            W1 = W.clone().requires_grad_(True)
+            ops.swiglu_down(g1, W1).backward(gy)
+            res[flag] = (g1.grad, W1.grad)
+        finally:
+            ops.SWIGLU_PROD_T = True
+    assert torch.equal(res[True][0], res[False][0])
+    ref = res[False][1].float()
+    assert float((res[True][1].float() - ref).norm() / ref.norm()) < 4e-3            # two bf16 roundings of differently ordered f32 sums
+    g2, W2 = gu.double().requires_grad_(True), W.double().requires_grad_(True)
+    ((F.silu(g2[:, :ff]) * g2[:, ff:]) @ W2.T).backward(gy.double())
+    assert float((res[True][1].double() - W2.grad).norm() / W2.grad.norm()) < 6e-3     # vs float64 autograd: one bf16 rounding of the result
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("H", [5, 40])      # 5 heads: several rows share a block (the K-heads-only call of the rotary fold); 40: one row per block
