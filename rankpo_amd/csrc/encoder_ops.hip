@@ -108,20 +108,24 @@ __global__ __launch_bounds__(kEwThreads) void rope_kernel(const T* xin, T* x, in
 // 3.23 ms per block at T = 151 552) -- which needs prod^T, and this kernel is the one that writes the product anyway: the same
 // bytes, stored through an LDS tile as whole 128-byte lines of the transposed matrix (the 64 x 64 tile of transpose_kernel,
 // measured the faster one there).  dg / du stay row-major (the input-gradient GEMM reads them that way).
-template <typename T>
+template <typename T, int TC>
 __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const T* __restrict__ g, const T* __restrict__ u, const T* __restrict__ dout,
                                                            T* __restrict__ dg, T* __restrict__ du, T* __restrict__ prod_t, int64_t rows,
                                                            int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu,
                                                            int64_t ld_pt) {
+    // tile = TR tokens x TC columns: the five row-major streams (g, u, dout in; dg, du out) move TC * sizeof(T) contiguous bytes
+    // per token row (512 B at TC = 256: a 64 x 64 tile's 128-byte pieces on ALL six streams measured 5.0 TB/s, 2.95 ms against
+    // the streaming kernel's 2.27 -- more than the GEMM wins back); only the transposed product is written in TR-token pieces
     constexpr int V = Elem<T>::kVec;
-    constexpr int TS = 64;
-    constexpr int LDT = TS + 8 / (int)sizeof(T);
-    constexpr int VPR = TS / V;
-    __shared__ __attribute__((aligned(16))) T tile[TS][LDT];
-    const int64_t r0 = (int64_t)blockIdx.y * TS, c0 = (int64_t)blockIdx.x * TS;
+    constexpr int TR = 64;
+    constexpr int LDT = TC + 8 / (int)sizeof(T);
+    constexpr int VPR = TC / V;                       // vectors per tile row
+    constexpr int VPC = TR / V;                       // vectors per output row (one column of the tile)
+    __shared__ __attribute__((aligned(16))) T tile[TR][LDT];
+    const int64_t r0 = (int64_t)blockIdx.y * TR, c0 = (int64_t)blockIdx.x * TC;
     const int t = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < TS * VPR / 256; ++i) {
+    for (int i = 0; i < TR * VPR / 256; ++i) {
         const int idx = t + 256 * i;
         const int row = idx / VPR, cv = (idx % VPR) * V;
         const int64_t r = r0 + row, c = c0 + cv;
@@ -149,9 +153,9 @@ __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const T* __restrict__
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < TS * VPR / 256; ++i) {
+    for (int i = 0; i < TC * VPC / 256; ++i) {
         const int idx = t + 256 * i;
-        const int oc = idx / VPR, rv = (idx % VPR) * V;          // output row = column c0 + oc; tokens r0 + rv .. + V - 1
+        const int oc = idx / VPC, rv = (idx % VPC) * V;          // output row = column c0 + oc; tokens r0 + rv .. + V - 1
         const int64_t c = c0 + oc, r = r0 + rv;
         if (c >= cols || r >= rows) continue;
         __attribute__((aligned(16))) T v[V];
@@ -301,15 +305,16 @@ extern "C" int rpo_swiglu_bwd_t(const void* g, const void* u, const void* dout, 
         !rpo_aligned16(prod_t_out))
         return RPO_ERR_UNSUPPORTED;
     // the transposed product may not overlay its inputs (a tile's product is written after OTHER tiles may still read dout)
-    const int64_t gx = rpo_cdiv(cols, 64), gy = rpo_cdiv(rows, 64);
+    constexpr int kTC = 256;
+    const int64_t gx = rpo_cdiv(cols, kTC), gy = rpo_cdiv(rows, 64);
     if (gy > 65535 || gx > INT32_MAX) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)gx, (unsigned)gy);
     if (dtype == RPO_DT_BF16)
-        RPO_LAUNCH(swiglu_bwd_t_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)u, (const bf16_t*)dout,
+        RPO_LAUNCH((swiglu_bwd_t_kernel<bf16_t, kTC>), grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)u, (const bf16_t*)dout,
                    (bf16_t*)dg, (bf16_t*)du, (bf16_t*)prod_t_out, rows, cols, ld_gu, ld_dout, ld_dgu, ld_prod_t);
     else if (dtype == RPO_DT_F32)
-        RPO_LAUNCH(swiglu_bwd_t_kernel<float>, grid, dim3(256), 0, st, (const float*)g, (const float*)u, (const float*)dout,
+        RPO_LAUNCH((swiglu_bwd_t_kernel<float, kTC / 2>), dim3((unsigned)rpo_cdiv(cols, kTC / 2), (unsigned)gy), dim3(256), 0, st, (const float*)g, (const float*)u, (const float*)dout,
                    (float*)dg, (float*)du, (float*)prod_t_out, rows, cols, ld_gu, ld_dout, ld_dgu, ld_prod_t);
     else
         return RPO_ERR_INVALID_ARG;
