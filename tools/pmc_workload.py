@@ -57,7 +57,11 @@ dgu = torch.empty_like(gu)
 run("rpo_swiglu_bwd", ["swiglu_bwd_kernel"], f"{T} x {ff} bf16, product rewritten over dprod", 6 * T * ff * 2,
     lambda: lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * 2, prod.data_ptr(), dgu.data_ptr(), dgu.data_ptr() + ff * 2,
                                prod.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, ff, 1, st()))
-del gu, dgu, prod
+prod_t = torch.empty(ff, T, device=DEV, dtype=bf)
+run("rpo_swiglu_bwd_t", ["swiglu_bwd_t_kernel"], f"{T} x {ff} bf16, product written transposed [{ff}, {T}]", 6 * T * ff * 2,
+    lambda: lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * 2, prod.data_ptr(), dgu.data_ptr(), dgu.data_ptr() + ff * 2,
+                                 prod_t.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, T, 1, st()))
+del gu, dgu, prod, prod_t
 nh, nkv, hd = 32, 8, 64
 W = (nh + 2 * nkv) * hd
 qkv = torch.randn(T, W, device=DEV, dtype=bf)
