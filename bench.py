@@ -126,9 +126,12 @@ def _algo(name, a):
     if name == "rpo_swiglu_fwd":
         n = a[3] * a[4]
         return 3 * n * _es(a[7]), 5 * n
-    if name in ("rpo_swiglu_bwd", "rpo_swiglu_bwd_t"):
+    if name == "rpo_swiglu_bwd":
         n = a[6] * a[7]
         return (6 if a[5] is not None else 5) * n * _es(a[12]), 13 * n
+    if name == "rpo_swiglu_bwd_t":
+        n = a[7] * a[8]
+        return (8 if a[6] is not None else 6) * n * _es(a[13]), 13 * n
     if name == "rpo_rope":
         rows, H, hd, dt = a[5], a[6], a[7], a[9]
         return 2 * rows * H * hd * _es(dt) + rows * hd * 4, 3 * rows * H * hd
@@ -915,6 +918,8 @@ def main():
     ap.add_argument("--no-wgrad-mixed", action="store_true", help="A/B: weight-gradient GEMMs as autograd issues them")
     ap.add_argument("--no-prod-t", action="store_true",
                     help="A/B: SwiGLU backward writes the recomputed product row-major (round 2-3) instead of transposed (ops.SWIGLU_PROD_T)")
+    ap.add_argument("--no-dgu-t", action="store_true",
+                    help="A/B: no transposed copy of d(gate|up) from the SwiGLU backward (ops.SWIGLU_DGU_T)")
     ap.add_argument("--wgrad-split", type=int, default=None,
                     help="A/B: chunks of the token reduction for the q|k|v and o weight gradients (ops.WGRAD_SPLIT_T; 1 = one GEMM)")
     ap.add_argument("--fold-rope", type=int, default=2, choices=(0, 1, 2),
@@ -1024,6 +1029,8 @@ def main():
         rankpo_amd.ops.WGRAD_MIXED = False
     if args.no_prod_t:
         rankpo_amd.ops.SWIGLU_PROD_T = False
+    if args.no_dgu_t:
+        rankpo_amd.ops.SWIGLU_DGU_T = False
     if args.wgrad_split is not None:
         rankpo_amd.ops.WGRAD_SPLIT_T = args.wgrad_split
     rankpo_amd.encoder.FOLD_ROPE = args.fold_rope

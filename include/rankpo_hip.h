@@ -195,11 +195,13 @@ int rpo_swiglu_fwd(const void* g, const void* u, void* out, int64_t rows, int64_
 int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, void* dg, void* du, void* prod_out, int64_t rows,
                    int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int64_t ld_prod, int dtype,
                    rpo_stream_t stream);
-/* rpo_swiglu_bwd with the recomputed product written TRANSPOSED: prod_t_out [cols, rows] (row stride ld_prod_t >= rows), the
+/* rpo_swiglu_bwd with the recomputed product written TRANSPOSED: prod_t_out [cols, rows] (row stride ld_t >= rows), the
  * operand layout in which the weight gradient of the following (down) projection, dW = dY^T prod, has BOTH operands contiguous
- * along the token reduction.  prod_t_out may not overlay the inputs. */
-int rpo_swiglu_bwd_t(const void* g, const void* u, const void* dout, void* dg, void* du, void* prod_t_out, int64_t rows,
-                     int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int64_t ld_prod_t, int dtype,
+ * along the token reduction.  dgu_t_out (may be NULL): dg and du ALSO written transposed, [2 cols, rows] with the same row stride
+ * (dg^T in rows 0 .. cols - 1, du^T behind it), the same for the weight gradient of the fused gate|up projection; dg / du are
+ * written row-major in any case (the input-gradient GEMM reads them).  The transposed outputs may not overlay the inputs. */
+int rpo_swiglu_bwd_t(const void* g, const void* u, const void* dout, void* dg, void* du, void* prod_t_out, void* dgu_t_out,
+                     int64_t rows, int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int64_t ld_t, int dtype,
                      rpo_stream_t stream);
 int rpo_rope(const void* x_in, void* x_out, int64_t row_stride, const float* cos_tab, const float* sin_tab,
              int64_t rows, int64_t heads, int64_t head_dim, int64_t period, int dtype, int backward,

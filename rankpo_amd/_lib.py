@@ -57,7 +57,7 @@ SIGNATURES = {
     "rpo_swiglu_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "rpo_topk_merge": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "rpo_swiglu_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
-    "rpo_swiglu_bwd_t": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
+    "rpo_swiglu_bwd_t": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "rpo_transpose": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "rpo_add_rmsnorm_waves": (C.c_int, [_i64]),
     "rpo_add_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),

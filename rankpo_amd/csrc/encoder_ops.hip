@@ -108,28 +108,35 @@ __global__ __launch_bounds__(kEwThreads) void rope_kernel(const T* xin, T* x, in
 // 3.23 ms per block at T = 151 552) -- which needs prod^T, and this kernel is the one that writes the product anyway: the same
 // bytes, stored through an LDS tile as whole 128-byte lines of the transposed matrix (the 64 x 64 tile of transpose_kernel,
 // measured the faster one there).  dg / du stay row-major (the input-gradient GEMM reads them that way).
-template <typename T, int TC>
+template <typename T, int TC, bool DGU_T>
 __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const T* __restrict__ g, const T* __restrict__ u, const T* __restrict__ dout,
-                                                           T* __restrict__ dg, T* __restrict__ du, T* __restrict__ prod_t, int64_t rows,
-                                                           int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu,
-                                                           int64_t ld_pt) {
+                                                           T* __restrict__ dg, T* __restrict__ du, T* __restrict__ prod_t,
+                                                           T* __restrict__ dgu_t, int64_t rows, int64_t cols, int64_t ld_gu,
+                                                           int64_t ld_dout, int64_t ld_dgu, int64_t ld_pt) {
     // tile = TR tokens x TC columns: the five row-major streams (g, u, dout in; dg, du out) move TC * sizeof(T) contiguous bytes
     // per token row (512 B at TC = 256: a 64 x 64 tile's 128-byte pieces on ALL six streams measured 5.0 TB/s, 2.95 ms against
-    // the streaming kernel's 2.27 -- more than the GEMM wins back); only the transposed product is written in TR-token pieces
+    // the streaming kernel's 2.27 -- more than the GEMM wins back); only the transposed outputs are written in TR-token pieces.
+    // DGU_T: dg and du are ALSO written transposed, dgu_t [2 cols, rows] (dg^T in rows 0 .. cols - 1, du^T behind it), for the
+    // weight gradient of the fused gate|up projection; the three transposed tiles go through the ONE LDS tile one after the
+    // other, the packed results waiting in registers.
     constexpr int V = Elem<T>::kVec;
     constexpr int TR = 64;
     constexpr int LDT = TC + 8 / (int)sizeof(T);
     constexpr int VPR = TC / V;                       // vectors per tile row
     constexpr int VPC = TR / V;                       // vectors per output row (one column of the tile)
+    constexpr int NI = TR * VPR / 256;                // vectors per thread
     __shared__ __attribute__((aligned(16))) T tile[TR][LDT];
     const int64_t r0 = (int64_t)blockIdx.y * TR, c0 = (int64_t)blockIdx.x * TC;
     const int t = threadIdx.x;
+    uint4_t pk_g[DGU_T ? NI : 1], pk_u[DGU_T ? NI : 1];
 #pragma unroll
-    for (int i = 0; i < TR * VPR / 256; ++i) {
+    for (int i = 0; i < NI; ++i) {
         const int idx = t + 256 * i;
         const int row = idx / VPR, cv = (idx % VPR) * V;
         const int64_t r = r0 + row, c = c0 + cv;
         __attribute__((aligned(16))) T pv[V];
+        __attribute__((aligned(16))) T gv[V];
+        __attribute__((aligned(16))) T uv[V];
         if (r < rows && c < cols) {                      // cols is a multiple of V: a vector is inside or outside as a whole
             Vec16<T> a, b, d, og, ou;
             a.load_nt(g + r * ld_gu + c);
@@ -142,32 +149,57 @@ __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const T* __restrict__
                 og.v[k] = d.v[k] * b.v[k] * (sg + silu * (1.0f - sg));
                 ou.v[k] = d.v[k] * silu;
                 Elem<T>::st(&pv[k], silu * b.v[k]);            // the forward product, same arithmetic and rounding as swiglu_fwd_kernel
+                if constexpr (DGU_T) {
+                    Elem<T>::st(&gv[k], og.v[k]);
+                    Elem<T>::st(&uv[k], ou.v[k]);
+                }
             }
             og.store_nt(dg + r * ld_dgu + c);
             ou.store_nt(du + r * ld_dgu + c);
         } else {
 #pragma unroll
-            for (int k = 0; k < V; ++k) pv[k] = T(0);
+            for (int k = 0; k < V; ++k) pv[k] = gv[k] = uv[k] = T(0);
         }
         *reinterpret_cast<uint4_t*>(&tile[row][cv]) = *reinterpret_cast<const uint4_t*>(pv);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < TC * VPC / 256; ++i) {
-        const int idx = t + 256 * i;
-        const int oc = idx / VPC, rv = (idx % VPC) * V;          // output row = column c0 + oc; tokens r0 + rv .. + V - 1
-        const int64_t c = c0 + oc, r = r0 + rv;
-        if (c >= cols || r >= rows) continue;
-        __attribute__((aligned(16))) T v[V];
-#pragma unroll
-        for (int e = 0; e < V; ++e) v[e] = tile[rv + e][oc];
-        if (r + V <= rows) {
-            __builtin_nontemporal_store(*reinterpret_cast<const uint4_t*>(v), reinterpret_cast<uint4_t*>(prod_t + c * ld_pt + r));
-        } else {
-#pragma unroll
-            for (int e = 0; e < V; ++e)
-                if (r + e < rows) prod_t[c * ld_pt + r + e] = v[e];
+        if constexpr (DGU_T) {
+            pk_g[i] = *reinterpret_cast<const uint4_t*>(gv);
+            pk_u[i] = *reinterpret_cast<const uint4_t*>(uv);
         }
+    }
+    auto flush = [&](T* __restrict__ out) {                 // the LDS tile, transposed, to out[c0 + oc][r0 ..]
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TC * VPC / 256; ++i) {
+            const int idx = t + 256 * i;
+            const int oc = idx / VPC, rv = (idx % VPC) * V;      // output row = column c0 + oc; tokens r0 + rv .. + V - 1
+            const int64_t c = c0 + oc, r = r0 + rv;
+            if (c >= cols || r >= rows) continue;
+            __attribute__((aligned(16))) T v[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) v[e] = tile[rv + e][oc];
+            if (r + V <= rows) {
+                __builtin_nontemporal_store(*reinterpret_cast<const uint4_t*>(v), reinterpret_cast<uint4_t*>(out + c * ld_pt + r));
+            } else {
+#pragma unroll
+                for (int e = 0; e < V; ++e)
+                    if (r + e < rows) out[c * ld_pt + r + e] = v[e];
+            }
+        }
+    };
+    flush(prod_t);
+    if constexpr (DGU_T) {
+        auto refill = [&](const uint4_t* pk) {
+            __syncthreads();                                 // everybody has read the previous tile
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int idx = t + 256 * i;
+                *reinterpret_cast<uint4_t*>(&tile[idx / VPR][(idx % VPR) * V]) = pk[i];
+            }
+        };
+        refill(pk_g);
+        flush(dgu_t);
+        refill(pk_u);
+        flush(dgu_t + cols * ld_pt);
     }
 }
 
@@ -296,28 +328,33 @@ extern "C" int rpo_swiglu_bwd(const void* g, const void* u, const void* dout, vo
 }
 
 extern "C" int rpo_swiglu_bwd_t(const void* g, const void* u, const void* dout, void* dg, void* du, void* prod_t_out,
-                                int64_t rows, int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu, int64_t ld_prod_t,
-                                int dtype, rpo_stream_t stream) {
+                                void* dgu_t_out, int64_t rows, int64_t cols, int64_t ld_gu, int64_t ld_dout, int64_t ld_dgu,
+                                int64_t ld_t, int dtype, rpo_stream_t stream) {
     if (!g || !u || !dout || !dg || !du || !prod_t_out || rows <= 0 || cols <= 0) return RPO_ERR_INVALID_ARG;
     const int V = dtype == RPO_DT_BF16 ? 8 : 4;
-    if (cols % V != 0 || ld_gu % V != 0 || ld_dout % V != 0 || ld_dgu % V != 0 || ld_prod_t % V != 0 || ld_prod_t < rows ||
+    if (cols % V != 0 || ld_gu % V != 0 || ld_dout % V != 0 || ld_dgu % V != 0 || ld_t % V != 0 || ld_t < rows ||
         !rpo_aligned16(g) || !rpo_aligned16(u) || !rpo_aligned16(dout) || !rpo_aligned16(dg) || !rpo_aligned16(du) ||
-        !rpo_aligned16(prod_t_out))
+        !rpo_aligned16(prod_t_out) || (dgu_t_out && !rpo_aligned16(dgu_t_out)))
         return RPO_ERR_UNSUPPORTED;
-    // the transposed product may not overlay its inputs (a tile's product is written after OTHER tiles may still read dout)
+    // the transposed outputs may not overlay the inputs (a tile's product is written after OTHER tiles may still read dout)
     constexpr int kTC = 256;
-    const int64_t gx = rpo_cdiv(cols, kTC), gy = rpo_cdiv(rows, 64);
-    if (gy > 65535 || gx > INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    const int64_t gy = rpo_cdiv(rows, 64);
+    if (gy > 65535) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const dim3 grid((unsigned)gx, (unsigned)gy);
-    if (dtype == RPO_DT_BF16)
-        RPO_LAUNCH((swiglu_bwd_t_kernel<bf16_t, kTC>), grid, dim3(256), 0, st, (const bf16_t*)g, (const bf16_t*)u, (const bf16_t*)dout,
-                   (bf16_t*)dg, (bf16_t*)du, (bf16_t*)prod_t_out, rows, cols, ld_gu, ld_dout, ld_dgu, ld_prod_t);
-    else if (dtype == RPO_DT_F32)
-        RPO_LAUNCH((swiglu_bwd_t_kernel<float, kTC / 2>), dim3((unsigned)rpo_cdiv(cols, kTC / 2), (unsigned)gy), dim3(256), 0, st, (const float*)g, (const float*)u, (const float*)dout,
-                   (float*)dg, (float*)du, (float*)prod_t_out, rows, cols, ld_gu, ld_dout, ld_dgu, ld_prod_t);
-    else
+#define RPO_SWT(T, TCV, FLAG)                                                                                               \
+    RPO_LAUNCH((swiglu_bwd_t_kernel<T, TCV, FLAG>), dim3((unsigned)rpo_cdiv(cols, TCV), (unsigned)gy), dim3(256), 0, st,    \
+               (const T*)g, (const T*)u, (const T*)dout, (T*)dg, (T*)du, (T*)prod_t_out, (T*)dgu_t_out, rows, cols, ld_gu,   \
+               ld_dout, ld_dgu, ld_t)
+    if (dtype == RPO_DT_BF16) {
+        if (dgu_t_out) RPO_SWT(bf16_t, kTC, true);
+        else RPO_SWT(bf16_t, kTC, false);
+    } else if (dtype == RPO_DT_F32) {
+        if (dgu_t_out) RPO_SWT(float, kTC / 2, true);
+        else RPO_SWT(float, kTC / 2, false);
+    } else {
         return RPO_ERR_INVALID_ARG;
+    }
+#undef RPO_SWT
     return rpo_launch_status();
 }
 

@@ -274,6 +274,8 @@ def _swiglu_fwd(lib, gu, prod, rows, ff):
 
 LINEAR_TN = True      # input-gradient GEMMs against a transposed copy of the weight (`_LinearTN`); bench.py --no-linear-tn
 WGRAD_MIXED = True    # weight-gradient GEMMs with the smaller operand transposed first (`wgrad`); bench.py --no-wgrad-mixed
+SWIGLU_DGU_T = True   # ... and d(gate|up) transposed as well, for the gate|up weight gradient; bench.py --no-dgu-t
+SWIGLU_DGU_T_MAX_BYTES = 6 * 2 ** 30
 SWIGLU_PROD_T = True  # SwiGLU backward writes the recomputed product transposed for the down projection's weight gradient; bench.py --no-prod-t
 WGRAD_SPLIT_T = 4     # chunks of the token reduction for the small-output weight gradients (0 / 1: one GEMM); bench.py --wgrad-split
 
@@ -292,6 +294,9 @@ def transpose2d(x):
     return out
 
 
+_DY_T = {}            # (data_ptr, numel) of a gradient tensor -> its transposed copy, left by the kernel that produced it (one entry)
+
+
 def wgrad(dy2, x2):
     """dW [n, k] = dy2[T, n]^T x2[T, k] (reduction over the tokens).  hipBLASLt's kernels for two operands that are both
     strided along the reduction reach 0.9-1.2 PFLOP/s on the block's shapes, with ONE operand contiguous along it 1.36-1.39
@@ -299,6 +304,11 @@ def wgrad(dy2, x2):
     smaller one (0.25 ms, HBM-bound) buys 0.7-1.1 ms of GEMM time; at 2 : 3 (q|k|v) the copy costs what it saves and at
     1 : 1 (o) autograd's layout is the fastest."""
     n, k = dy2.shape[1], x2.shape[1]
+    if _DY_T:
+        # the producer of dy (the SwiGLU backward) left its transposed copy [n, T]: both operands contiguous along the tokens
+        dy_t = _DY_T.pop((dy2.data_ptr(), dy2.numel()), None)
+        if dy_t is not None and x2.stride(1) == 1:
+            return torch.nn.functional.linear(dy_t, transpose2d(x2))                # [n, T] x [k, T]^T -> [n, k]
     if WGRAD_MIXED and dy2.is_cuda and dy2.dtype == torch.bfloat16 and dy2.stride(1) == 1 and x2.stride(1) == 1:
         if n >= 2 * k:
             return dy2.t() @ transpose2d(x2).t()          # x is the smaller operand
@@ -389,11 +399,20 @@ class _SwiGLUDown(torch.autograd.Function):
         if (want_dw and SWIGLU_PROD_T and WGRAD_MIXED and gu.dtype == torch.bfloat16 and ff >= 2 * n and rows >= 4096
                 and rows % 8 == 0):
             prod_t = torch.empty((ff, rows), dtype=gu.dtype, device=gu.device)
+            # ... and d(gate|up) ALSO transposed (an extra store, unlike the product) for the weight gradient of the fused gate|up
+            # projection, the last one with a strided operand: 7.49 -> 6.34 ms of GEMM for ~0.9 ms of kernel; handed over through
+            # `_DY_T` (the next backward node is that projection's `_LinearTN`).  Skipped when the [2 ff, T] buffer is large
+            # (cfg 5 runs at 88 % of HBM).
+            dgu_t = None
+            _DY_T.clear()
+            if SWIGLU_DGU_T and 2 * ff * rows * es <= SWIGLU_DGU_T_MAX_BYTES:
+                dgu_t = torch.empty((2 * ff, rows), dtype=gu.dtype, device=gu.device)
+                _DY_T[(dgu.data_ptr(), dgu.numel())] = dgu_t
             with torch.cuda.device(gu.device):
                 check(lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),
-                                           dgu.data_ptr() + ff * es, prod_t.data_ptr(), rows, ff, 2 * ff, ff, 2 * ff, rows,
-                                           _dt(gu), _stream(gu)), "rpo_swiglu_bwd_t")
-            del dprod
+                                           dgu.data_ptr() + ff * es, prod_t.data_ptr(), _p(dgu_t), rows, ff, 2 * ff, ff, 2 * ff,
+                                           rows, _dt(gu), _stream(gu)), "rpo_swiglu_bwd_t")
+            del dprod, dgu_t
             return dgu, torch.nn.functional.linear(transpose2d(dy2), prod_t)      # [n, T] x [ff, T]^T -> [n, ff]
         with torch.cuda.device(gu.device):
             check(lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),

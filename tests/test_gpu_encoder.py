@@ -67,28 +67,40 @@ def test_swiglu_down_transposed_product_path(T, ff, d):
                               prod.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, ff, _dt(gu), _stream(gu)) == 0
     prod_t = torch.full((ff, T), float("nan"), dtype=dtype, device=DEV)
     assert lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu_b.data_ptr(), dgu_b.data_ptr() + ff * es,
-                                prod_t.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, T, _dt(gu), _stream(gu)) == 0
+                                prod_t.data_ptr(), None, T, ff, 2 * ff, ff, 2 * ff, T, _dt(gu), _stream(gu)) == 0
     assert torch.equal(dgu_a, dgu_b)
     assert torch.equal(prod_t, prod.t())
-    # through the autograd op: both paths, same inputs
+    # ... and with d(gate|up) transposed as well: [2 ff, T] = the transpose of the row-major [dg | du], bit for bit
+    dgu_c, prod_t2 = torch.empty_like(gu), torch.full((ff, T), float("nan"), dtype=dtype, device=DEV)
+    dgu_t = torch.full((2 * ff, T), float("nan"), dtype=dtype, device=DEV)
+    assert lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu_c.data_ptr(), dgu_c.data_ptr() + ff * es,
+                                prod_t2.data_ptr(), dgu_t.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, T, _dt(gu), _stream(gu)) == 0
+    assert torch.equal(dgu_c, dgu_a) and torch.equal(prod_t2, prod_t) and torch.equal(dgu_t, dgu_a.t())
+    # through the autograd ops: the fused gate|up projection (ops.linear) feeding swiglu_down, transposed outputs on / off
     W = (torch.randn(d, ff, device=DEV) * 0.05).to(dtype)
+    Wgu = (torch.randn(2 * ff, d, device=DEV) * 0.05).to(dtype)
+    x = torch.randn(T, d, device=DEV).to(dtype)
     gy = torch.randn(T, d, device=DEV).to(dtype)
     res = {}
     for flag in (True, False):
-        ops.SWIGLU_PROD_T = flag
+        ops.SWIGLU_PROD_T = ops.SWIGLU_DGU_T = flag
         try:
-            g1 = gu.clone().requires_grad_(True)
-            W1 = W.clone().requires_grad_(True)
-            ops.swiglu_down(g1, W1).backward(gy)
-            res[flag] = (g1.grad, W1.grad)
+            x1, W1, Wgu1 = x.clone().requires_grad_(True), W.clone().requires_grad_(True), Wgu.clone().requires_grad_(True)
+            ops.swiglu_down(ops.linear(x1, Wgu1), W1).backward(gy)
+            res[flag] = (x1.grad, W1.grad, Wgu1.grad)
+            assert not ops._DY_T                                   # the hand-over entry was consumed
         finally:
-            ops.SWIGLU_PROD_T = True
-    assert torch.equal(res[True][0], res[False][0])
-    ref = res[False][1].float()
-    assert float((res[True][1].float() - ref).norm() / ref.norm()) < 4e-3            # two bf16 roundings of differently ordered f32 sums
-    g2, W2 = gu.double().requires_grad_(True), W.double().requires_grad_(True)
-    ((F.silu(g2[:, :ff]) * g2[:, ff:]) @ W2.T).backward(gy.double())
-    assert float((res[True][1].double() - W2.grad).norm() / W2.grad.norm()) < 6e-3     # vs float64 autograd: one bf16 rounding of the result
+            ops.SWIGLU_PROD_T = ops.SWIGLU_DGU_T = True
+    assert torch.equal(res[True][0], res[False][0])                # the input gradient reads the row-major d(gate|up): unchanged
+    for i in (1, 2):                                               # two bf16 roundings of differently ordered f32 sums
+        ref = res[False][i].float()
+        assert float((res[True][i].float() - ref).norm() / ref.norm()) < 4e-3
+    x2, W2, Wgu2 = x.double().requires_grad_(True), W.double().requires_grad_(True), Wgu.double().requires_grad_(True)
+    gu2 = x2 @ Wgu2.T
+    gu2 = gu2.to(dtype).double() + (gu2 - gu2.detach())            # the projection output is stored in bf16 (straight-through)
+    ((F.silu(gu2[:, :ff]) * gu2[:, ff:]) @ W2.T).backward(gy.double())
+    assert float((res[True][1].double() - W2.grad).norm() / W2.grad.norm()) < 8e-3     # vs float64 autograd
+    assert float((res[True][2].double() - Wgu2.grad).norm() / Wgu2.grad.norm()) < 8e-3
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
