@@ -97,7 +97,7 @@ def test_swiglu_down_transposed_product_path(T, ff, d):
         assert float((res[True][i].float() - ref).norm() / ref.norm()) < 4e-3
     x2, W2, Wgu2 = x.double().requires_grad_(True), W.double().requires_grad_(True), Wgu.double().requires_grad_(True)
     gu2 = x2 @ Wgu2.T
-    gu2 = gu2.to(dtype).double() + (gu2 - gu2.detach())            # the projection output is stored in bf16 (straight-through)
+    gu2 = gu2.detach().to(dtype).double() + (gu2 - gu2.detach())   # the projection output is stored in bf16 (straight-through)
     ((F.silu(gu2[:, :ff]) * gu2[:, ff:]) @ W2.T).backward(gy.double())
     assert float((res[True][1].double() - W2.grad).norm() / W2.grad.norm()) < 8e-3     # vs float64 autograd
     assert float((res[True][2].double() - Wgu2.grad).norm() / Wgu2.grad.norm()) < 8e-3
