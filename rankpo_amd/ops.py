@@ -294,21 +294,21 @@ def transpose2d(x):
     return out
 
 
-_DY_T = {}            # (data_ptr, numel) of a gradient tensor -> its transposed copy, left by the kernel that produced it (one entry)
+WGRAD_DY_T_HITS = 0   # weight gradients that used a transposed copy of dY left by the kernel that produced dY (tests read it)
 
 
-def wgrad(dy2, x2):
+def wgrad(dy2, x2, dy_t=None):
     """dW [n, k] = dy2[T, n]^T x2[T, k] (reduction over the tokens).  hipBLASLt's kernels for two operands that are both
     strided along the reduction reach 0.9-1.2 PFLOP/s on the block's shapes, with ONE operand contiguous along it 1.36-1.39
     (tools/probe_wgrad.py): when one operand is at most half of the other (gate|up: x, down: dy), a transposed copy of the
     smaller one (0.25 ms, HBM-bound) buys 0.7-1.1 ms of GEMM time; at 2 : 3 (q|k|v) the copy costs what it saves and at
     1 : 1 (o) autograd's layout is the fastest."""
     n, k = dy2.shape[1], x2.shape[1]
-    if _DY_T:
+    if dy_t is not None and tuple(dy_t.shape) == (n, dy2.shape[0]) and dy_t.dtype == dy2.dtype and x2.stride(1) == 1:
         # the producer of dy (the SwiGLU backward) left its transposed copy [n, T]: both operands contiguous along the tokens
-        dy_t = _DY_T.pop((dy2.data_ptr(), dy2.numel()), None)
-        if dy_t is not None and x2.stride(1) == 1:
-            return torch.nn.functional.linear(dy_t, transpose2d(x2))                # [n, T] x [k, T]^T -> [n, k]
+        global WGRAD_DY_T_HITS
+        WGRAD_DY_T_HITS += 1
+        return torch.nn.functional.linear(dy_t, transpose2d(x2))                    # [n, T] x [k, T]^T -> [n, k]
     if WGRAD_MIXED and dy2.is_cuda and dy2.dtype == torch.bfloat16 and dy2.stride(1) == 1 and x2.stride(1) == 1:
         if n >= 2 * k:
             return dy2.t() @ transpose2d(x2).t()          # x is the smaller operand
@@ -349,7 +349,10 @@ class _LinearTN(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.nn.functional.linear(dy, _wt(w))
         if ctx.needs_input_grad[1]:
-            dw = wgrad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]))
+            # `_rpo_transposed`: set on the gradient tensor by the kernel that produced it (`_SwiGLUDown.backward`); the attribute
+            # travels with the tensor object through the autograd engine.  Should it ever not, the slower layout runs: a miss
+            # costs time, a false match cannot happen (round 4's first version keyed a module-level dict by the data pointer).
+            dw = wgrad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]), getattr(dy, "_rpo_transposed", None))
         return dx, dw
 
 
@@ -400,14 +403,13 @@ class _SwiGLUDown(torch.autograd.Function):
                 and rows % 8 == 0):
             prod_t = torch.empty((ff, rows), dtype=gu.dtype, device=gu.device)
             # ... and d(gate|up) ALSO transposed (an extra store, unlike the product) for the weight gradient of the fused gate|up
-            # projection, the last one with a strided operand: 7.49 -> 6.34 ms of GEMM for ~0.9 ms of kernel; handed over through
-            # `_DY_T` (the next backward node is that projection's `_LinearTN`).  Skipped when the [2 ff, T] buffer is large
-            # (cfg 5 runs at 88 % of HBM).
+            # projection, the last one with a strided operand: 7.49 -> 6.34 ms of GEMM for ~0.9 ms of kernel; handed over as an
+            # attribute of the gradient tensor (the next backward node is that projection's `_LinearTN`).  Skipped when the
+            # [2 ff, T] buffer is large (cfg 5 runs at 88 % of HBM).
             dgu_t = None
-            _DY_T.clear()
             if SWIGLU_DGU_T and 2 * ff * rows * es <= SWIGLU_DGU_T_MAX_BYTES:
                 dgu_t = torch.empty((2 * ff, rows), dtype=gu.dtype, device=gu.device)
-                _DY_T[(dgu.data_ptr(), dgu.numel())] = dgu_t
+                dgu._rpo_transposed = dgu_t
             with torch.cuda.device(gu.device):
                 check(lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),
                                            dgu.data_ptr() + ff * es, prod_t.data_ptr(), _p(dgu_t), rows, ff, 2 * ff, ff, 2 * ff,

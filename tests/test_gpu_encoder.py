@@ -86,9 +86,10 @@ def test_swiglu_down_transposed_product_path(T, ff, d):
         ops.SWIGLU_PROD_T = ops.SWIGLU_DGU_T = flag
         try:
             x1, W1, Wgu1 = x.clone().requires_grad_(True), W.clone().requires_grad_(True), Wgu.clone().requires_grad_(True)
+            hits = ops.WGRAD_DY_T_HITS
             ops.swiglu_down(ops.linear(x1, Wgu1), W1).backward(gy)
             res[flag] = (x1.grad, W1.grad, Wgu1.grad)
-            assert not ops._DY_T                                   # the hand-over entry was consumed
+            assert ops.WGRAD_DY_T_HITS == hits + int(flag)         # the transposed copy reached the gate|up weight gradient
         finally:
             ops.SWIGLU_PROD_T = ops.SWIGLU_DGU_T = True
     assert torch.equal(res[True][0], res[False][0])                # the input gradient reads the row-major d(gate|up): unchanged
