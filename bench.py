@@ -1180,6 +1180,25 @@ def main():
             ts.opt.reducer.zero_()
             torch.cuda.empty_cache()
             torch.cuda.reset_peak_memory_stats(device)
+        # The transposed d(gate|up) of the SwiGLU backward (ops.SWIGLU_DGU_T) is taken up to 6 GiB by default; the Llama-3-8B shape
+        # needs 13 GB.  With the worst-case peak MEASURED, it is allowed when twice its size still leaves 10 % of the usable HBM
+        # free on every rank (cfg 5 on one GPU: 88 % used, no; at 8 GPUs with the optimizer state partitioned: yes), and the
+        # pre-size step runs once more so that the allocator holds the buffer before the timed region.
+        need = 2 * 2 * getattr(cfg, "intermediate_size", 0) * tok_pad * es
+        if ("llama" in arch and not args.no_dgu_t and not args.no_prod_t and need > rankpo_amd.ops.SWIGLU_DGU_T_MAX_BYTES):
+            peak = torch.cuda.max_memory_allocated(device)
+            ok = peak + 2 * need < 0.90 * hbm_usable
+            if multi:
+                okt = torch.tensor([0.0 if ok else 1.0], device=device)
+                dist.all_reduce(okt, op=dist.ReduceOp.MAX)
+                ok = bool(okt.item() == 0)
+            if ok:
+                rankpo_amd.ops.SWIGLU_DGU_T_MAX_BYTES = need
+                wd.phase("allocator pre-size step again (transposed d(gate|up) enabled)", 900)
+                ts.step(full if gas == 1 else [full] * gas)
+                torch.cuda.synchronize()
+            mem_guard["transposed_dgu_buffer_GiB"] = round(need / 2 ** 30, 1)
+            mem_guard["transposed_dgu_enabled"] = bool(ok)
         mem_guard.update(checkpointed_blocks_run=(nl if ckpt < 0 else ckpt),
                          presize_peak_GiB=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
                          presize_peak_over_usable=round(torch.cuda.max_memory_allocated(device) / hbm_usable, 3))

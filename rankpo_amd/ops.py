@@ -275,8 +275,8 @@ def _swiglu_fwd(lib, gu, prod, rows, ff):
 LINEAR_TN = True      # input-gradient GEMMs against a transposed copy of the weight (`_LinearTN`); bench.py --no-linear-tn
 WGRAD_MIXED = True    # weight-gradient GEMMs with the smaller operand transposed first (`wgrad`); bench.py --no-wgrad-mixed
 SWIGLU_DGU_T = True   # ... and d(gate|up) transposed as well, for the gate|up weight gradient; bench.py --no-dgu-t
-SWIGLU_DGU_T_MAX_BYTES = 6 * 2 ** 30          # always taken up to this size ...
-SWIGLU_DGU_T_MARGIN_BYTES = 24 * 2 ** 30      # ... above it only while this much HBM stays free beside it (`_room_for`)
+SWIGLU_DGU_T_MAX_BYTES = 6 * 2 ** 30   # the [2 ff, T] buffer is optional: taken up to this size (cfg 2: 5.1 GB; the Llama-3-8B shape needs 13 GB and
+                                       # runs at 88 % of HBM on one GPU: a caller that has MEASURED its headroom may raise it, as bench.py does)
 SWIGLU_PROD_T = True  # SwiGLU backward writes the recomputed product transposed for the down projection's weight gradient; bench.py --no-prod-t
 WGRAD_SPLIT_T = 4     # chunks of the token reduction for the small-output weight gradients (0 / 1: one GEMM); bench.py --wgrad-split
 
@@ -365,19 +365,6 @@ def linear(x, w, bias=None):
     return torch.nn.functional.linear(x, w, bias)
 
 
-def _room_for(nbytes: int, device) -> bool:
-    """An OPTIONAL transient buffer (the transposed d(gate|up): 5.1 GB on cfg 2, 13 GB on the Llama-3-8B shape) is taken when it is
-    small, or when the device has room to spare for it right now: free HBM as the driver reports it plus what PyTorch's caching
-    allocator holds unused, less a margin -- the Llama-3-8B step runs at 88 % of HBM on one GPU (every block checkpointed), where the
-    buffer must not be what breaks it, and at 8 GPUs with the optimizer state partitioned it has 80 GB to spare.  Either way the
-    results are the same up to the summation order of one GEMM."""
-    if nbytes <= SWIGLU_DGU_T_MAX_BYTES:
-        return True
-    free, _ = torch.cuda.mem_get_info(device)
-    cached = torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
-    return free + cached >= nbytes + SWIGLU_DGU_T_MARGIN_BYTES
-
-
 class _SwiGLUDown(torch.autograd.Function):
     """y = (silu(g) * u) @ W^T with gu = [g | u] the output of ONE fused gate|up projection.  Saves gu and W only: the
     [tokens, ff] product (the largest activation of the block) is recomputed by one fused pass in backward."""
@@ -421,7 +408,7 @@ class _SwiGLUDown(torch.autograd.Function):
             # attribute of the gradient tensor (the next backward node is that projection's `_LinearTN`).  Skipped when the
             # [2 ff, T] buffer is large (cfg 5 runs at 88 % of HBM).
             dgu_t = None
-            if SWIGLU_DGU_T and _room_for(2 * ff * rows * es, gu.device):
+            if SWIGLU_DGU_T and 2 * ff * rows * es <= SWIGLU_DGU_T_MAX_BYTES:
                 dgu_t = torch.empty((2 * ff, rows), dtype=gu.dtype, device=gu.device)
                 dgu._rpo_transposed = dgu_t
             with torch.cuda.device(gu.device):
