@@ -1184,7 +1184,7 @@ def main():
         # needs 13 GB.  With the worst-case peak MEASURED, it is allowed when twice its size still leaves 10 % of the usable HBM
         # free on every rank (cfg 5 on one GPU: 88 % used, no; at 8 GPUs with the optimizer state partitioned: yes), and the
         # pre-size step runs once more so that the allocator holds the buffer before the timed region.
-        need = 2 * 2 * getattr(cfg, "intermediate_size", 0) * tok_pad * es
+        need = 2 * getattr(cfg, "intermediate_size", 0) * tok_pad * es          # [2 ff, T] at the worst-case token count
         if ("llama" in arch and not args.no_dgu_t and not args.no_prod_t and need > rankpo_amd.ops.SWIGLU_DGU_T_MAX_BYTES):
             peak = torch.cuda.max_memory_allocated(device)
             ok = peak + 2 * need < 0.90 * hbm_usable
