@@ -322,7 +322,10 @@ def wgrad(dy2, x2, dy_t=None):
         # accumulator is (relative difference to it 8e-5: summation order).
         T, S = dy2.shape[0], WGRAD_SPLIT_T
         if S > 1 and T >= 32768 and T % S == 0 and n * k <= 8 * 1024 * 1024 and dy2.is_contiguous() and x2.is_contiguous():
-            part = torch.bmm(dy2.view(S, T // S, n).transpose(1, 2), x2.view(S, T // S, k), out_dtype=torch.float32)
+            try:
+                part = torch.bmm(dy2.view(S, T // S, n).transpose(1, 2), x2.view(S, T // S, k), out_dtype=torch.float32)
+            except TypeError:                              # a torch without bmm(out_dtype=): one GEMM, as before
+                return dy2.t() @ x2
             return part.sum(0).to(dy2.dtype)
     return dy2.t() @ x2
 
