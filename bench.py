@@ -379,11 +379,32 @@ def sweep(lib_timed, device):
             ms = e0.elapsed_time(e1) / reps
             best = ms if best is None else min(best, ms)
         fl = 2.0 * Q * P * d
-        res.append(dict(kernel="rpo_infonce_fwd", Q=Q, P=P, d=d, dtype="bf16", ms=round(best, 4),
-                        achieved_TFLOPs=round(fl / best / 1e9, 1),
-                        frac_mfma=round(fl / best / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)))
+        entry = dict(kernel="rpo_infonce_fwd", Q=Q, P=P, d=d, dtype="bf16", ms=round(best, 4),
+                     achieved_TFLOPs=round(fl / best / 1e9, 1),
+                     frac_mfma=round(fl / best / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4))
+        entry.update(_sweep_spot_check(q, p, scores, lse, 0.02))
+        res.append(entry)
         del q, p, scores, ws
     return res
+
+
+def _sweep_spot_check(q, p, scores, lse, temperature, rows=64):
+    """The timed kernel's VALUES on one block of query rows from the middle of the matrix (advisor, round 4: the sweep is the
+    only caller that runs the tile kernels' LDS-DMA rings 32-64 K-steps deep and it asserted rc == 0 only): scores against a
+    float32 matmul with the kernel's two bf16 rounding points (dot -> bf16, / T -> bf16; <= 2 ulps, the tolerance of
+    tests/test_gpu_kernels.py), lse against logsumexp of the RETURNED scores.  A failure raises: a fast wrong kernel is not a
+    sweep point."""
+    Q = q.shape[0]
+    r0 = (Q // 2) // rows * rows
+    raw = q[r0:r0 + rows].float() @ p.float().t()
+    exp = (raw.to(torch.bfloat16).float() / temperature).to(torch.bfloat16).float()
+    got = scores[r0:r0 + rows].float()
+    ulps = ((got - exp).abs() / (exp.abs().clamp_min(1e-2) * 2.0 ** -7)).max().item()
+    lse_err = (torch.logsumexp(got, dim=-1) - lse[r0:r0 + rows]).abs().max().item()
+    if not (ulps <= 2.0 + 1e-6 and lse_err <= 2e-4):
+        raise SystemExit(f"roofline sweep: rpo_infonce_fwd at Q = P = {Q}, d = {q.shape[1]} returns wrong values "
+                         f"(scores {ulps:.2f} bf16 ulps off a float32 matmul, lse error {lse_err:.2e}, rows {r0}..{r0 + rows - 1})")
+    return {"checked_rows": [r0, r0 + rows], "scores_max_ulps": round(ulps, 3), "lse_max_abs_err": float(f"{lse_err:.3g}")}
 
 
 def _cpu_model():
@@ -904,6 +925,87 @@ def rehearse_launch(rank, world, args):
     wd.done()
 
 
+# ----------------------------------------------------------------------------------------------------------
+# Memory guard: the checkpointing plan and its corrections as PURE functions of (usable bytes, measured peak, model shape,
+# world), so that they are tested without a GPU (tests/test_host_logic.py::test_memory_guard_*; round 4's cfg-5 run died of a
+# decision that only a GPU run could exercise).  bench.main feeds them what the device reports.
+# ----------------------------------------------------------------------------------------------------------
+PLAN_HBM_FRACTION = 0.72          # of the usable HBM: what the plan budgets for states + kept activations
+PRESIZE_TIGHT_FRACTION = 0.94     # a worst-case peak above this share of the usable HBM counts as "does not fit"
+DGU_T_ROOM_FRACTION = 0.90        # the transposed d(gate|up) buffer is admitted while peak + 2 x buffer stays below this share
+
+
+def usable_hbm(free_now, reserved_by_this_process, total, ranks_sharing_the_card=1):
+    """HBM this rank can really use: what the device reports free NOW (after RCCL created its communicator, with whatever else
+    lives on the card) plus what this process already holds; `--share-gpu` rehearsals split one card between the ranks."""
+    return min((free_now + reserved_by_this_process) // max(1, ranks_sharing_the_card), total)
+
+
+def optimizer_state_bytes(nparam, es, world, partitioned):
+    """parameters + gradients (2 es B/param) + f32 master / m / v (12 B/param; or 12 / W with the state partitioned over W
+    ranks, + the es / W reduced-gradient shard)."""
+    return nparam * (es * 2 + ((12 + es) / max(1, world) if partitioned else 12))
+
+
+def plan_free_blocks(hbm_usable, nparam, es, hidden, inter, nl, tok_pad, world=1, partitioned=False):
+    """How many of the nl blocks may run WITHOUT activation checkpointing.  Activation bytes kept per token per un-checkpointed
+    block: x, norm(x), q, k, v, attn out, x', norm(x'), gate, up (the SwiGLU product is recomputed) = es (6.5 d + 2 ff) upper
+    bound; measured 44 KB for Llama-3.2-1B bf16 (0.75 of the bound; 0.8 is budgeted).  Tokens: the worst case (every row at
+    full length), also in packed mode.  Besides the states, every block keeps its input (checkpoint or not) and two blocks'
+    worth of working set are in flight."""
+    per_layer = tok_pad * int(0.8 * es * (6.5 * hidden + 2 * inter))
+    budget = (PLAN_HBM_FRACTION * hbm_usable - optimizer_state_bytes(nparam, es, world, partitioned)
+              - tok_pad * hidden * es * nl - 2 * per_layer)
+    return max(0, min(nl, int(budget // per_layer)))
+
+
+def plan_checkpointing(hbm_usable, nparam, es, hidden, inter, nl, tok_pad, world=1, multi=False, partition_mode="auto",
+                       per_block_control=True):
+    """-> (checkpointed blocks: 0 = none, -1 = all for encoders without per-block control, else the first k; partition the
+    optimizer state?).  `auto` partitions exactly when the replicated state would force blocks to be checkpointed."""
+    shape = (nparam, es, hidden, inter, nl, tok_pad, world)
+    partition = multi and partition_mode == "on"
+    if multi and partition_mode == "auto":
+        partition = world > 1 and plan_free_blocks(hbm_usable, *shape, partitioned=False) < nl
+    free = plan_free_blocks(hbm_usable, *shape, partitioned=partition)
+    ckpt = nl - free
+    if not per_block_control:
+        ckpt = 0 if free == nl else -1
+    return ckpt, partition
+
+
+def presize_is_tight(peak, hbm_usable, oom=False):
+    """The worst-case step ran out of memory, or left less than 6 % of the usable HBM to spare."""
+    return bool(oom or peak > PRESIZE_TIGHT_FRACTION * hbm_usable)
+
+
+def checkpoint_more(now_ckpt, nl):
+    """A quarter more of the blocks, or None when every block is checkpointed already (nothing left to give)."""
+    return None if now_ckpt >= nl else min(nl, now_ckpt + max(1, nl // 4))
+
+
+def transposed_dgu_bytes(inter, tok_pad, es):
+    """[2 ff, T] at the worst-case token count: the SwiGLU backward's transposed d(gate|up) (ops.SWIGLU_DGU_T)."""
+    return 2 * inter * tok_pad * es
+
+
+def admit_transposed_dgu(measured_peak, need, hbm_usable, default_limit):
+    """None: the buffer is within ops' static default, nothing to decide.  Else: allowed iff, with the worst-case peak
+    MEASURED, twice its size still leaves 10 % of the usable HBM free (cfg 5 on one GPU: 253 GiB of 287 used, 22 GiB more: no;
+    at 8 GPUs with the optimizer state partitioned: yes).  A dynamic "is there room right now" rule inside ops let cfg 5 run
+    out of memory in round 4 (gpurun_out/r5h)."""
+    if need <= default_limit:
+        return None
+    return bool(measured_peak + 2 * need < DGU_T_ROOM_FRACTION * hbm_usable)
+
+
+def may_retry_after_oom(world):
+    """An out-of-memory error of ONE rank inside a step that holds collectives cannot be agreed on afterwards (its peers sit
+    in the step's all-gather / gradient reduce): with more than one rank it is fatal, `--share-gpu` rehearsals included
+    (advisor, round 4: the retry was allowed there and would have mismatched the collectives)."""
+    return world == 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -963,6 +1065,9 @@ def main():
                          "torch's own default is 10 minutes for nccl, 30 for gloo: longer than a driver's patience)")
     ap.add_argument("--watchdog-scale", type=float, default=1.0,
                     help="multiplies every phase budget of the per-rank watchdog (0 = no watchdog, phases are still logged)")
+    ap.add_argument("--memory-summary", default=None,
+                    help="write torch.cuda.memory_summary() + the allocator's totals after the allocator pre-size step to this file "
+                         "(what the worst-case peak is made of: profiles/r05_cfg5_memory_summary.txt)")
     ap.add_argument("--headline-parity", default="auto", choices=("auto", "on", "off"),
                     help="N = 1: second step-parity sample at the headline size (2 queries <= q_len + 6 passages <= p_len tokens "
                          "through ALL blocks, float32 oracle on the device pinned to the host); auto = on for the Llama-3.2-1B "
@@ -1051,7 +1156,6 @@ def main():
     tok_real = [int(sum(l)) for l in batch_lens]
     tok_pad = B * Lq + B * (1 + K) * Lp
     ckpt = args.ckpt_layers
-    partition = multi and args.partition_optimizer == "on"
     es = 2 if dtype == torch.bfloat16 else 4
     nl = cfg.num_hidden_layers
     nparam = sum(p.numel() for p in enc.parameters())
@@ -1060,33 +1164,17 @@ def main():
     # whatever else lives on the card -- plus what this process already holds (the bf16 parameters), MIN over the ranks, so that
     # every rank derives the same checkpointing plan (round 3 budgeted 0.72 of the nominal 288 GB whatever was free)
     free_now, total_hbm = torch.cuda.mem_get_info(device)
-    hbm_usable = free_now + torch.cuda.memory_reserved(device)
+    hbm_usable = usable_hbm(free_now, torch.cuda.memory_reserved(device), total_hbm, world if args.share_gpu else 1)
     if multi:
         hu = torch.tensor([float(hbm_usable)], dtype=torch.float64, device=device if not args.share_gpu else "cpu")
         dist.all_reduce(hu, op=dist.ReduceOp.MIN)
         hbm_usable = int(hu.item())
-        if args.share_gpu:
-            hbm_usable //= world                 # the rehearsal's ranks share one card
-    hbm_usable = min(hbm_usable, total_hbm)
-
-    def free_blocks(part):
-        # activation bytes kept per token per un-checkpointed block: x, norm(x), q, k, v, attn out, x', norm(x'),
-        # gate, up (the SwiGLU product is recomputed) = s (6.5 d + 2 ff) upper bound; measured 44 KB for
-        # Llama-3.2-1B bf16 (0.75 of the bound).  States: parameters + gradients (2 s B/param) + f32 master / m / v
-        # (12 B/param, or 12 / W with the optimizer state partitioned over W ranks, + the s / W reduced-gradient shard).
-        per_tok = int(0.8 * es * (6.5 * cfg.hidden_size + 2 * cfg.intermediate_size))
-        toks = tok_pad     # budget for the worst case (every row at full length), also in packed mode
-        per_layer = toks * per_tok
-        state = nparam * (es * 2 + ((12 + es) / max(1, world) if part else 12))
-        budget = 0.72 * hbm_usable - state - toks * cfg.hidden_size * es * nl - 2 * per_layer
-        return max(0, min(nl, int(budget // per_layer)))
-    if multi and args.partition_optimizer == "auto":
-        partition = world > 1 and free_blocks(False) < nl
+    # the plan itself: pure functions above (tested without a GPU)
+    plan_ckpt, partition = plan_checkpointing(hbm_usable, nparam, es, cfg.hidden_size, cfg.intermediate_size, nl, tok_pad,
+                                              world=world, multi=multi, partition_mode=args.partition_optimizer,
+                                              per_block_control=hasattr(enc, "layers"))
     if ckpt == -2:
-        free_layers = free_blocks(partition)
-        ckpt = nl - free_layers
-        if not hasattr(enc, "layers"):          # encoders without per-block control: all blocks or none
-            ckpt = 0 if free_layers == nl else -1
+        ckpt = plan_ckpt
     if ckpt != 0 and hasattr(enc, "layers"):
         model.gradient_checkpointing_enable(layers=None if ckpt < 0 else ckpt)
     elif ckpt != 0:
@@ -1157,24 +1245,26 @@ def main():
                 ts.step(full if gas == 1 else [full] * gas)
                 torch.cuda.synchronize()
             except torch.OutOfMemoryError:
-                if world > 1 and not args.share_gpu:
+                if not may_retry_after_oom(world):
                     raise
                 oom = True
+                ts.abort_step()                  # the step died half way: gradients zeroed, reducer disarmed, no pending work
             peak = torch.cuda.max_memory_allocated(device)
-            tight = oom or peak > 0.94 * hbm_usable
+            tight = presize_is_tight(peak, hbm_usable, oom)
             if multi:
                 tg = torch.tensor([1.0 if tight else 0.0], device=device)
                 dist.all_reduce(tg, op=dist.ReduceOp.MAX)
                 tight = bool(tg.item() > 0)
             now_ckpt = nl if ckpt < 0 else ckpt
-            can_more = hasattr(enc, "layers") and now_ckpt < nl
+            more = checkpoint_more(now_ckpt, nl) if hasattr(enc, "layers") else None
+            can_more = more is not None
             note(f"allocator pre-sized on a full-length batch: peak mem {peak / 2**30:.1f} GiB of {hbm_usable / 2**30:.1f} usable"
                  + (" -- OUT OF MEMORY" if oom else "") + (f"; tight: checkpointing more blocks ({now_ckpt} of {nl} so far)" if tight and can_more else ""))
             if not tight or not can_more:
                 if oom:
                     raise SystemExit(f"bench: the worst-case step does not fit in {hbm_usable / 2**30:.1f} GiB of HBM with every block checkpointed")
                 break
-            ckpt = min(nl, now_ckpt + max(1, nl // 4))
+            ckpt = more
             model.gradient_checkpointing_enable(layers=ckpt)
             mem_guard["retries"] += 1
             ts.opt.reducer.zero_()
@@ -1184,10 +1274,9 @@ def main():
         # needs 13 GB.  With the worst-case peak MEASURED, it is allowed when twice its size still leaves 10 % of the usable HBM
         # free on every rank (cfg 5 on one GPU: 88 % used, no; at 8 GPUs with the optimizer state partitioned: yes), and the
         # pre-size step runs once more so that the allocator holds the buffer before the timed region.
-        need = 2 * getattr(cfg, "intermediate_size", 0) * tok_pad * es          # [2 ff, T] at the worst-case token count
-        if ("llama" in arch and not args.no_dgu_t and not args.no_prod_t and need > rankpo_amd.ops.SWIGLU_DGU_T_MAX_BYTES):
-            peak = torch.cuda.max_memory_allocated(device)
-            ok = peak + 2 * need < 0.90 * hbm_usable
+        need = transposed_dgu_bytes(getattr(cfg, "intermediate_size", 0), tok_pad, es)
+        ok = admit_transposed_dgu(torch.cuda.max_memory_allocated(device), need, hbm_usable, rankpo_amd.ops.SWIGLU_DGU_T_MAX_BYTES)
+        if "llama" in arch and not args.no_dgu_t and not args.no_prod_t and ok is not None:
             if multi:
                 okt = torch.tensor([0.0 if ok else 1.0], device=device)
                 dist.all_reduce(okt, op=dist.ReduceOp.MAX)
@@ -1199,6 +1288,16 @@ def main():
                 torch.cuda.synchronize()
             mem_guard["transposed_dgu_buffer_GiB"] = round(need / 2 ** 30, 1)
             mem_guard["transposed_dgu_enabled"] = bool(ok)
+        if args.memory_summary and rank == 0:
+            st_ = torch.cuda.memory_stats(device)
+            with open(args.memory_summary, "w") as f:
+                f.write(f"# {args.workload} ({arch}), world {world}, after the allocator pre-size step (every row at full length: {tok_pad} tokens)\n"
+                        f"# usable HBM {hbm_usable / 2**30:.1f} GiB; peak allocated {st_['allocated_bytes.all.peak'] / 2**30:.1f} GiB, peak reserved "
+                        f"{st_['reserved_bytes.all.peak'] / 2**30:.1f} GiB, allocated now {st_['allocated_bytes.all.current'] / 2**30:.1f} GiB "
+                        f"(= states that outlive a step), reserved now {st_['reserved_bytes.all.current'] / 2**30:.1f} GiB\n"
+                        f"# optimizer_state_bytes (model) {optimizer_state_bytes(nparam, es, world, ts.opt.partition) / 2**30:.1f} GiB; "
+                        f"checkpointed blocks {nl if ckpt < 0 else ckpt} of {nl}; block inputs kept {tok_pad * cfg.hidden_size * es * nl / 2**30:.1f} GiB\n")
+                f.write(torch.cuda.memory_summary(device))
         mem_guard.update(checkpointed_blocks_run=(nl if ckpt < 0 else ckpt),
                          presize_peak_GiB=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
                          presize_peak_over_usable=round(torch.cuda.max_memory_allocated(device) / hbm_usable, 3))

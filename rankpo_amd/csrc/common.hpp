@@ -10,6 +10,7 @@ typedef unsigned short bf16_t;  // raw bf16 bits
 typedef __attribute__((ext_vector_type(8))) short short8_t;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float float4_t;   // 16x16 MFMA accumulator fragment
 typedef __attribute__((ext_vector_type(4))) unsigned int uint4_t;
+typedef __attribute__((ext_vector_type(2))) unsigned int uint2_t;
 
 // ---- bf16 <-> f32 ------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t b) { return __uint_as_float(((unsigned)b) << 16); }

@@ -128,6 +128,15 @@ __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const T* __restrict__
     __shared__ __attribute__((aligned(16))) T tile[TR][LDT];
     const int64_t r0 = (int64_t)blockIdx.y * TR, c0 = (int64_t)blockIdx.x * TC;
     const int t = threadIdx.x;
+    // Tile rows are LDT * sizeof(T) = 520 bytes (bf16): odd rows are 8-byte aligned only, so a 16-byte vector goes in as two
+    // 8-byte stores (a `ds_write_b128` there is a misaligned access: advisor, round 4; two `ds_write_b64` cost the same 12-13
+    // cycles).  Rows of a 16-byte multiple would make the transposed 2-byte reads below 4-way bank-conflicted instead of 2-way
+    // (8 rows apart = 8 * stride dwords = 0 or 32 mod 64 banks for every 16-byte-multiple stride).
+    auto st_tile = [](T* dst, const uint4_t v) {
+        uint2_t* d2 = reinterpret_cast<uint2_t*>(dst);
+        d2[0] = uint2_t{v.x, v.y};
+        d2[1] = uint2_t{v.z, v.w};
+    };
     uint4_t pk_g[DGU_T ? NI : 1], pk_u[DGU_T ? NI : 1];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const T* __restrict__
 #pragma unroll
             for (int k = 0; k < V; ++k) pv[k] = gv[k] = uv[k] = T(0);
         }
-        *reinterpret_cast<uint4_t*>(&tile[row][cv]) = *reinterpret_cast<const uint4_t*>(pv);
+        st_tile(&tile[row][cv], *reinterpret_cast<const uint4_t*>(pv));
         if constexpr (DGU_T) {
             pk_g[i] = *reinterpret_cast<const uint4_t*>(gv);
             pk_u[i] = *reinterpret_cast<const uint4_t*>(uv);
@@ -193,7 +202,7 @@ __global__ __launch_bounds__(256) void swiglu_bwd_t_kernel(const T* __restrict__
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int idx = t + 256 * i;
-                *reinterpret_cast<uint4_t*>(&tile[idx / VPR][(idx % VPR) * V]) = pk[i];
+                st_tile(&tile[idx / VPR][(idx % VPR) * V], pk[i]);
             }
         };
         refill(pk_g);

@@ -342,5 +342,13 @@ class FlatGradAllReducer:
         self._armed = False
         return 1.0 / self.world
 
+    def reset(self):
+        """Forget a step that did not complete (an exception between arm() and finish()): disarmed, nothing pending, gradients
+        zeroed.  Single-rank use only -- with peers, a rank that leaves a step mid-way has already broken the collective sequence."""
+        self._armed = False
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        self.zero_()
+
     def zero_(self):
         self.flat.zero_()

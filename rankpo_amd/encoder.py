@@ -48,6 +48,15 @@ def llama_config(**kw) -> EncoderConfig:
              max_position_embeddings=131072, pad_token_id=None, attention_bias=False, mlp_bias=False,
              initializer_range=0.02, hidden_act="silu", padding_side="right", attention_dropout=0.0)
     d.update(kw)
+    rp = d.pop("rope_parameters", None)
+    if rp:
+        # config.json as transformers >= 5 writes it: rope_theta and the scaling rule live in ONE `rope_parameters` dict
+        # (4.45, the reference's pin, has `rope_theta` + `rope_scaling` at the top level; both are accepted).  Found by
+        # tests/test_checkpoints.py: a 5.x-written checkpoint loaded with the default theta and gave wrong embeddings.
+        if "rope_theta" in rp:
+            d["rope_theta"] = float(rp["rope_theta"])
+        if rp.get("rope_type", rp.get("type", "default")) != "default":
+            d["rope_scaling"] = {k: v for k, v in rp.items() if k != "rope_theta"}
     if d["head_dim"] is None:
         d["head_dim"] = d["hidden_size"] // d["num_attention_heads"]
     return EncoderConfig(**d)
@@ -116,7 +125,10 @@ def _rope_inv_freq(cfg) -> torch.Tensor:
     dim = cfg.head_dim
     inv = 1.0 / (cfg.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.float64) / dim))
     rs = getattr(cfg, "rope_scaling", None)
-    if rs and rs.get("rope_type", rs.get("type")) == "llama3":
+    kind = rs.get("rope_type", rs.get("type")) if rs else None
+    if kind not in (None, "default", "llama3"):
+        raise ValueError(f"rope scaling {kind!r} is not implemented (default and llama3 are: every Llama checkpoint the reference names)")
+    if kind == "llama3":
         factor, lo, hi = rs["factor"], rs["low_freq_factor"], rs["high_freq_factor"]
         old = rs["original_max_position_embeddings"]
         wavelen = 2 * math.pi / inv
@@ -395,6 +407,20 @@ class LlamaLayer(nn.Module):
         return xl + self.mlp(self.post_attention_layernorm(xl))
 
 
+def _resized_embedding(old: nn.Embedding, n: int, std: float) -> nn.Embedding:
+    if n == old.num_embeddings:
+        return old
+    new = nn.Embedding(n, old.embedding_dim, padding_idx=old.padding_idx, device=old.weight.device, dtype=old.weight.dtype)
+    k = min(n, old.num_embeddings)
+    with torch.no_grad():
+        nn.init.normal_(new.weight, 0.0, std)
+        if new.padding_idx is not None and new.padding_idx < n:
+            new.weight[new.padding_idx].zero_()
+        new.weight[:k] = old.weight[:k]
+    new.weight.requires_grad_(old.weight.requires_grad)
+    return new
+
+
 class LlamaEncoder(nn.Module):
     """Decoder-only Llama stack without lm_head (== HF `LlamaModel`)."""
 
@@ -438,18 +464,17 @@ class LlamaEncoder(nn.Module):
     def gradient_checkpointing_disable(self):
         self.gradient_checkpointing = False
 
+    def get_input_embeddings(self):
+        return self.embed_tokens
+
     def resize_token_embeddings(self, n):
-        old = self.embed_tokens
-        if n == old.num_embeddings:
-            return old
-        new = nn.Embedding(n, old.embedding_dim, device=old.weight.device, dtype=old.weight.dtype)
-        nn.init.normal_(new.weight, 0.0, self.config.initializer_range)
-        k = min(n, old.num_embeddings)
-        with torch.no_grad():
-            new.weight[:k] = old.weight[:k]
-        self.embed_tokens = new
-        self.config.vocab_size = n
-        return new
+        """HF `PreTrainedModel.resize_token_embeddings` (run_contrastive.py:132-142: seven special tokens are added to the
+        tokenizer, then `model.model.resize_token_embeddings(len(tokenizer))`): the first min(old, n) rows are kept bit for bit,
+        new rows are drawn N(0, initializer_range) as transformers 4.45's `_init_weights` does, `config.vocab_size` follows.
+        The table is a NEW parameter: build the optimizer (train_step.FlatAdamW) after the resize, as the reference does."""
+        self.embed_tokens = _resized_embedding(self.embed_tokens, n, self.config.initializer_range)
+        self.config.vocab_size = self.embed_tokens.num_embeddings
+        return self.embed_tokens
 
     @property
     def inv_freq(self) -> torch.Tensor:
@@ -714,6 +739,15 @@ class BertEncoder(nn.Module):
     def gradient_checkpointing_enable(self, **_):
         self.gradient_checkpointing = True
 
+    def get_input_embeddings(self):
+        return self.embeddings.word_embeddings
+
+    def resize_token_embeddings(self, n):
+        """See LlamaEncoder.resize_token_embeddings (the reference resizes its XLM-R / BERT encoders the same way)."""
+        self.embeddings.word_embeddings = _resized_embedding(self.embeddings.word_embeddings, n, self.config.initializer_range)
+        self.config.vocab_size = self.embeddings.word_embeddings.num_embeddings
+        return self.embeddings.word_embeddings
+
     def forward(self, input_ids=None, attention_mask=None, token_type_ids=None, return_dict=True, **_):
         x = self.embeddings(input_ids, token_type_ids)
         mask = None
@@ -745,38 +779,160 @@ def build_encoder(config: EncoderConfig) -> nn.Module:
     raise ValueError(f"unsupported architecture {arch!r} (Llama*, Bert* and (XLM)Roberta* encoders are implemented)")
 
 
+SAFE_WEIGHTS, SAFE_INDEX = "model.safetensors", "model.safetensors.index.json"
+BIN_WEIGHTS, BIN_INDEX = "pytorch_model.bin", "pytorch_model.bin.index.json"
+# keys of *For<Task> heads and HF buffers the bare encoder has no use for (AutoModel.from_pretrained drops them too)
+_IGNORED_KEYS = ("pooler.", "lm_head.", "cls.", "classifier.", "score.", "qa_outputs.")
+_IGNORED_PARTS = ("position_ids", "token_type_ids", "inv_freq")
+
+
+def _checkpoint_files(path: str):
+    """The weight files of an HF checkpoint directory, in shard order, as (file name, keys it must hold or None, format).
+    `AutoModel.from_pretrained` (modeling.py:175-178) reads, in this order of preference: one `model.safetensors`; a sharded
+    `model.safetensors.index.json` (how `save_pretrained` writes anything above `max_shard_size`, 5 GB by default in
+    transformers 4.45: Llama-3-8B ships as 4 shards); the same two forms as `pytorch_model.bin`."""
+    for single, index, fmt in ((SAFE_WEIGHTS, SAFE_INDEX, "safetensors"), (BIN_WEIGHTS, BIN_INDEX, "bin")):
+        if os.path.exists(os.path.join(path, single)):
+            return [(single, None, fmt)]
+        if os.path.exists(os.path.join(path, index)):
+            with open(os.path.join(path, index)) as f:
+                wm = json.load(f)["weight_map"]
+            shards = {}
+            for key, fn in wm.items():
+                shards.setdefault(fn, []).append(key)
+            absent = [fn for fn in shards if not os.path.exists(os.path.join(path, fn))]
+            if absent:
+                raise FileNotFoundError(f"checkpoint {path}: {index} names shard files that do not exist: {sorted(absent)}")
+            return [(fn, shards[fn], fmt) for fn in sorted(shards)]
+    raise FileNotFoundError(f"no {SAFE_WEIGHTS}, {SAFE_INDEX}, {BIN_WEIGHTS} or {BIN_INDEX} under {path}")
+
+
+def _encoder_key(key: str, arch: str) -> Optional[str]:
+    """Checkpoint key -> name in the bare encoder's state dict (None: a head / buffer the encoder does not have).  A checkpoint
+    written from LlamaForCausalLM (how meta-llama ships) carries `model.` in front of every encoder key and `lm_head.weight`
+    (absent when tied: Llama-3.2-1B); *ForMaskedLM / *ForSequenceClassification carry `bert.` / `roberta.`."""
+    if key.startswith(_IGNORED_KEYS) or any(part in key for part in _IGNORED_PARTS):
+        return None
+    if "Llama" in arch and key.startswith("model."):
+        return key[len("model."):]
+    for prefix in ("bert.", "roberta."):
+        if key.startswith(prefix):
+            key = key[len(prefix):]
+            return None if key.startswith(_IGNORED_KEYS) else key
+    return key
+
+
 def load_encoder(path: str, torch_dtype=None) -> nn.Module:
-    """Load `config.json` + `model.safetensors` (HF layout, base-model key names) from a directory."""
-    from safetensors.torch import load_file
+    """Load `config.json` + the weights of an HF-layout checkpoint directory: `model.safetensors`, or
+    `model.safetensors.index.json` + its shards, or the `pytorch_model.bin` forms of the two (what
+    `AutoModel.from_pretrained` accepts, modeling.py:175-178).  The encoder is allocated ONCE (in `torch_dtype` if given, as
+    HF's `torch_dtype=` does; float32 otherwise, HF's default) and filled tensor by tensor, shard by shard -- safetensors
+    files are memory-mapped and one tensor is materialised at a time, so a Llama-3-8B load peaks at the model's own size plus
+    one tensor, not twice the checkpoint."""
     with open(os.path.join(path, "config.json")) as f:
         raw = json.load(f)
     default_arch = {"llama": "LlamaModel", "xlm-roberta": "XLMRobertaModel", "roberta": "RobertaModel"}
     arch = (raw.get("architectures") or [default_arch.get(raw.get("model_type"), "BertModel")])[0]
     raw["architectures"] = [arch]
     cfg = llama_config(**raw) if "Llama" in arch else bert_config(**raw)
+    files = _checkpoint_files(path)
     with torch.device("meta"):
         enc = build_encoder(cfg)
-    sd = load_file(os.path.join(path, "model.safetensors"))
-    sd = {(k[len("model."):] if k.startswith("model.") and "Llama" in arch else k): v for k, v in sd.items()}
-    for prefix in ("bert.", "roberta."):            # checkpoints saved from a *ForMaskedLM / *ForSequenceClassification head
-        sd = {(k[len(prefix):] if k.startswith(prefix) else k): v for k, v in sd.items()}
+    if torch_dtype is not None:
+        enc = enc.to(torch_dtype)                              # on the meta device: no bytes move
     enc = enc.to_empty(device="cpu")
-    missing, unexpected = enc.load_state_dict(sd, strict=False)
-    unexpected = [u for u in unexpected if not (u.startswith("pooler.") or u.startswith("lm_head.") or
-                                               "position_ids" in u or "token_type_ids" in u or "inv_freq" in u)]
+    target = enc.state_dict()                                  # name -> the parameter's / buffer's own storage
+    loaded, unexpected = set(), []
+
+    def put(key, get):
+        name = _encoder_key(key, arch)
+        if name is None:
+            return
+        if name not in target:
+            unexpected.append(key)
+            return
+        t = get()
+        if tuple(t.shape) != tuple(target[name].shape):
+            raise RuntimeError(f"checkpoint {path}: size mismatch for {key}: checkpoint {tuple(t.shape)}, "
+                               f"encoder {tuple(target[name].shape)} (config.json: vocab_size={getattr(cfg, 'vocab_size', None)})")
+        with torch.no_grad():
+            target[name].copy_(t)                              # casts to the encoder's dtype on the way
+        loaded.add(name)
+
+    for fn, expect, fmt in files:
+        full = os.path.join(path, fn)
+        if fmt == "safetensors":
+            from safetensors import safe_open
+            with safe_open(full, framework="pt", device="cpu") as f:
+                keys = list(f.keys())
+                for k in keys:
+                    put(k, lambda k=k: f.get_tensor(k))
+        else:
+            sd = torch.load(full, map_location="cpu", weights_only=True, mmap=True)
+            keys = list(sd)
+            for k in keys:
+                put(k, lambda k=k: sd[k])
+            del sd
+        if expect is not None and set(expect) - set(keys):
+            raise RuntimeError(f"checkpoint {path}: the index places {sorted(set(expect) - set(keys))[:4]} ... in {fn}, which does not hold them")
+    missing = [k for k in target if k not in loaded]
     if missing or unexpected:
         raise RuntimeError(f"checkpoint {path} does not match the encoder: missing={missing} unexpected={unexpected}")
     if "Llama" in arch:
         enc._inv_freq = {"cpu": _rope_inv_freq(cfg)}         # (built under the meta device above)
-    return enc.to(torch_dtype) if torch_dtype is not None else enc
+    return enc
 
 
-def save_encoder(enc: nn.Module, path: str):
-    """Write the INNER encoder in HF layout (what the reference's save_model does: contrastive_trainer.py:964-1027)."""
+def _parse_size(size) -> int:
+    """'5GB' / '200KB' / '10MiB' / int bytes, as transformers' `max_shard_size` (decimal units for KB / MB / GB)."""
+    if isinstance(size, (int, float)):
+        return int(size)
+    s = str(size).strip().upper()
+    for unit, mult in (("KIB", 2 ** 10), ("MIB", 2 ** 20), ("GIB", 2 ** 30), ("KB", 10 ** 3), ("MB", 10 ** 6), ("GB", 10 ** 9)):
+        if s.endswith(unit):
+            return int(float(s[:-len(unit)]) * mult)
+    return int(s)
+
+
+def save_encoder(enc: nn.Module, path: str, max_shard_size="5GB"):
+    """Write the INNER encoder in HF layout (what the reference's save_model does: contrastive_trainer.py:964-1027, which calls
+    `self.model.model.save_pretrained(output_dir, safe_serialization=True)`): `config.json` (with the CURRENT vocab_size, i.e.
+    after `resize_token_embeddings`, run_contrastive.py:132-142) + `model.safetensors`, or -- above `max_shard_size`, 5 GB as in
+    transformers 4.45 -- `model-0000i-of-0000N.safetensors` + `model.safetensors.index.json` (greedy split in state-dict order,
+    HF's rule).  Tensors go to the host one shard at a time: parameters may be views of ONE flat optimizer buffer
+    (train_step.FlatAdamW), so each gets a private contiguous copy, and a Llama-3-8B save holds 5 GB of host copies, not 16."""
     from safetensors.torch import save_file
     os.makedirs(path, exist_ok=True)
-    # a private host copy of every tensor: parameters may be views of ONE flat optimizer buffer (train_step.FlatAdamW)
-    sd = {k: v.detach().to("cpu", copy=True).contiguous() for k, v in enc.state_dict().items()}
-    save_file(sd, os.path.join(path, "model.safetensors"), metadata={"format": "pt"})
+    limit = _parse_size(max_shard_size)
+    sd = enc.state_dict()
+    shards, cur, cur_bytes = [], [], 0
+    for k, v in sd.items():
+        nb = v.numel() * v.element_size()
+        if cur and cur_bytes + nb > limit:
+            shards.append(cur)
+            cur, cur_bytes = [], 0
+        cur.append(k)
+        cur_bytes += nb
+    if cur:
+        shards.append(cur)
+    for fn in os.listdir(path):                                 # a previous save of another shard count must not shine through
+        if fn == SAFE_INDEX or (fn.startswith("model") and fn.endswith(".safetensors")):
+            os.remove(os.path.join(path, fn))
+    names = [SAFE_WEIGHTS] if len(shards) == 1 else [f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors" for i in range(len(shards))]
+    weight_map, total = {}, 0
+    for fn, keys in zip(names, shards):
+        part = {k: sd[k].detach().to("cpu", copy=True).contiguous() for k in keys}
+        save_file(part, os.path.join(path, fn), metadata={"format": "pt"})
+        for k in keys:
+            weight_map[k] = fn
+            total += part[k].numel() * part[k].element_size()
+        del part
+    if len(shards) > 1:
+        with open(os.path.join(path, SAFE_INDEX), "w") as f:
+            json.dump({"metadata": {"total_size": total}, "weight_map": weight_map}, f, indent=2, sort_keys=True)
     with open(os.path.join(path, "config.json"), "w") as f:
-        json.dump({k: v for k, v in enc.config.to_dict().items()}, f, indent=2, default=str)
+        cfgd = {k: v for k, v in enc.config.to_dict().items()}
+        p0 = next(iter(enc.parameters()), None)
+        if p0 is not None:
+            cfgd["torch_dtype"] = str(p0.dtype).replace("torch.", "")
+        json.dump(cfgd, f, indent=2, default=str)

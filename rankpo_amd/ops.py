@@ -322,12 +322,28 @@ def wgrad(dy2, x2, dy_t=None):
         # accumulator is (relative difference to it 8e-5: summation order).
         T, S = dy2.shape[0], WGRAD_SPLIT_T
         if S > 1 and T >= 32768 and T % S == 0 and n * k <= 8 * 1024 * 1024 and dy2.is_contiguous() and x2.is_contiguous():
-            try:
+            if _bmm_f32_out_ok(dy2.device):
                 part = torch.bmm(dy2.view(S, T // S, n).transpose(1, 2), x2.view(S, T // S, k), out_dtype=torch.float32)
-            except TypeError:                              # a torch without bmm(out_dtype=): one GEMM, as before
-                return dy2.t() @ x2
-            return part.sum(0).to(dy2.dtype)
+                return part.sum(0).to(dy2.dtype)
     return dy2.t() @ x2
+
+
+_BMM_F32_OUT = {}
+
+
+def _bmm_f32_out_ok(device) -> bool:
+    """Does this torch / backend run `bmm(bf16, bf16, out_dtype=float32)`?  Probed ONCE per device on a tiny problem, catching
+    whatever it raises (a torch without the keyword: TypeError; a backend that rejects bf16 -> f32: RuntimeError /
+    NotImplementedError); the split weight gradient is gated on the cached answer instead of a try / except per call."""
+    key = str(device)
+    if key not in _BMM_F32_OUT:
+        try:
+            a = torch.ones(2, 8, 16, dtype=torch.bfloat16, device=device)
+            r = torch.bmm(a.transpose(1, 2), a, out_dtype=torch.float32)
+            _BMM_F32_OUT[key] = bool(r.dtype == torch.float32 and float(r[0, 0, 0]) == 8.0)
+        except Exception:
+            _BMM_F32_OUT[key] = False
+    return _BMM_F32_OUT[key]
 
 
 def _wt(w):
@@ -354,9 +370,16 @@ class _LinearTN(torch.autograd.Function):
             dx = torch.nn.functional.linear(dy, _wt(w))
         if ctx.needs_input_grad[1]:
             # `_rpo_transposed`: set on the gradient tensor by the kernel that produced it (`_SwiGLUDown.backward`); the attribute
-            # travels with the tensor object through the autograd engine.  Should it ever not, the slower layout runs: a miss
-            # costs time, a false match cannot happen (round 4's first version keyed a module-level dict by the data pointer).
-            dw = wgrad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]), getattr(dy, "_rpo_transposed", None))
+            # travels with the tensor object through the autograd engine.  It is STAMPED with the tensor's version counter and
+            # data pointer at production: were the projection output ever given a second consumer (or a hook that edits the
+            # gradient in place), the engine would accumulate into this very tensor object and the transposed copy would be
+            # stale -- the stamp no longer matches and the slower layout runs on the tensor as it is (advisor, round 4).  A miss
+            # costs time, a false match cannot happen.
+            dy_t = None
+            tag = getattr(dy, "_rpo_transposed", None)
+            if tag is not None and tag[1] == dy._version and tag[2] == dy.data_ptr():
+                dy_t = tag[0]
+            dw = wgrad(dy.reshape(-1, dy.shape[-1]), x.reshape(-1, x.shape[-1]), dy_t)
         return dx, dw
 
 
@@ -413,11 +436,12 @@ class _SwiGLUDown(torch.autograd.Function):
             dgu_t = None
             if SWIGLU_DGU_T and 2 * ff * rows * es <= SWIGLU_DGU_T_MAX_BYTES:
                 dgu_t = torch.empty((2 * ff, rows), dtype=gu.dtype, device=gu.device)
-                dgu._rpo_transposed = dgu_t
             with torch.cuda.device(gu.device):
                 check(lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),
                                            dgu.data_ptr() + ff * es, prod_t.data_ptr(), _p(dgu_t), rows, ff, 2 * ff, ff, 2 * ff,
                                            rows, _dt(gu), _stream(gu)), "rpo_swiglu_bwd_t")
+            if dgu_t is not None:                             # stamped AFTER the kernel wrote dgu (version and pointer as handed on)
+                dgu._rpo_transposed = (dgu_t, dgu._version, dgu.data_ptr())
             del dprod, dgu_t
             return dgu, torch.nn.functional.linear(transpose2d(dy2), prod_t)      # [n, T] x [ff, T]^T -> [n, ff]
         with torch.cuda.device(gu.device):

@@ -184,6 +184,15 @@ class TrainStep:
         loss.backward()
         return loss.detach()
 
+    def abort_step(self):
+        """After an exception inside `step` (e.g. an out-of-memory error the caller answers by checkpointing more blocks): drop
+        the half-accumulated gradients and the reducer's armed state, so that the next `step` starts clean.  The optimizer's
+        moments and step count are untouched (the failed step never reached `opt.step`)."""
+        r = self.opt.reducer
+        r.reset()
+        for p, o in zip(r.order, r.offsets):                   # every .grad is the parameter's view of the flat buffer again
+            p.grad = r.flat[o:o + p.numel()].view_as(p)
+
     def step(self, batches) -> torch.Tensor:
         """`batches`: a list of GAS micro-batches (or a single batch when GAS == 1)."""
         if isinstance(batches, dict):

@@ -452,6 +452,52 @@ def test_checkpoint_round_trip_after_flat_optimizer_step(tmp_path):
     assert torch.equal(h1, h2)
 
 
+def test_resize_train_save_load_on_the_hip_optimizer(tmp_path):
+    """f4 + f2 on the device (the CPU twin with torch stand-ins for the two optimizer launches is tests/test_checkpoints.py):
+    the reference's +7-token flow (run_contrastive.py:132-142) -- load, `resize_token_embeddings(V + 7)`, optimizer built after
+    it, one contrastive step through the HIP scoring path and `rpo_adamw_step` on a batch that uses the new ids, sharded save,
+    load: old rows bit-equal before the step, new rows trained, everything back bit for bit, vocab_size V + 7 on disk."""
+    import json
+    import os
+    import rankpo_amd
+    from rankpo_amd import encoder as PE
+    from rankpo_amd.train_step import TrainStep
+    torch.manual_seed(31)
+    V = 200
+    cfg = PE.llama_config(vocab_size=V, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+                          num_attention_heads=4, num_key_value_heads=2, pad_token_id=0)
+    PE.save_encoder(PE.LlamaEncoder(cfg), str(tmp_path / "stage0"))
+    enc = PE.load_encoder(str(tmp_path / "stage0"), torch_dtype=torch.bfloat16).to(DEV)
+    old = enc.embed_tokens.weight.detach().clone()
+    enc.resize_token_embeddings(V + 7)
+    assert enc.embed_tokens.weight.device.type == "cuda" and enc.embed_tokens.weight.dtype == torch.bfloat16
+    assert torch.equal(enc.embed_tokens.weight[:V], old) and enc.config.vocab_size == V + 7
+    model = rankpo_amd.ModelForTraining(encoder=enc, temperature=0.05).train()
+    ts = TrainStep(model.parameters(), lambda b: model(**b)["loss"], lr=1e-2, total_steps=4, warmup_ratio=0.0)
+    rs = np.random.RandomState(32)
+    qi, qm = _batch(rs, 4, 12, V)
+    pi, pm = _batch(rs, 8, 20, V)
+    qi[:, 0] = torch.arange(V + 3, V + 7)                       # four of the seven new tokens, one per query
+    batch = {"query": {"input_ids": qi.to(DEV), "attention_mask": qm.to(DEV)},
+             "passage": {"input_ids": pi.to(DEV), "attention_mask": pm.to(DEV)}}
+    before = enc.embed_tokens.weight.detach().clone()
+    loss = ts.step(batch)
+    assert torch.isfinite(loss)
+    moved = (enc.embed_tokens.weight.detach().float() - before.float()).abs().amax(dim=1)
+    assert (moved[V + 3:V + 7] > 0).all() and (moved[V:V + 3] == 0).all()
+    out = str(tmp_path / "stage1")
+    PE.save_encoder(enc, out, max_shard_size="100KB")
+    assert os.path.exists(os.path.join(out, PE.SAFE_INDEX))
+    assert json.load(open(os.path.join(out, "config.json")))["vocab_size"] == V + 7
+    back = PE.load_encoder(out, torch_dtype=torch.bfloat16).to(DEV)
+    for (k, a), (_, b) in zip(enc.state_dict().items(), back.state_dict().items()):
+        assert torch.equal(a, b), k
+    with torch.no_grad():
+        h1 = enc.eval()(input_ids=qi.to(DEV), attention_mask=qm.to(DEV)).last_hidden_state
+        h2 = back.eval()(input_ids=qi.to(DEV), attention_mask=qm.to(DEV)).last_hidden_state
+    assert torch.equal(h1, h2)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_transpose_and_mixed_layout_wgrad(dtype):
     """rpo_transpose (exact: a permutation of the elements) on aligned, ragged and strided inputs, and ops.wgrad's

@@ -175,6 +175,50 @@ SHAPES = [
 ]
 
 
+DEEP_K_SHAPES = [
+    # Q, P, d: the tile kernels' LDS-DMA ring in STEADY STATE (advisor, round 4: SHAPES reach at most 2 K-steps on the 128-wide
+    # tiles and 6 on 64 x 64, fewer than the ring is deep, so slot reuse -- `stage(t + S - 1, nxt)` behind the counted
+    # `s_waitcnt vmcnt` and the raw `s_barrier` -- ran value-unchecked; only bench.sweep went that deep, asserting rc == 0).
+    (2048, 4096, 512),    # 128 x 128 tiles, ring of 2: 8 K-steps (bf16)
+    (1536, 3072, 1024),   # 128 passages x 64 queries, ring of 3: 16 K-steps
+    (1024, 1024, 2048),   # 64 x 64, ring of 8: 32 K-steps (SURVEY 8d's smallest sweep point at its full depth)
+    (1000, 1100, 1024),   # 64 x 64, ragged in both dimensions, 16 K-steps
+    (2040, 6100, 1024),   # 256 x 256 phased kernel (bf16: 8 x 24 = 192 tiles), 16 K-steps, ragged edges (f32: 128 x 128)
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("Q,P,d", DEEP_K_SHAPES)
+def test_similarity_tile_kernels_deep_k(dtype, Q, P, d):
+    """Scores, lse-derived loss and the eval-mode similarity of the MFMA tile kernels against the f64 oracle at reduction depths
+    beyond every ring depth (same tolerances as test_infonce_forward_backward_shapes)."""
+    rs = np.random.RandomState(Q + 3 * P + d)
+    qn, pn = unit(rs.randn(Q, d)), unit(rs.randn(P, d))
+    G = P // Q
+    pn[::G][:Q] = unit(pn[::G][:Q] + (2.0 / np.sqrt(d)) * qn)
+    q, p = t(qn, dtype), t(pn, dtype)
+    qv, pv = npf(q), npf(p)
+    loss, scores = ops().infonce_loss(q, p, T)
+    s = npf(scores)
+    raw = R.similarity(qv, pv)
+    sev = npf(ops().similarity(q, p))
+    tgt = np.arange(Q) * G
+    if dtype == torch.float32:
+        np.testing.assert_allclose(s, raw / T, rtol=3e-5, atol=3e-5)
+        np.testing.assert_allclose(sev, raw, rtol=3e-5, atol=3e-6)
+        ref = raw / T
+    else:
+        exp = R.round_bf16(R.round_bf16(raw).astype(np.float64) / T)
+        ulps = (np.abs(s - exp) / (np.maximum(np.abs(exp), 1e-2) * 2.0 ** -7)).max()
+        assert ulps <= 2.0 + 1e-6, ulps
+        e1 = R.round_bf16(raw)
+        assert (np.abs(sev - e1) / (np.maximum(np.abs(e1), 1e-3) * 2.0 ** -7)).max() <= 1.0 + 1e-6
+        ref = s.astype(np.float64)                     # the fused softmax / CE is exact on the scores actually returned
+    m = ref.max(-1, keepdims=True)
+    lse = (m + np.log(np.exp(ref - m).sum(-1, keepdims=True)))[:, 0]
+    np.testing.assert_allclose(loss.item(), (lse - ref[np.arange(Q), tgt]).mean(), rtol=3e-5, atol=3e-6)
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Q,P,d", SHAPES)
 def test_infonce_forward_backward_shapes(dtype, Q, P, d):

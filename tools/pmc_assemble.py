@@ -45,7 +45,7 @@ def main():
     seen = defaultdict(int)
     res = {"_meta": {"head": head, "source": "tools/pmc_workload.py under rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum "
                                              "(separate passes, --kernel-trace only); read bytes = 2 x FETCH_SIZE KiB (gfx950), median dispatch",
-                     "round": 4}}
+                     "round": 5}}
     reps = None
     for entry, a in algo.items():
         per, tot_f, tot_w = {}, 0.0, 0.0

@@ -58,9 +58,17 @@ run("rpo_swiglu_bwd", ["swiglu_bwd_kernel"], f"{T} x {ff} bf16, product rewritte
     lambda: lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * 2, prod.data_ptr(), dgu.data_ptr(), dgu.data_ptr() + ff * 2,
                                prod.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, ff, 1, st()))
 prod_t = torch.empty(ff, T, device=DEV, dtype=bf)
-run("rpo_swiglu_bwd_t", ["swiglu_bwd_t_kernel"], f"{T} x {ff} bf16, product written transposed [{ff}, {T}]", 6 * T * ff * 2,
+run("rpo_swiglu_bwd_t@prod_only", ["swiglu_bwd_t_kernel"], f"{T} x {ff} bf16, product written transposed [{ff}, {T}] (6 units)",
+    6 * T * ff * 2,
     lambda: lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * 2, prod.data_ptr(), dgu.data_ptr(), dgu.data_ptr() + ff * 2,
-                                 prod_t.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, T, 1, st()))
+                                 prod_t.data_ptr(), None, T, ff, 2 * ff, ff, 2 * ff, T, 1, st()))
+dgu_t = torch.empty(2 * ff, T, device=DEV, dtype=bf)
+# the form the cfg-2 step runs (ops.SWIGLU_DGU_T): d(gate|up) is ALSO written transposed, 8 units of [T, ff] traffic
+run("rpo_swiglu_bwd_t", ["swiglu_bwd_t_kernel"], f"{T} x {ff} bf16, product AND d(gate|up) written transposed too (8 units)",
+    8 * T * ff * 2,
+    lambda: lib.rpo_swiglu_bwd_t(gu.data_ptr(), gu.data_ptr() + ff * 2, prod.data_ptr(), dgu.data_ptr(), dgu.data_ptr() + ff * 2,
+                                 prod_t.data_ptr(), dgu_t.data_ptr(), T, ff, 2 * ff, ff, 2 * ff, T, 1, st()))
+del dgu_t
 del gu, dgu, prod, prod_t
 nh, nkv, hd = 32, 8, 64
 W = (nh + 2 * nkv) * hd
@@ -90,6 +98,30 @@ xt = torch.empty(d, T, device=DEV, dtype=bf)
 run("rpo_transpose", ["transpose_kernel"], f"[{T}, {d}] bf16 -> [{d}, {T}]", 2 * T * d * 2,
     lambda: lib.rpo_transpose(x.data_ptr(), xt.data_ptr(), T, d, d, T, 1, st()))
 del x, dl, xo, y, dx, xt
+
+# ---- pooling + L2 normalisation at an encode()-scale batch (north_star: "achieved HBM GB/s on normalize/pool") ------------------
+# ModelForInference.encode (reference modeling.py:519-536) pools [N, L, d] hidden states with the int64 attention mask; N = 4096
+# rows of L = 512 tokens, d = 2048.  Forward reads the mask (N L 8 B) and ONE row per sample, writes [N, d]; the padded training
+# path's backward writes the dense [N, L, d] gradient in full (zeros + the one scattered row per sample).
+Np, Lp = 4096, 512
+hp = torch.randn(Np, Lp, d, device=DEV, dtype=bf)
+gm = torch.Generator().manual_seed(5)
+plen = torch.randint(Lp // 2, Lp + 1, (Np,), generator=gm)
+plen[0] = Lp
+pmask = (torch.arange(Lp)[None] < plen[:, None]).to(torch.int64).to(DEV)
+pout = torch.empty(Np, d, device=DEV, dtype=bf)
+pidx = torch.empty(Np, device=DEV, dtype=torch.int32)
+pnorm = torch.empty(Np, device=DEV)
+run("rpo_pool_normalize_fwd", ["pool_normalize_fwd_kernel"], f"N = {Np}, L = {Lp}, d = {d} bf16, int64 mask, last-token + normalize",
+    Np * Lp * 8 + 2 * Np * d * 2 + 8 * Np,
+    lambda: lib.rpo_pool_normalize_fwd(hp.data_ptr(), hp.stride(0), hp.stride(1), pmask.data_ptr(), Np, Lp, d, 1, 0, 1, 1e-12,
+                                       pout.data_ptr(), pidx.data_ptr(), pnorm.data_ptr(), st()))
+pg = torch.randn(Np, d, device=DEV, dtype=bf)
+run("rpo_pool_normalize_bwd", ["pool_normalize_bwd_kernel"], f"N = {Np}, L = {Lp}, d = {d} bf16: dense [N, L, d] gradient written in full",
+    Np * Lp * d * 2 + 2 * Np * d * 2 + 8 * Np,
+    lambda: lib.rpo_pool_normalize_bwd(pg.data_ptr(), pout.data_ptr(), pidx.data_ptr(), pnorm.data_ptr(), Np, Lp, d, 1, 1, 1e-12,
+                                       hp.data_ptr(), None, st()))
+del hp, pmask, pout, pg
 
 # ---- optimizer -------------------------------------------------------------------------------------------------------------------
 n = 1_235_828_736
