@@ -383,9 +383,63 @@ def sweep(lib_timed, device):
                      achieved_TFLOPs=round(fl / best / 1e9, 1),
                      frac_mfma=round(fl / best / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4))
         entry.update(_sweep_spot_check(q, p, scores, lse, 0.02))
+        entry.update(_sweep_backward(lib, q, p, scores, lse, 0.02, best, st))
         res.append(entry)
         del q, p, scores, ws
     return res
+
+
+def _sweep_backward(lib, q, p, scores, lse, temperature, fwd_ms, st):
+    """The scoring BACKWARD at the sweep point (SURVEY 8d counts the path as 6 Q P d FLOP forward + backward): rpo_infonce_ds
+    (dS and dS^T from the stored scores + lse) and the two products dq = dS p, dp = dS^T q -- timed with both arms of the products,
+    the forward kernel's own MFMA frame (rpo_sim_gemm_nt on transposed embeddings; transposes inside the timed region) and
+    hipBLASLt through torch.matmul; the arm `ops.INFONCE_BWD_GEMM` names is the one the product runs and `fwd_bwd_ms` counts.
+    The two arms' gradients are compared (both round dS to bf16 first; they differ by accumulation order only)."""
+    from rankpo_amd import ops
+    Q, d = q.shape
+    P = p.shape[0]
+    gl = torch.ones((), device=q.device)
+    ds = torch.empty(Q, P, device=q.device, dtype=torch.bfloat16)
+    dst = torch.empty(P, Q, device=q.device, dtype=torch.bfloat16)
+    out = {}
+
+    def run(arm):
+        assert lib.rpo_infonce_ds(scores.data_ptr(), lse.data_ptr(), gl.data_ptr(), Q, P, 1, temperature, 0, Q, 0, P,
+                                  ds.data_ptr(), dst.data_ptr(), st) == 0
+        if arm == "hip":
+            out[arm] = (ops.sim_gemm_nt(ds, ops.transpose2d(p)), ops.sim_gemm_nt(dst, ops.transpose2d(q)))
+        else:
+            out[arm] = (ds @ p, dst @ q)
+    times = {}
+    reps = 10 if Q <= 8192 else 4
+    for arm in ("hip", "blaslt"):
+        for _ in range(2):
+            run(arm)
+        torch.cuda.synchronize()
+    for _ in range(3):
+        for arm in ("hip", "blaslt"):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run(arm)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / reps
+            times[arm] = min(times.get(arm, ms), ms)
+    dq_h, dp_h = out["hip"]
+    dq_b, dp_b = out["blaslt"]
+    rel = max(((dq_h.float() - dq_b.float()).abs().max() / dq_b.float().abs().max()).item(),
+              ((dp_h.float() - dp_b.float()).abs().max() / dp_b.float().abs().max()).item())
+    if not rel <= 2.0 ** -6:
+        raise SystemExit(f"roofline sweep: the two arms of the scoring backward disagree at Q = P = {Q}, d = {d}: {rel:.3e}")
+    arm = ops.INFONCE_BWD_GEMM
+    fl = 2.0 * Q * P * d
+    tot = fwd_ms + times[arm]
+    return {"bwd_ms_hip": round(times["hip"], 4), "bwd_ms_blaslt": round(times["blaslt"], 4), "bwd_arm": arm,
+            "bwd_arms_rel_diff": float(f"{rel:.3g}"),
+            "frac_mfma_bwd_hip": round(2 * fl / times["hip"] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "frac_mfma_bwd_blaslt": round(2 * fl / times["blaslt"] / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4),
+            "fwd_bwd_ms": round(tot, 4), "frac_mfma_fwd_bwd": round(3 * fl / tot / 1e9 / MFMA_BF16_PEAK_TFLOPS, 4)}
 
 
 def _sweep_spot_check(q, p, scores, lse, temperature, rows=64):
@@ -405,6 +459,55 @@ def _sweep_spot_check(q, p, scores, lse, temperature, rows=64):
         raise SystemExit(f"roofline sweep: rpo_infonce_fwd at Q = P = {Q}, d = {q.shape[1]} returns wrong values "
                          f"(scores {ulps:.2f} bf16 ulps off a float32 matmul, lse error {lse_err:.2e}, rows {r0}..{r0 + rows - 1})")
     return {"checked_rows": [r0, r0 + rows], "scores_max_ulps": round(ulps, 3), "lse_max_abs_err": float(f"{lse_err:.3g}")}
+
+
+def attention_standalone(timed, cfg, batch_lens, device, reps=6):
+    """The attention entry points of the timed steps, launched back to back ON THEIR OWN in this same process on the same packed
+    shapes (every timed batch's 56 sequence lengths + the filler, rotary fold on, the encoder's own work lists), bracketed by the
+    same HIP events: what a call costs when nothing else has run since the previous call, against what it cost inside the step
+    (`kernels[]`).  Rounds 2-4 quoted stand-alone rates from other boxes and other shapes (48 passages, no rotary) and read the
+    difference as an in-step loss of 12 % / 7 %."""
+    from rankpo_amd import ops
+    nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+    W = (nh + 2 * nkv) * hd
+    kb = ops.ATTN_KEY_BLOCK if hd == 64 else ops.ATTN_KEY_BLOCK_HD128
+    scale = 1.0 / hd ** 0.5
+    n0 = len(timed.records)
+    was = timed.enabled
+    for lens in batch_lens:
+        lens = [int(x) for x in lens]
+        fill = (-sum(lens)) % 256
+        if fill:
+            lens = lens + [fill]
+        T = sum(lens)
+        qkv = torch.randn(T, W, device=device).to(torch.bfloat16)
+        pos = torch.cat([torch.arange(n) for n in lens]).to(device).float()
+        fr = torch.outer(pos, 1.0 / (float(cfg.rope_theta) ** (torch.arange(0, hd, 2, device=device).float() / hd)))
+        rope = (fr.cos().contiguous(), fr.sin().contiguous())
+        cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=device)
+        tiles = ops.attn_tile_table(lens, device, nh, nkv)
+        kt = ops.attn_key_tile_table(lens, device, nkv, kb)      # the defaults the encoder's packed path uses
+        views = lambda t: (t[:, :nh * hd].unflatten(1, (nh, hd)), t[:, nh * hd:(nh + nkv) * hd].unflatten(1, (nkv, hd)),
+                           t[:, (nh + nkv) * hd:].unflatten(1, (nkv, hd)))
+        qv, kv_, vv = views(qkv)
+        dqkv = torch.empty_like(qkv)
+        go = torch.randn(T, nh, hd, device=device).to(torch.bfloat16)
+        for on in (False, True):                                 # one untimed warm-up pair, then `reps` timed pairs
+            timed.enabled = on
+            for _ in range(reps if on else 1):
+                out, lse = ops.flash_attn_varlen_fwd(qv, kv_, vv, cu, tiles, scale, rope=rope)
+                ops.flash_attn_varlen_bwd(qv, kv_, vv, out, go, lse, cu, tiles, kt, scale, grads=views(dqkv), key_block=kb, rope=rope)
+        torch.cuda.synchronize()
+        del qkv, dqkv, go, out, lse
+    timed.enabled = was
+    recs, timed.records = timed.records[n0:], timed.records[:n0]
+    res = {}
+    for name in ("rpo_flash_attn_fwd", "rpo_flash_attn_bwd"):
+        ms = [e0.elapsed_time(e1) for (n, e0, e1, *_rest) in recs if n == name]
+        fl = [r[4] for r in recs if r[0] == name]
+        res[name] = {"calls": len(ms), "avg_us": round(1e3 * sum(ms) / max(1, len(ms)), 2),
+                     "frac_mfma": round(sum(fl) / max(1e-9, sum(ms) * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 5)}
+    return res
 
 
 def _cpu_model():
@@ -930,9 +1033,12 @@ def rehearse_launch(rank, world, args):
 # world), so that they are tested without a GPU (tests/test_host_logic.py::test_memory_guard_*; round 4's cfg-5 run died of a
 # decision that only a GPU run could exercise).  bench.main feeds them what the device reports.
 # ----------------------------------------------------------------------------------------------------------
-PLAN_HBM_FRACTION = 0.72          # of the usable HBM: what the plan budgets for states + kept activations
-PRESIZE_TIGHT_FRACTION = 0.94     # a worst-case peak above this share of the usable HBM counts as "does not fit"
+PLAN_HBM_FRACTION = 0.85          # of the usable HBM: what the plan lets the MODELLED worst-case peak reach (the allocator's own
+#                                   slack on top of it was 13 % on cfg 5: 286 GiB reserved for 253 GiB allocated)
+PRESIZE_TIGHT_FRACTION = 0.94     # a MEASURED worst-case peak above this share of the usable HBM counts as "does not fit"
 DGU_T_ROOM_FRACTION = 0.90        # the transposed d(gate|up) buffer is admitted while peak + 2 x buffer stays below this share
+ACT_KEEP_FRACTION = 0.8           # kept activations of an un-checkpointed block / the upper bound es (6.5 d + 2 ff) per token
+WORKING_SET_BLOCKS = 2.4          # recomputed activations + backward temporaries of the block in flight, in kept-block units
 
 
 def usable_hbm(free_now, reserved_by_this_process, total, ranks_sharing_the_card=1):
@@ -947,16 +1053,29 @@ def optimizer_state_bytes(nparam, es, world, partitioned):
     return nparam * (es * 2 + ((12 + es) / max(1, world) if partitioned else 12))
 
 
+def modelled_peak_bytes(free_blocks, nparam, es, hidden, inter, nl, tok_pad, world=1, partitioned=False):
+    """Worst-case (every row at full length) peak of allocated HBM with `free_blocks` of the nl blocks un-checkpointed:
+      states  +  checkpointed blocks x their kept INPUTS  +  free blocks x their kept activations  +  the block in flight.
+    A block's input is TWO [tokens, d] tensors -- the residual stream travels as (x, delta) because the add is fused into the
+    RMSNorm that follows it (encoder.LlamaLayer.forward(x, delta, ...)) -- which round 4's plan counted once: the 45 GiB nobody
+    had accounted for at cfg 5 (profiles/r05_cfg5_memory_summary.txt: 253.4 GiB allocated = 111.8 states + 2 x 50.5 inputs +
+    40.6 in flight; allocator slack is on top of that, not inside it).  Kept activations per token of a free block: x, norm(x),
+    q|k|v, attention out, x', norm(x'), gate|up (the SwiGLU product is recomputed) <= es (6.5 d + 2 ff), measured 0.75 of that
+    on Llama-3.2-1B.  The block in flight (recomputed activations + d(gate|up), d(product), the transposed product ...) was
+    calibrated on the cfg-5 peak: 2.4 kept-block units.  cfg 2 (all 16 blocks free): modelled 187 GiB, measured 198."""
+    per_layer = tok_pad * int(ACT_KEEP_FRACTION * es * (6.5 * hidden + 2 * inter))
+    return (optimizer_state_bytes(nparam, es, world, partitioned) + (nl - free_blocks) * 2 * tok_pad * hidden * es
+            + free_blocks * per_layer + WORKING_SET_BLOCKS * per_layer)
+
+
 def plan_free_blocks(hbm_usable, nparam, es, hidden, inter, nl, tok_pad, world=1, partitioned=False):
-    """How many of the nl blocks may run WITHOUT activation checkpointing.  Activation bytes kept per token per un-checkpointed
-    block: x, norm(x), q, k, v, attn out, x', norm(x'), gate, up (the SwiGLU product is recomputed) = es (6.5 d + 2 ff) upper
-    bound; measured 44 KB for Llama-3.2-1B bf16 (0.75 of the bound; 0.8 is budgeted).  Tokens: the worst case (every row at
-    full length), also in packed mode.  Besides the states, every block keeps its input (checkpoint or not) and two blocks'
-    worth of working set are in flight."""
-    per_layer = tok_pad * int(0.8 * es * (6.5 * hidden + 2 * inter))
-    budget = (PLAN_HBM_FRACTION * hbm_usable - optimizer_state_bytes(nparam, es, world, partitioned)
-              - tok_pad * hidden * es * nl - 2 * per_layer)
-    return max(0, min(nl, int(budget // per_layer)))
+    """How many of the nl blocks may run WITHOUT activation checkpointing: the largest count whose modelled worst-case peak
+    stays within PLAN_HBM_FRACTION of the usable HBM (0 when even full checkpointing does not: the pre-size step decides)."""
+    shape = (nparam, es, hidden, inter, nl, tok_pad, world, partitioned)
+    free = 0
+    while free < nl and modelled_peak_bytes(free + 1, *shape) <= PLAN_HBM_FRACTION * hbm_usable:
+        free += 1
+    return free
 
 
 def plan_checkpointing(hbm_usable, nparam, es, hidden, inter, nl, tok_pad, world=1, multi=False, partition_mode="auto",
@@ -1065,6 +1184,9 @@ def main():
                          "torch's own default is 10 minutes for nccl, 30 for gloo: longer than a driver's patience)")
     ap.add_argument("--watchdog-scale", type=float, default=1.0,
                     help="multiplies every phase budget of the per-rank watchdog (0 = no watchdog, phases are still logged)")
+    ap.add_argument("--attn-standalone", action="store_true",
+                    help="after the timed steps: the attention entry points back to back on their own, on the timed batches' shapes "
+                         "(same process, same events) -> `attention_in_step_vs_standalone` in the line")
     ap.add_argument("--memory-summary", default=None,
                     help="write torch.cuda.memory_summary() + the allocator's totals after the allocator pre-size step to this file "
                          "(what the worst-case peak is made of: profiles/r05_cfg5_memory_summary.txt)")
@@ -1298,6 +1420,10 @@ def main():
                         f"# optimizer_state_bytes (model) {optimizer_state_bytes(nparam, es, world, ts.opt.partition) / 2**30:.1f} GiB; "
                         f"checkpointed blocks {nl if ckpt < 0 else ckpt} of {nl}; block inputs kept {tok_pad * cfg.hidden_size * es * nl / 2**30:.1f} GiB\n")
                 f.write(torch.cuda.memory_summary(device))
+        if "llama" in arch:
+            run_ckpt = nl if ckpt < 0 else ckpt
+            mem_guard["modelled_peak_GiB"] = round(modelled_peak_bytes(nl - run_ckpt, nparam, es, cfg.hidden_size, cfg.intermediate_size,
+                                                                       nl, tok_pad, world, ts.opt.partition) / 2 ** 30, 1)
         mem_guard.update(checkpointed_blocks_run=(nl if ckpt < 0 else ckpt),
                          presize_peak_GiB=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
                          presize_peak_over_usable=round(torch.cuda.max_memory_allocated(device) / hbm_usable, 3))
@@ -1471,6 +1597,15 @@ def main():
                     "hand_written_kernel_ms_per_step": round(hand_ms, 2), "library_and_glue_ms_per_step": round(lib_ms, 2),
                     "library_gemm_TFLOPs_at_least": round(flops["gemm_required"] / args.steps / (lib_ms * 1e-3) / 1e12, 1),
                     "gemm_share_of_step_time_at_most": round(lib_ms / step_ms, 4)})
+        if world == 1 and args.attn_standalone and kernels and "llama" in arch:
+            wd.phase("attention entry points stand-alone on the timed shapes", 600)
+            alone = attention_standalone(timed, cfg, batch_lens[args.warmup * gas:(args.warmup + args.steps) * gas], device)
+            instep = {k_["entry"]: k_ for k_ in kernels}
+            out["attention_in_step_vs_standalone"] = {
+                name: {"in_step_avg_us": instep[name]["avg_us"], "in_step_frac_mfma": instep[name]["frac_mfma"],
+                       "standalone_avg_us": a["avg_us"], "standalone_frac_mfma": a["frac_mfma"], "standalone_calls": a["calls"],
+                       "in_step_over_standalone": round(instep[name]["avg_us"] / a["avg_us"], 4)}
+                for name, a in alone.items() if name in instep}
         if world == 1 and not args.no_sweep:
             wd.phase("roofline sweep (similarity + InfoNCE kernel)", 600)
             out["roofline_sweep"] = sweep(timed, device)

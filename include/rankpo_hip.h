@@ -116,6 +116,18 @@ int rpo_infonce_ds(const void* scores, const float* lse, const float* grad_loss,
                    float temperature, int64_t q_row0, int64_t q_rows, int64_t p_row0, int64_t p_rows,
                    void* ds_out, void* dst_out, rpo_stream_t stream);
 
+/* The two products of that GEMM form on the FORWARD kernel's own MFMA frame (round 5; replaces autograd's
+ * `grad_scores @ p` / `grad_scores.t() @ q` of modeling.py:252's matmul, which rounds 1-4 handed to hipBLASLt):
+ *   C [rows_b, rows_a] = B [rows_b, K] A [rows_a, K]^T      bf16 in, f32 accumulation, one rounding to bf16
+ * 256 x 256 tiles, K-step 64, 16-byte LDS-DMA staging, phased MFMA schedule (sim_tile256_kernel with a plain epilogue).
+ * Both operands are contiguous along the reduction, as q and p are in the forward:
+ *   dq [q_rows, d] = rpo_sim_gemm_nt(a = p_all^T [d, P], b = ds_out  [q_rows, P], K = P)
+ *   dp [p_rows, d] = rpo_sim_gemm_nt(a = q_all^T [d, Q], b = dst_out [p_rows, Q], K = Q)
+ * with the transposed embeddings from rpo_transpose.  lda / ldb / ldc: row strides in elements.  Requires K % 64 == 0,
+ * strides % 8 == 0 and 16-byte aligned pointers (RPO_ERR_UNSUPPORTED otherwise: the caller keeps the library GEMM). */
+int rpo_sim_gemm_nt(const void* a, int64_t rows_a, int64_t lda, const void* b, int64_t rows_b, int64_t ldb, int64_t K,
+                    void* c, int64_t ldc, rpo_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * (3) RankPO paired scoring + loss + metrics.
  * Replaces rankpo_trainer.py:436-443 (scores), 545-566 (rankpo_loss), 482-520 (loss mix + metrics).

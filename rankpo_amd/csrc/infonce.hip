@@ -320,10 +320,17 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
     }
 }
 
+// EPI = 0: the scoring forward (scores = <q, p> / T with the reference's two bf16 roundings, per-tile softmax partials).
+// EPI = 1 (round 5): the same frame as a plain NT GEMM, C[Q, P] = q[Q, K] p[P, K]^T rounded to bf16 once -- the two products of the
+// scoring BACKWARD at sweep sizes, dq = dS p_all and dp = dS^T q_all, with the reduction operand transposed beforehand so that
+// both operands are contiguous along the reduction like the forward's (rpo_sim_gemm_nt).  lda / ldb / ldc: row strides (elements)
+// of p, q and the output (EPI 0: d, d, P).
+template <int EPI>
 __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
-    const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, float temperature,
-    int scale, int do_stats, bf16_t* __restrict__ scores, float2* __restrict__ partial, int nPt, int nQt,
-    int stagger, int dbg) {
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, int64_t lda, int64_t ldb,
+    int64_t ldc, float temperature, int scale, int do_stats_arg, bf16_t* __restrict__ scores, float2* __restrict__ partial,
+    int nPt, int nQt, int stagger, int dbg) {
+    const int do_stats = EPI == 0 ? do_stats_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef short8_t Frag;
     constexpr int KE = 64;   // bf16 elements per K-step
@@ -358,7 +365,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
             const int tr = big_unit_row(u, ur);                 // tile row
             const bool isA = (u == 0 || u == 3);
             const int64_t gr = isA ? min(p0 + tr, P - 1) : min(q0 + tr, Q - 1);
-            src[u][j] = (isA ? p : q) + gr * d + lchunk * 8;
+            src[u][j] = (isA ? p : q) + gr * (isA ? lda : ldb) + lchunk * 8;
         }
 #define RPO_BIG_STAGE(U, T, BUF)                                                                                   \
     do {                                                                                                           \
@@ -490,13 +497,13 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     // ---- epilogue: acc[m][n][j] = <p_{pbase + 16m + j}, q_{qbase + 16n}>
     const int64_t pbase = p0 + wp * 128 + g * 4;
     const int64_t qbase = q0 + wq * 64 + frow;
-    const bool vec_ok = (P % 4 == 0) && rpo_aligned16_dev(scores);
+    const bool vec_ok = (ldc % 4 == 0) && rpo_aligned16_dev(scores);
     const float inv_t = 1.0f / temperature;
     // Scores leave through LDS: each wave parks its 64 (q) x 128 (p) bf16 sub-tile in its own 64 x 272-byte image
     // (8-byte ds_writes of 4 consecutive p) and streams it out as whole 256-byte row segments with 16-byte stores,
     // instead of 8-byte stores that touch a quarter of a 128-byte line each (measured: the direct stores cost 14 %
     // of the kernel at Q = P = 16384).
-    const bool staged = (P % 8 == 0) && rpo_aligned16_dev(scores) && !(dbg & 2);
+    const bool staged = (ldc % 8 == 0) && rpo_aligned16_dev(scores) && !(dbg & 2);
     const bool interior = staged && p0 + kBigTile <= P && q0 + kBigTile <= Q;
     char* wstage = smem + wave * kBigStageWaveBytes;
     float2* s_stat = reinterpret_cast<float2*>(smem + 8 * kBigStageWaveBytes);   // [wq][64] from the wp == 1 waves
@@ -505,7 +512,17 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         const int64_t qi = qbase + 16 * n;
         const bool qv = qi < Q;
         float mx = RPO_NEG_INF, sum = 0.f;
-        if (interior) {
+        if constexpr (EPI == 1) {
+            // plain GEMM epilogue: one rounding to bf16, parked in the wave's LDS image, streamed out below as 256-byte segments
+            // (the host admits this instantiation only when the staged path applies: ldc % 8 == 0, 16-byte aligned output)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                uint2 w;
+                w.x = pack2_bf16(acc[m][n][0], acc[m][n][1]);
+                w.y = pack2_bf16(acc[m][n][2], acc[m][n][3]);
+                *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
+            }
+        } else if (interior) {
             // interior tile (no row or column outside the matrix): no bounds tests, both roundings as packed conversions
             // (two scores per v_cvt_pk_bf16_f32, whose result IS the store payload): ~10 VALU instructions per score
             // instead of ~18 -- the epilogue is VALU-bound (128 scores per lane) and was 14 % of the kernel at d = 2048
@@ -558,7 +575,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                     w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
                     *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
                 } else if (qv && !(dbg & 1)) {
-                    store_scores4<bf16_t>(scores + qi * P, pbase + 16 * m, P, v, vec_ok);
+                    store_scores4<bf16_t>(scores + qi * ldc, pbase + 16 * m, P, v, vec_ok);
                 }
             }
             if (do_stats) {
@@ -588,7 +605,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                 const int64_t qi = q0 + wq * 64 + r;
                 const uint4_t w = *reinterpret_cast<const uint4_t*>(wstage + r * kBigStageRowBytes + (lane & 15) * 16);
                 if (qi < Q) {
-                    bf16_t* dst = scores + qi * P + prow0;
+                    bf16_t* dst = scores + qi * ldc + prow0;
                     if (prow0 + 7 < P) {
                         if (dbg & 4) *reinterpret_cast<uint4_t*>(dst) = w;
                         else __builtin_nontemporal_store(w, reinterpret_cast<uint4_t*>(dst));
@@ -1324,12 +1341,12 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
         if constexpr (sizeof(T) == 2) {
             static bool attr_set256 = false;
             if (!attr_set256) {
-                (void)hipFuncSetAttribute((const void*)sim_tile256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           kBigLdsBytes);
                 attr_set256 = true;
             }
-            RPO_LAUNCH(sim_tile256_kernel, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kBigThreads), kBigLdsBytes, st,
-                       (const bf16_t*)q, (const bf16_t*)p, Q, P, d, temperature, scale, do_stats ? 1 : 0,
+            RPO_LAUNCH(sim_tile256_kernel<0>, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kBigThreads), kBigLdsBytes, st,
+                       (const bf16_t*)q, (const bf16_t*)p, Q, P, d, d, d, P, temperature, scale, do_stats ? 1 : 0,
                        (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0);
         }
     } else if (pl.path == PATH_SKINNY) {
@@ -1516,6 +1533,28 @@ extern "C" int rpo_infonce_ds(const void* scores, const float* lse, const float*
     else
         RPO_LAUNCH(infonce_ds_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)scores, lse, grad_loss, Q, P,
                    temperature, P / Q, q_row0, q_rows, p_row0, p_rows, (bf16_t*)ds_out, (bf16_t*)dst_out);
+    return rpo_launch_status();
+}
+
+// C [rows_b, rows_a] = B [rows_b, K] A [rows_a, K]^T (bf16 in, f32 accumulate, one rounding to bf16): see sim_tile256_kernel<1>.
+extern "C" int rpo_sim_gemm_nt(const void* a, int64_t rows_a, int64_t lda, const void* b, int64_t rows_b, int64_t ldb, int64_t K,
+                               void* c, int64_t ldc, rpo_stream_t stream) {
+    if (!a || !b || !c || rows_a <= 0 || rows_b <= 0 || K <= 0) return RPO_ERR_INVALID_ARG;
+    // the frame's K-step is 64 elements and its operands travel as 16-byte LDS-DMA pieces; the epilogue streams 256-byte row
+    // segments out of LDS (the `staged` path of the forward): everything else is left to the caller's library GEMM
+    if (K % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || lda < K || ldb < K || ldc < rows_a || !rpo_aligned16(a) ||
+        !rpo_aligned16(b) || !rpo_aligned16(c))
+        return RPO_ERR_UNSUPPORTED;
+    const int64_t nPt = rpo_cdiv(rows_a, kBigTile), nQt = rpo_cdiv(rows_b, kBigTile);
+    if (nPt * nQt > 0x7fffffff) return RPO_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
+        attr_set = true;
+    }
+    RPO_LAUNCH(sim_tile256_kernel<1>, dim3((unsigned)(nPt * nQt)), dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream,
+               (const bf16_t*)b, (const bf16_t*)a, rows_b, rows_a, K, lda, ldb, ldc, 1.0f, 0, 0, (bf16_t*)c, (float2*)nullptr,
+               (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0);
     return rpo_launch_status();
 }
 

@@ -149,8 +149,8 @@ class _InfoNCE(torch.autograd.Function):
                 check(lib.rpo_infonce_ds(scores.data_ptr(), lse.data_ptr(), gl.data_ptr(), Q, P, dt, temperature,
                                          q_row0, q_rows if need_q else 0, p_row0, p_rows if need_p else 0, _p(ds),
                                          _p(dst), _stream(q_all)), "rpo_infonce_ds")
-            dq = ds @ p_all if need_q else None
-            dp = dst @ q_all if need_p else None
+            dq = _bwd_product(ds, p_all) if need_q else None
+            dp = _bwd_product(dst, q_all) if need_p else None
             return dq, dp, None, None, None, None, None, None
         dq = torch.empty((q_rows, d), dtype=q_all.dtype, device=q_all.device) if need_q else None
         dp = torch.empty((p_rows, d), dtype=q_all.dtype, device=q_all.device) if need_p else None
@@ -161,6 +161,33 @@ class _InfoNCE(torch.autograd.Function):
                                           p_row0, p_rows, _p(dq), _p(dp), None, 0, _stream(q_all)),
                       "rpo_infonce_bwd")
         return dq, dp, None, None, None, None, None, None
+
+
+INFONCE_BWD_GEMM = "hip"     # "hip": the two products of the large backward on the forward's own MFMA frame (rpo_sim_gemm_nt);
+#                              "blaslt": torch.matmul -> hipBLASLt (rounds 1-4; the A/B arm, bench.py sweep reports both)
+
+
+def sim_gemm_nt(b, a):
+    """b [M, K] a [N, K]^T -> [M, N] (bf16, both operands contiguous along K): sim_tile256_kernel's frame with a plain epilogue."""
+    lib = _lib.load()
+    M, K = b.shape
+    N = a.shape[0]
+    c = torch.empty((M, N), dtype=b.dtype, device=b.device)
+    with torch.cuda.device(b.device):
+        check(lib.rpo_sim_gemm_nt(a.data_ptr(), N, a.stride(0), b.data_ptr(), M, b.stride(0), K, c.data_ptr(), c.stride(0),
+                                  _stream(b)), "rpo_sim_gemm_nt")
+    return c
+
+
+def _bwd_product(ds, x_all):
+    """ds [rows, K] @ x_all [K, d]: dq = dS p_all or dp = dS^T q_all.  On the hand-written path the embeddings are transposed
+    first (rpo_transpose: 2 K d bytes each way, ~1 % of the product's time at sweep sizes) so that both operands are contiguous
+    along the reduction, the layout of the forward kernel's LDS-DMA staging."""
+    K, d = x_all.shape
+    if (INFONCE_BWD_GEMM == "hip" and ds.dtype == torch.bfloat16 and K % 64 == 0 and d % 8 == 0 and ds.stride(1) == 1
+            and ds.stride(0) % 8 == 0 and ds.data_ptr() % 16 == 0):
+        return sim_gemm_nt(ds, transpose2d(x_all))
+    return ds @ x_all
 
 
 def infonce_loss(q_local, p_local, temperature: float, use_inbatch_neg: bool = True, q_all=None, p_all=None,
@@ -578,7 +605,7 @@ def rope_(x, cos, sin, heads, head_dim, grad_inplace: bool = False):
 # ------------------------------------------------------------------------------------------------
 # (6) causal variable-length flash attention, head_dim 64 (encoder side)
 # ------------------------------------------------------------------------------------------------
-def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, block_m: int = 128):
+def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, block_m: int = 128, heads_per_block: int = 1):
     """The query-tile work list of the forward and dQ kernels (block = 128 queries of one (sequence, head)).
 
     num_heads == 0: int32 [ntiles, 2] = (sequence id, first query row), heaviest (latest) tiles first; the kernels run one
@@ -596,6 +623,8 @@ def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, blo
         return torch.tensor(tiles, dtype=torch.int32).to(device, non_blocking=True)
     H = num_kv_heads if num_kv_heads > 0 else num_heads
     rep = num_heads // H
+    if rep % heads_per_block:
+        raise ValueError("attn_tile_table: heads_per_block must divide the q heads per kv head")
     lens_np = np.asarray(lens, dtype=np.int64)
     order = np.argsort(-lens_np, kind="stable")                       # sequences, longest first
     nt_seq = (lens_np[order] + block_m - 1) // block_m                   # query tiles per sequence (rank order)
@@ -610,8 +639,9 @@ def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, blo
         pos = np.arange(tot) - np.repeat(np.cumsum(nt) - nt, nt)
         q0 = (nt[gi] - 1 - pos) * block_m                                # latest tile of the group first
         seq = order[rank][gi]
-        e = np.stack([np.repeat(seq, rep), np.repeat(q0, rep),
-                      np.repeat(hk[gi] * rep, rep) + np.tile(np.arange(rep), tot)], 1).astype(np.int32)
+        nb = rep // heads_per_block                                       # blocks per (tile, kv head): each serves heads_per_block q heads
+        e = np.stack([np.repeat(seq, nb), np.repeat(q0, nb),
+                      np.repeat(hk[gi] * rep, nb) + np.tile(np.arange(nb) * heads_per_block, tot)], 1).astype(np.int32)
         chunks.append(e)
     per = max(len(c) for c in chunks)
     pad = np.array([[0, 1 << 30, 0]], dtype=np.int32)
@@ -992,7 +1022,7 @@ def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
     return best_val, best_idx
 
 
-__all__ = ["pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
+__all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
            "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
            "attn_key_tile_table"]

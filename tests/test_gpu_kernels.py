@@ -488,12 +488,20 @@ def test_c_abi_argument_errors():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("arm", ["hip", "blaslt"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("Q,P,d,win", [(512, 1536, 128, None), (520, 1560, 192, None), (512, 2048, 64, (128, 200, 640, 600))])
-def test_infonce_backward_gemm_form(dtype, Q, P, d, win):
+@pytest.mark.parametrize("Q,P,d,win", [(512, 1536, 128, None), (520, 1560, 192, None), (512, 2048, 64, (128, 200, 640, 600)),
+                                       (1024, 3072, 512, (256, 300, 1024, 1000))])
+def test_infonce_backward_gemm_form(dtype, Q, P, d, win, arm, monkeypatch):
     """Large problems take the dS-kernel + two-GEMM backward (ops._GEMM_BWD_MIN_PAIRS); same maths, same own-row
-    window semantics as the fused small-shape kernel."""
+    window semantics as the fused small-shape kernel.  Both arms of the two products: the forward's own MFMA frame
+    (rpo_sim_gemm_nt; bf16 with a reduction length that is a multiple of 64, else it hands over to the library by itself)
+    and hipBLASLt through torch.matmul."""
     from rankpo_amd import ops as o
+    monkeypatch.setattr(o, "INFONCE_BWD_GEMM", arm)
+    calls = []
+    real = o.sim_gemm_nt
+    monkeypatch.setattr(o, "sim_gemm_nt", lambda b, a: (calls.append(tuple(b.shape)), real(b, a))[1])
     rs = np.random.RandomState(Q + P)
     qn, pn = unit(rs.randn(Q, d)), unit(rs.randn(P, d))
     qa, pa = t(qn, dtype), t(pn, dtype)
@@ -513,6 +521,44 @@ def test_infonce_backward_gemm_form(dtype, Q, P, d, win):
     tol = 3e-4 if dtype == torch.float32 else 2.0 ** -6      # bf16: dS itself is rounded to bf16 before the GEMM
     assert relmax(npf(ql.grad), dq_ref) < tol
     assert relmax(npf(pl.grad), dp_ref) < tol
+    # the hand-written frame really ran where it applies (bf16, K = P and K = Q multiples of 64), and only there
+    hip_ok = arm == "hip" and dtype == torch.bfloat16
+    assert len(calls) == (int(P % 64 == 0) + int(Q % 64 == 0) if hip_ok else 0), calls
+
+
+@pytest.mark.parametrize("M,N,K,lds", [(256, 256, 64, None), (1000, 384, 4096, None), (300, 2048, 1024, (1096, 1032, 2056)),
+                                       (4096, 512, 8192, None), (77, 40, 128, None)])
+def test_sim_gemm_nt_matches_float32_matmul(M, N, K, lds):
+    """rpo_sim_gemm_nt (sim_tile256_kernel's LDS-DMA / MFMA frame with a plain epilogue): C = B A^T in bf16 with f32 accumulation
+    and ONE rounding, against a float32 matmul -- ragged edges in both output dimensions, row strides wider than the rows,
+    reductions from 1 to 128 K-steps; and the shapes it must refuse (the caller then keeps the library GEMM)."""
+    from rankpo_amd import _lib
+    from rankpo_amd import ops as o
+    torch.manual_seed(M + N + K)
+    ldb, lda, ldc = lds if lds else (K, K, N)
+    bb = torch.randn(M, ldb, device=DEV).to(torch.bfloat16)
+    aa = torch.randn(N, lda, device=DEV).to(torch.bfloat16)
+    b, a = bb[:, :K], aa[:, :K]
+    if lds is None:
+        c = o.sim_gemm_nt(b, a)
+    else:
+        cc = torch.full((M, ldc), 7.0, device=DEV, dtype=torch.bfloat16)
+        lib = _lib.load()
+        assert lib.rpo_sim_gemm_nt(a.data_ptr(), N, lda, b.data_ptr(), M, ldb, K, cc.data_ptr(), ldc,
+                                   torch.cuda.current_stream().cuda_stream) == 0
+        c = cc[:, :N]
+        assert (cc[:, N:] == 7.0).all()                   # nothing written past the rows' ends
+    ref = b.float() @ a.float().t()
+    err = ((c.float() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
+    assert err <= 2.0 ** -8 * 1.03, err                   # half a bf16 ulp of the f32 result + f32 accumulation-order noise (K up to 8192)
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(256, 256, device=DEV, dtype=torch.bfloat16)
+    assert lib.rpo_sim_gemm_nt(x.data_ptr(), 256, 256, x.data_ptr(), 256, 256, 96, x.data_ptr(), 256, st) == -2     # K % 64
+    assert lib.rpo_sim_gemm_nt(x.data_ptr(), 256, 100, x.data_ptr(), 256, 256, 64, x.data_ptr(), 256, st) == -2     # lda % 8
+    assert lib.rpo_sim_gemm_nt(x.data_ptr() + 2, 64, 256, x.data_ptr(), 64, 256, 64, x.data_ptr(), 256, st) == -2   # alignment
+    assert lib.rpo_sim_gemm_nt(None, 64, 256, x.data_ptr(), 64, 256, 64, x.data_ptr(), 256, st) == -1
+    torch.cuda.synchronize()
 
 
 # ------------------------------------------------------------------------------------------------------------------

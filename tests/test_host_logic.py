@@ -972,3 +972,112 @@ def test_gloo_rebalance_groups(world):
     ret = mgr.dict()
     mp.spawn(_rebalance_worker, args=(world, 29761 + world, ret), nprocs=world, join=True)
     assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+# ------------------------------------------------------------------------------------------------ bench.py's memory guard
+_GIB = 2 ** 30
+_TOK_CONTRASTIVE = 8 * 1280 + 48 * 4096          # cfg 2 / cfg 5: every row at full length (the pre-size step's batch)
+_LLAMA_1B = (1_235_828_736 + 7 * 2048, 2, 2048, 8192, 16)      # parameters, bytes per element, d, ff, blocks
+_LLAMA_8B = (7_504_953_344, 2, 4096, 14336, 32)
+
+
+def test_memory_guard_plans_cfg2_and_cfg5_without_a_gpu():
+    """The checkpointing plan is a pure function of (usable bytes, model shape, world): bench.py's round-4 cfg-5 run died of a
+    memory decision that only a GPU run could exercise (gpurun_out/r5h).  Pinned here against what the GPU measured:
+    cfg 2 runs all 16 blocks un-checkpointed (measured worst-case peak 198 GiB, modelled 187); cfg 5 on one GPU checkpoints all
+    32 (measured 253.4 GiB at 287.2 usable, modelled 253.7); with the optimizer state partitioned over 8 ranks 4 blocks run free."""
+    import bench
+    usable = int(287.2 * _GIB)
+    assert bench.plan_free_blocks(usable, *_LLAMA_1B, _TOK_CONTRASTIVE) == 16
+    assert bench.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE) == (0, False)
+    assert abs(bench.modelled_peak_bytes(16, *_LLAMA_1B, _TOK_CONTRASTIVE) / _GIB - 198) < 15
+    assert bench.plan_free_blocks(usable, *_LLAMA_8B, _TOK_CONTRASTIVE) == 0
+    assert bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE) == (32, False)
+    # the calibration point: state + two kept input tensors per block + the block in flight (profiles/r05_cfg5_memory_summary.txt)
+    assert abs(bench.modelled_peak_bytes(0, *_LLAMA_8B, _TOK_CONTRASTIVE) / _GIB - 253.4) < 2.0
+    assert abs(bench.optimizer_state_bytes(_LLAMA_8B[0], 2, 1, False) / _GIB - 111.8) < 0.2
+    # 8 ranks: `auto` partitions the optimizer state exactly because the replicated state forces checkpointing, and gives the
+    # freed 70 GiB back to activations
+    ckpt, part = bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="auto")
+    assert part is True and ckpt == 28
+    assert bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="off") == (32, False)
+    assert bench.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="auto") == (0, False)
+    # a card with less room (another tenant, RCCL buffers): fewer free blocks, never a negative count; monotone in the room
+    last = -1
+    for room in (40, 120, 180, 230, 287.2, 400):
+        f = bench.plan_free_blocks(int(room * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE)
+        assert 0 <= f <= 16 and f >= last
+        last = f
+    assert bench.plan_free_blocks(int(40 * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE) == 0
+    # encoders without per-block control: all or nothing
+    assert bench.plan_checkpointing(int(100 * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE, per_block_control=False) == (-1, False)
+    assert bench.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, per_block_control=False) == (0, False)
+    # a --share-gpu rehearsal splits the card between its ranks
+    assert bench.usable_hbm(200 * _GIB, 10 * _GIB, 288 * _GIB, 4) == (210 * _GIB) // 4
+    assert bench.usable_hbm(280 * _GIB, 20 * _GIB, 288 * _GIB) == 288 * _GIB
+
+
+def test_memory_guard_retry_and_transposed_buffer_decisions():
+    """The corrections that follow the MEASURED worst-case step: "tight" means out of memory or above 94 % of the usable HBM, the
+    answer is a quarter more of the blocks until none is left; the 11 GiB transposed d(gate|up) buffer of the Llama-3-8B shape is
+    refused on one GPU (253.4 GiB measured: the round-4 OOM) and admitted where twice its size still leaves 10 % free; an
+    out-of-memory error may be answered by a retry only when the process is alone."""
+    import bench
+    usable = int(287.2 * _GIB)
+    assert bench.presize_is_tight(int(253.4 * _GIB), usable) is False          # cfg 5, N = 1: 88 %
+    assert bench.presize_is_tight(int(271 * _GIB), usable) is True
+    assert bench.presize_is_tight(0, usable, oom=True) is True
+    assert [bench.checkpoint_more(c, 32) for c in (0, 8, 22, 28, 31, 32)] == [8, 16, 30, 32, 32, None]
+    assert bench.checkpoint_more(0, 2) == 1 and bench.checkpoint_more(16, 16) is None
+    need8 = bench.transposed_dgu_bytes(14336, _TOK_CONTRASTIVE, 2)
+    need1 = bench.transposed_dgu_bytes(8192, _TOK_CONTRASTIVE, 2)
+    lim = 6 * _GIB
+    assert abs(need8 / _GIB - 11.05) < 0.05 and abs(need1 / _GIB - 6.31) < 0.05
+    assert bench.admit_transposed_dgu(int(253.4 * _GIB), need8, usable, lim) is False      # cfg 5 on one GPU
+    assert bench.admit_transposed_dgu(int(198 * _GIB), need1, usable, lim) is True         # cfg 2's full-length batch
+    assert bench.admit_transposed_dgu(int(100 * _GIB), 5 * _GIB, usable, lim) is None      # within ops' static default: no decision
+    # 8 ranks, state partitioned: what the plan's own peak model says for the free-block count it chose, and for one block fewer
+    # (the measured peak decides at run time; on every rank the same way: the verdict is all-reduced)
+    for free, expect in ((4, False), (3, True)):
+        peak = bench.modelled_peak_bytes(free, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, partitioned=True)
+        assert bench.admit_transposed_dgu(int(peak), need8, usable, lim) is expect
+    assert bench.may_retry_after_oom(1) is True and bench.may_retry_after_oom(2) is False
+
+
+def test_train_step_abort_leaves_a_clean_reducer(monkeypatch):
+    """bench.py answers an out-of-memory error of the single-rank pre-size step by checkpointing more blocks and stepping again;
+    the failed step must leave no armed reducer, no pending bucket and no stale gradient (advisor, round 4)."""
+    from rankpo_amd.train_step import FlatAdamW, TrainStep
+    monkeypatch.setattr(FlatAdamW, "_sumsq", FlatAdamW._sumsq)        # restored after the test: the stand-ins below are class-wide
+    monkeypatch.setattr(FlatAdamW, "_adamw", FlatAdamW._adamw)
+    _cpu_optimizer_kernels(FlatAdamW)
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    boom = {"on": True}
+
+    def loss_fn(b):
+        y = net(b).pow(2).mean()
+        if boom["on"]:
+            y.backward()                                   # half a step's gradients are in the flat buffer ...
+            raise torch.OutOfMemoryError("synthetic")       # ... when the step dies
+        return y
+    ts = TrainStep(net.parameters(), loss_fn, lr=1e-2, total_steps=4, warmup_ratio=0.0)
+    x = torch.randn(4, 6)
+    with pytest.raises(torch.OutOfMemoryError):
+        ts.step([x])
+    r = ts.opt.reducer
+    assert r.flat.abs().sum() > 0
+    ts.abort_step()
+    assert r.flat.abs().sum() == 0 and not r._armed and not r._works and sum(r._pending) == 0
+    lo = r.flat.data_ptr()
+    assert all(lo <= p.grad.data_ptr() < lo + r.flat.numel() * r.flat.element_size() for p in net.parameters())
+    boom["on"] = False
+    before = [p.detach().clone() for p in net.parameters()]
+    ts.step([x])
+    ref = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.Tanh(), torch.nn.Linear(5, 3))
+    for p, b in zip(ref.parameters(), before):
+        p.data.copy_(b)
+    ts2 = TrainStep(ref.parameters(), lambda b: ref(b).pow(2).mean(), lr=1e-2, total_steps=4, warmup_ratio=0.0)
+    ts2.step([x])
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.equal(a, b)                           # the retried step = a first step: nothing of the failed one leaked
