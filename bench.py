@@ -433,6 +433,8 @@ def _sweep_backward(lib, q, p, scores, lse, temperature, fwd_ms, st):
     if not rel <= 2.0 ** -6:
         raise SystemExit(f"roofline sweep: the two arms of the scoring backward disagree at Q = P = {Q}, d = {d}: {rel:.3e}")
     arm = ops.INFONCE_BWD_GEMM
+    if arm == "auto":
+        arm = "hip" if min(Q, P) >= ops.INFONCE_BWD_HIP_MIN_K else "blaslt"
     fl = 2.0 * Q * P * d
     tot = fwd_ms + times[arm]
     return {"bwd_ms_hip": round(times["hip"], 4), "bwd_ms_blaslt": round(times["blaslt"], 4), "bwd_arm": arm,

@@ -769,285 +769,10 @@ __global__ __launch_bounds__(64 * WQ * HEADS, WQ * HEADS == 4 ? 2 : 1) void fa_f
     }
 }
 
-// The same forward as a SOFTWARE PIPELINE inside the wave (round 5): S^T of key tile kt + 1 is issued BEFORE the softmax of tile kt,
-// so that the matrix pipe works through those 16 MFMAs while the vector unit does tile kt's row maximum, exp2 and packing, instead
-// of waiting for them (in the loop above a wave's stream is S-MFMAs -> [pipe idle] softmax -> PV-MFMAs; the ablations put the
-// softmax at 27 % of the kernel).  Same arithmetic in the same order on every element: bit-identical to fa_fwd128_kernel.
-// Costs: 16 more registers (two generations of scores), a ring of FOUR (K | V) tiles (tile kt's V and tile kt + 1's K are read in the
-// same iteration, two more tiles are in flight), one barrier per 32 keys as before.
-template <int WQ, int HEADS>
-__global__ __launch_bounds__(64 * WQ * HEADS, WQ * HEADS == 4 ? 2 : 1) void fa_fwd128p_kernel(
-    const bf16_t* q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
-    int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
-    float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
-    int64_t lse_head_stride, int lse_packed, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod,
-    bf16_t* q_rw) {
-    constexpr int WAVES = WQ * HEADS;
-    constexpr int BM = 32 * WQ;
-    constexpr int BN = kFa128BN;
-    constexpr int kTile = 2 * BN * kFa128Row;            // (K tile | V tile), 16 KiB
-    constexpr int kVOff = BN * kFa128Row;
-    constexpr int PPW = (BN / 4) / WAVES;                // 1-KiB DMA pieces per operand and wave
-    constexpr int RING = 4;
-    static_assert(PPW >= 1 && PPW * WAVES * 4 == BN, "the waves split a tile's rows evenly");
-    __shared__ __attribute__((aligned(16))) char smem[RING * kTile];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, fr = lane & 15;
-    const FaTile ft = fa_tile(tiles, tcols);
-    if (ft.q0 >= (1 << 30)) return;
-    const int seq = ft.seq, q0 = ft.q0;
-    const int h_first = tcols == 3 ? ft.h : ft.h * HEADS;
-    const int h = h_first + wave / WQ, hk = h_first / (nh / nkv);
-    const int64_t t0 = cu[seq];
-    const int len = cu[seq + 1] - (int)t0;
-    const int qw = q0 + 32 * (wave % WQ);
-
-    short8_t bq[2][4];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int qi = qw + 16 * n + fr;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (qi < len) bq[n][ks] = *reinterpret_cast<const short8_t*>(q + (t0 + qi) * sq + h * kFa128HD + 32 * ks + 8 * g);
-            else bq[n][ks] = short8_t{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-    }
-    const int last_q = min(q0 + BM - 1, len - 1);
-    const int nkt = last_q / BN + 1;                                    // key tiles the BLOCK walks (barriers, staging)
-    const int na = qw < len ? min(nkt, (qw + 31) / BN + 1) : 0;         // ... of which this wave computes the first na
-    const int srow = lane >> 4;
-    const char* ksrc = reinterpret_cast<const char*>(k + t0 * sk + hk * kFa128HD);
-    const char* vsrc = reinterpret_cast<const char*>(v + t0 * sv + hk * kFa128HD);
-    const unsigned skb = (unsigned)sk * 2u, svb = (unsigned)sv * 2u;
-    auto stage = [&](int kt, int buf) {
-        char* base = smem + buf * kTile;
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int u = PPW * wave + i;
-            const int trow = 4 * u + srow;
-            const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
-            const unsigned row = (unsigned)min(kt * BN + trow, len - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + (row * skb + lchunk * 16)),
-                                             (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + (row * svb + lchunk * 16)),
-                                             (__attribute__((address_space(3))) void*)(base + kVOff + u * 1024), 16, 0, 0);
-        }
-    };
-    stage(0, 0);
-    if (nkt > 1) stage(1, 1);
-    if (nkt > 2) stage(2, 2);
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(bq[n][ks]));
-    if (rcos) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int qi = qw + 16 * n + fr;
-            if (qi >= len) continue;
-            const int64_t tr = ((t0 + qi) % rperiod) * (kFa128HD / 2) + 8 * g;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                rope_frag(bq[n][ks], bq[n][ks + 2], *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks),
-                          *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks + 4),
-                          *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks),
-                          *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks + 4));
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                *reinterpret_cast<short8_t*>(q_rw + (t0 + qi) * sq + h * kFa128HD + 32 * ks + 8 * g) = bq[n][ks];
-        }
-    }
-
-    float4_t oacc[8][2];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-#pragma unroll
-        for (int n = 0; n < 2; ++n) oacc[c][n] = float4_t{0.f, 0.f, 0.f, 0.f};
-    float mrun[2] = {-1e30f, -1e30f};
-    float4_t lacc[2] = {float4_t{0.f, 0.f, 0.f, 0.f}, float4_t{0.f, 0.f, 0.f, 0.f}};
-    short8_t ones;
-    {
-        typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_;
-        u32x4_ w;
-        asm volatile("v_mov_b32 %0, 0x3f803f80\n\tv_mov_b32 %1, 0x3f803f80\n\tv_mov_b32 %2, 0x3f803f80\n\tv_mov_b32 %3, 0x3f803f80"
-                     : "=v"(w[0]), "=v"(w[1]), "=v"(w[2]), "=v"(w[3]));
-        ones = __builtin_bit_cast(short8_t, w);
-    }
-    const int qq = fr >> 2, pp = fr & 3;
-    const int vsw = 2 * (4 * (g & 1) + qq);
-    unsigned tr_off[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        tr_off[c] = kVOff + (4 * g + qq) * kFa128Row + (((2 * c + (pp >> 1)) ^ vsw) << 4) + 8 * (pp & 1);
-    unsigned row_off[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) row_off[ks] = fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
-    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-
-    // S^T of key tile `kt` from ring buffer `buf`, causal / length mask applied: 16 MFMAs
-    auto scores = [&](int kt, int buf, float4_t (&s)[2][2]) {
-        const char* Ks = smem + buf * kTile;
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) s[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const short8_t a = *reinterpret_cast<const short8_t*>(Ks + row_off[ks] + m * 16 * kFa128Row);
-#pragma unroll
-                for (int n = 0; n < 2; ++n) s[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, bq[n][ks], s[m][n], 0, 0, 0);
-            }
-        }
-    };
-    auto mask = [&](int kt, float4_t (&s)[2][2]) {
-        const int k0 = kt * BN;
-        if ((k0 + BN - 1 > qw) || (k0 + BN > len)) {
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int qi = qw + 16 * n + fr;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int key = k0 + 4 * g + 16 * m + r;
-                        if (key > qi || key >= len) s[m][n][r] = -1e30f;
-                    }
-            }
-        }
-    };
-
-    // tile 0's scores before the loop (tile 0 and 1 landed: one more stage may fly)
-    if (nkt > 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    float4_t snext[2][2];
-    if (na > 0) scores(0, 0, snext);
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt + 1 has landed (the newest stage, kt + 2, may still fly); behind the barrier nobody reads tile kt - 1 any more:
-        // its buffer takes tile kt + 3
-        if (kt > 0) {
-            if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPW) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        if (kt + 3 < nkt) stage(kt + 3, (cur + 3) & 3);
-        if (kt < na) {
-            const unsigned tb = smem_base + cur * kTile;
-            u32x2 x0, x1, x2, x3, x4, x5, x6, x7, y0, y1, y2, y3, y4, y5, y6, y7;
-#define RPO_TR2V(OUT0, OUT1, ADDR)                                                                              \
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:4096" : "=&v"(OUT0), "=&v"(OUT1) : "v"(ADDR) : "memory")
-            RPO_TR2V(x0, y0, tb + tr_off[0]);
-            RPO_TR2V(x1, y1, tb + tr_off[1]);
-            RPO_TR2V(x2, y2, tb + tr_off[2]);
-            RPO_TR2V(x3, y3, tb + tr_off[3]);
-            RPO_TR2V(x4, y4, tb + tr_off[4]);
-            RPO_TR2V(x5, y5, tb + tr_off[5]);
-            RPO_TR2V(x6, y6, tb + tr_off[6]);
-            RPO_TR2V(x7, y7, tb + tr_off[7]);
-#undef RPO_TR2V
-            float4_t s[2][2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) s[m][n] = snext[m][n];
-            mask(kt, s);
-            float mnew[2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                float mm = max3_known(s[0][n][0], s[0][n][1], s[0][n][2]);
-                mm = max3_known(mm, s[0][n][3], s[1][n][0]);
-                mm = max3_known(mm, s[1][n][1], s[1][n][2]);
-                mm = max2_known(mm, s[1][n][3]);
-                mm = max_xor32_and(max_xor16(mm), mrun[n]);
-                mnew[n] = mm;
-            }
-            if (__builtin_amdgcn_ballot_w64(mnew[0] != mrun[0] || mnew[1] != mrun[1]) != 0) {
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    const float alpha = __builtin_amdgcn_exp2f((mrun[n] - mnew[n]) * scale_log2e);
-                    lacc[n] *= alpha;
-                    mrun[n] = mnew[n];
-#pragma unroll
-                    for (int c = 0; c < 8; ++c) oacc[c][n] *= alpha;
-                }
-            }
-            // The next tile's S^T chains and THIS tile's exponentials in ONE instruction stream, one MFMA : one fma + one exp2 (the
-            // matrix pipe takes an MFMA for 16 cycles and its issue for 8; the fma + exp2 of one score fill the other 8-12): computed
-            // unconditionally -- past the wave's last tile the chains read whatever the ring holds and their result is never used
-            // (a branch around them would put MFMAs and vector work into different basic blocks, where hipcc keeps them apart).
-            const char* Kn = smem + ((cur + 1) & 3) * kTile;
-            const float mls0 = mnew[0] * scale_log2e, mls1 = mnew[1] * scale_log2e;
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int n = 0; n < 2; ++n) snext[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const short8_t a0 = *reinterpret_cast<const short8_t*>(Kn + row_off[ks]);
-                const short8_t a1 = *reinterpret_cast<const short8_t*>(Kn + row_off[ks] + 16 * kFa128Row);
-                snext[0][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq[0][ks], snext[0][0], 0, 0, 0);
-                s[0][0][ks] = __builtin_amdgcn_exp2f(fmaf(s[0][0][ks], scale_log2e, -mls0));
-                snext[0][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0, bq[1][ks], snext[0][1], 0, 0, 0);
-                s[0][1][ks] = __builtin_amdgcn_exp2f(fmaf(s[0][1][ks], scale_log2e, -mls1));
-                snext[1][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq[0][ks], snext[1][0], 0, 0, 0);
-                s[1][0][ks] = __builtin_amdgcn_exp2f(fmaf(s[1][0][ks], scale_log2e, -mls0));
-                snext[1][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1, bq[1][ks], snext[1][1], 0, 0, 0);
-                s[1][1][ks] = __builtin_amdgcn_exp2f(fmaf(s[1][1][ks], scale_log2e, -mls1));
-            }
-            // pin the order the source spells out: LDS reads of a k-step, then (MFMA, fma, exp2) x 4
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x400, 1, 0);
-                }
-            }
-            short8_t pfrag[2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n) pfrag[n] = pack_frag(s[0][n], s[1][n]);
-            asm volatile("s_waitcnt lgkmcnt(0)"
-                         : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7), "+v"(y0),
-                           "+v"(y1), "+v"(y2), "+v"(y3), "+v"(y4), "+v"(y5), "+v"(y6), "+v"(y7)
-                         :
-                         : "memory");
-            const short8_t vt[8] = {join_tr(x0, y0), join_tr(x1, y1), join_tr(x2, y2), join_tr(x3, y3),
-                                    join_tr(x4, y4), join_tr(x5, y5), join_tr(x6, y6), join_tr(x7, y7)};
-#pragma unroll
-            for (int c = 0; c < 8; ++c)
-#pragma unroll
-                for (int n = 0; n < 2; ++n)
-                    oacc[c][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[c], pfrag[n], oacc[c][n], 0, 0, 0);
-#pragma unroll
-            for (int n = 0; n < 2; ++n) lacc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pfrag[n], lacc[n], 0, 0, 0);
-        }
-        cur = (cur + 1) & 3;
-    }
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const int qi = qw + 16 * n + fr;
-        if (qi >= len) continue;
-        const float l = lacc[n][0];
-        const float inv = 1.0f / l;
-        bf16_t* orow = o + (t0 + qi) * so + h * kFa128HD;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            uint2 w;
-            w.x = pack_bf16(oacc[c][n][0] * inv, oacc[c][n][1] * inv);
-            w.y = pack_bf16(oacc[c][n][2] * inv, oacc[c][n][3] * inv);
-            *reinterpret_cast<uint2*>(orow + 16 * c + 4 * g) = w;
-        }
-        if (g == 0)
-            lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
-                mrun[n] * scale + logf(l);
-    }
-}
+// (Round 5 also built this forward as a software pipeline inside the wave -- S^T of key tile kt + 1 issued before the softmax of tile
+// kt, ring of four tiles, chains and exponentials in one basic block under sched_group_barrier -- bit-identical, and 0.4-1.7 % SLOWER
+// in same-process A/Bs: with two waves per SIMD the partner wave already fills what the pipeline would; commit 1bc251a holds the
+// kernel, profiles/r05_fa_fwd128_ablation.txt the numbers.)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Backward.  Two launches, no atomics, deterministic:
@@ -4205,11 +3930,7 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
 #define RPO_F128_KF false
 #endif
     if (head_dim == kFa128HD && tile_cols != 3) grid.y = (unsigned)(num_heads / RPO_F128_HEADS);
-#ifdef RPO_F128_PIPE
-#define RPO_F128_KERNEL fa_fwd128p_kernel<RPO_F128_WQ, RPO_F128_HEADS>
-#else
 #define RPO_F128_KERNEL fa_fwd128_kernel<RPO_F128_WQ, RPO_F128_HEADS, RPO_F128_SUB, RPO_F128_KF>
-#endif
     if (head_dim == kFa128HD)
         RPO_LAUNCH((RPO_F128_KERNEL), grid, dim3(64 * RPO_F128_WQ * RPO_F128_HEADS), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
                    k_stride, v_stride, cu_seqlens, tiles, (int)tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,

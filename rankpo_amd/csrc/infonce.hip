@@ -17,6 +17,7 @@
 // Backward: dS = grad * (softmax(S) - onehot) / (Q T) is recomputed from the stored scores and lse;
 //   dq = dS p (own q rows), dp = dS^T q (own p rows).
 #include "common.hpp"
+#include <algorithm>
 #include <atomic>
 #include <cstdlib>
 
@@ -309,6 +310,7 @@ constexpr int kBigTile = 256, kBigThreads = 512, kBigUnitBytes = 128 * kTileRowB
 constexpr int kBigBufBytes = 4 * kBigUnitBytes;                                         // 64 KiB per buffer
 constexpr int kBigStageRowBytes = 272, kBigStageWaveBytes = 64 * kBigStageRowBytes;     // epilogue score staging
 constexpr int kBigLdsBytes = 8 * kBigStageWaveBytes + 4 * 64 * 8;                       // 141,312 B >= 2 buffers
+constexpr int64_t kBigPersistBlocks = 256;                                              // one per CU (a multiple of 8: XCD affinity)
 
 // tile row (0..255) of unit-local row u (0..127)
 __device__ __forceinline__ int big_unit_row(int unit, int u) {
@@ -320,6 +322,14 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
     }
 }
 
+// PERSISTENT since round 5 (DESIGN.md section 8.3 named it in round 2): one block per CU walks its tiles (launched with one block
+// per TILE it is the kernel of rounds 1-4: `have_next` is never true; that launch is the A/B arm, -DRPO_SIM_PERSIST=0).
+// What it buys: the 8 LDS-DMA instructions of a tile's first K-step are issued BEFORE the previous tile's epilogue (its address
+// arithmetic, the 1-2 us flight of the first units and the block relaunch hide under ~1500 vector instructions of epilogue), and the
+// score stores of tile i drain under the first K-step of tile i + 1: that K-step's counted waits are widened by the 16 store
+// instructions a wave issued behind the DMAs (CDNA4's vmcnt counts stores too) -- which is why the interior epilogue's stores
+// are asm here (an exact count), and why an edge tile, whose store count varies, ends in a full drain.  The epilogue stages through
+// the ring's SECOND buffer only (16 rows per wave at a time), so that the first buffer can take the next tile meanwhile.
 // EPI = 0: the scoring forward (scores = <q, p> / T with the reference's two bf16 roundings, per-tile softmax partials).
 // EPI = 1 (round 5): the same frame as a plain NT GEMM, C[Q, P] = q[Q, K] p[P, K]^T rounded to bf16 once -- the two products of the
 // scoring BACKWARD at sweep sizes, dq = dS p_all and dp = dS^T q_all, with the reduction operand transposed beforehand so that
@@ -341,60 +351,81 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     const int g = lane >> 4, frow = lane & 15;
 
     const int nwg = nPt * nQt;
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, q8 = nwg >> 3, r8 = nwg & 7;
-    const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
-    constexpr int GROUP = 4;
-    const int width = GROUP * nQt;
-    const int group_id = wg / width;
-    const int first_p = group_id * GROUP;
-    const int gsz = min(nPt - first_p, GROUP);
-    const int pt = first_p + (wg % width) % gsz;
-    const int qt = (wg % width) / gsz;
-    const int64_t p0 = (int64_t)pt * kBigTile, q0 = (int64_t)qt * kBigTile;
+    // virtual block vb -> tile: the one-tile kernel's XCD-aware order (blocks that share an XCD walk neighbouring tiles); this block
+    // takes vb = blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8: all of them on this block's XCD)
+    auto tile_of = [&](int vb, int64_t& p0_, int64_t& q0_, int& pt_) {
+        const int xcd = vb & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (vb >> 3);
+        constexpr int GROUP = 4;
+        const int width = GROUP * nQt;
+        const int first_p = (wg / width) * GROUP;
+        const int gsz = min(nPt - first_p, GROUP);
+        pt_ = first_p + (wg % width) % gsz;
+        p0_ = (int64_t)pt_ * kBigTile;
+        q0_ = (int64_t)((wg % width) / gsz) * kBigTile;
+    };
+    int64_t p0, q0;
+    int pt;
+    tile_of((int)blockIdx.x, p0, q0, pt);
 
     // staging: a unit is 16 DMA pieces of 1 KiB (8 rows); wave w issues pieces w and 8 + w of every unit.
     const int srow = lane >> 3;
     const int lchunk = (lane & 7) ^ srow;
-    const bf16_t* src[4][2];
+    // per-lane BYTE OFFSETS of this wave's 8 pieces from the two operand bases (32 bits each: the host admits operands below 4 GB);
+    // pointers would be 16 registers that have to live through the previous tile's epilogue, where the pressure peaks
+    unsigned soff[4][2];
+    auto set_src = [&](int64_t p0_, int64_t q0_) {
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int ur = (8 * j + wave) * 8 + srow;           // unit-local row
-            const int tr = big_unit_row(u, ur);                 // tile row
-            const bool isA = (u == 0 || u == 3);
-            const int64_t gr = isA ? min(p0 + tr, P - 1) : min(q0 + tr, Q - 1);
-            src[u][j] = (isA ? p : q) + gr * (isA ? lda : ldb) + lchunk * 8;
-        }
+            for (int j = 0; j < 2; ++j) {
+                const int ur = (8 * j + wave) * 8 + srow;           // unit-local row
+                const int tr = big_unit_row(u, ur);                 // tile row
+                const bool isA = (u == 0 || u == 3);
+                const int64_t gr = isA ? min(p0_ + tr, P - 1) : min(q0_ + tr, Q - 1);
+                soff[u][j] = (unsigned)((gr * (isA ? lda : ldb) + lchunk * 8) * 2);
+            }
+    };
+    set_src(p0, q0);
 #define RPO_BIG_STAGE(U, T, BUF)                                                                                   \
     do {                                                                                                           \
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                         \
             char* dst_ = smem + (BUF) * kBigBufBytes + (U) * kBigUnitBytes + (8 * j_ + wave) * 1024;               \
+            const char* base_ = reinterpret_cast<const char*>(((U) == 0 || (U) == 3) ? p : q);                     \
             __builtin_amdgcn_global_load_lds(                                                                      \
-                (const __attribute__((address_space(1))) void*)(src[U][j_] + (int64_t)(T) * KE),                   \
+                (const __attribute__((address_space(1))) void*)(base_ + (soff[U][j_] + (unsigned)(T) * (KE * 2))), \
                 (__attribute__((address_space(3))) void*)dst_, 16, 0, 0);                                          \
         }                                                                                                          \
     } while (0)
-
-    float4_t acc[8][4];
-#pragma unroll
-    for (int m = 0; m < 8; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = (int)(d / KE);
     // per-lane read offsets inside a unit (row part); the chunk part depends on the k-step
     const int a_off = (wp * 64 + frow) * kTileRowBytes;         // + m*16 rows, units 0 / 3
     const int b_off = (wq * 32 + frow) * kTileRowBytes;         // + n*16 rows, units 1 / 2
     const int c0 = ((0 * 4 + g) ^ (lane & 7)) << 4, c1 = ((1 * 4 + g) ^ (lane & 7)) << 4;
+    const float inv_t = 1.0f / temperature;
+    const bool vec_ok = (ldc % 4 == 0) && rpo_aligned16_dev(scores);
+    const bool staged = (ldc % 8 == 0) && rpo_aligned16_dev(scores) && !(dbg & 2);
+    // epilogue staging: 16 query rows x 128 passages of bf16 per wave at a time, in the ring's SECOND buffer
+    char* wstage = smem + kBigBufBytes + wave * (16 * kBigStageRowBytes);
+    float2* s_stat = reinterpret_cast<float2*>(smem + 8 * kBigStageWaveBytes);   // [wq][64] from the wp == 1 waves
 
     RPO_BIG_STAGE(0, 0, 0);
     RPO_BIG_STAGE(1, 0, 0);
     RPO_BIG_STAGE(2, 0, 0);
     RPO_BIG_STAGE(3, 0, 0);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");            // units 0, 1 of K-step 0 have landed (this wave's pieces)
-    __builtin_amdgcn_s_barrier();
+    bool carry = false;      // 16 score stores of the previous tile were issued BEHIND this tile's first DMAs and may still fly
+    for (int vb = (int)blockIdx.x; vb < nwg; vb += (int)gridDim.x) {
+    float4_t acc[8][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = float4_t{0.f, 0.f, 0.f, 0.f};
+    // units 0, 1 of K-step 0 have landed (this wave's pieces): all but units 2, 3 (4 instructions) and the carried stores
+    if (carry) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();      // ... everybody's; and every wave is through the previous tile's epilogue (its LDS staging area
+                                       // lies in the buffer K-step 0 stages K-step 1 into)
 
     // Two barriers per phase (load part | MFMA part) and the two wave groups offset by ONE barrier: while waves 0-3
     // (wp = 0) run their 16 MFMAs, waves 4-7 -- their SIMD partners -- issue ds_reads / LDS-DMA, and vice versa, so
@@ -419,7 +450,8 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         }
         if (more) {
             RPO_BIG_STAGE(0, t + 1, nxt);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // retires unit 2 of this K-step (read in phase 1)
+            if (carry && t == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");   // (+ the 16 stores between the tile's first DMAs and these)
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // retires unit 2 of this K-step (read in phase 1)
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -442,7 +474,8 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         }
         if (more) {
             RPO_BIG_STAGE(1, t + 1, nxt);
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // retires unit 3 of this K-step (read in phase 2)
+            if (carry && t == 0) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // retires unit 3 of this K-step (read in phase 2)
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_s_setprio(1);
@@ -490,23 +523,29 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
-#undef RPO_BIG_STAGE
     if (stagger && wp == 0) __builtin_amdgcn_s_barrier();
-    __syncthreads();   // every wave is done with LDS before it is reused for the statistics exchange
+    __syncthreads();   // every wave is done with the ring: the second buffer becomes the epilogue's staging area, the first one
+                       // takes the next tile's first K-step NOW (its units fly under the epilogue)
+    const int64_t p0e = p0, q0e = q0;      // this tile's origin, for the epilogue
+    const int pte = pt;
+    const bool have_next = vb + (int)gridDim.x < nwg;
+    if (have_next) {
+        tile_of(vb + (int)gridDim.x, p0, q0, pt);
+        set_src(p0, q0);
+        RPO_BIG_STAGE(0, 0, 0);
+        RPO_BIG_STAGE(1, 0, 0);
+        RPO_BIG_STAGE(2, 0, 0);
+        RPO_BIG_STAGE(3, 0, 0);
+    }
 
     // ---- epilogue: acc[m][n][j] = <p_{pbase + 16m + j}, q_{qbase + 16n}>
-    const int64_t pbase = p0 + wp * 128 + g * 4;
-    const int64_t qbase = q0 + wq * 64 + frow;
-    const bool vec_ok = (ldc % 4 == 0) && rpo_aligned16_dev(scores);
-    const float inv_t = 1.0f / temperature;
+    const int64_t pbase = p0e + wp * 128 + g * 4;
+    const int64_t qbase = q0e + wq * 64 + frow;
     // Scores leave through LDS: each wave parks its 64 (q) x 128 (p) bf16 sub-tile in its own 64 x 272-byte image
     // (8-byte ds_writes of 4 consecutive p) and streams it out as whole 256-byte row segments with 16-byte stores,
     // instead of 8-byte stores that touch a quarter of a 128-byte line each (measured: the direct stores cost 14 %
     // of the kernel at Q = P = 16384).
-    const bool staged = (ldc % 8 == 0) && rpo_aligned16_dev(scores) && !(dbg & 2);
-    const bool interior = staged && p0 + kBigTile <= P && q0 + kBigTile <= Q;
-    char* wstage = smem + wave * kBigStageWaveBytes;
-    float2* s_stat = reinterpret_cast<float2*>(smem + 8 * kBigStageWaveBytes);   // [wq][64] from the wp == 1 waves
+    const bool interior = staged && p0e + kBigTile <= P && q0e + kBigTile <= Q;
 #pragma unroll
     for (int n = 0; n < 4; ++n) {
         const int64_t qi = qbase + 16 * n;
@@ -520,7 +559,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                 uint2 w;
                 w.x = pack2_bf16(acc[m][n][0], acc[m][n][1]);
                 w.y = pack2_bf16(acc[m][n][2], acc[m][n][3]);
-                *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
+                *reinterpret_cast<uint2*>(wstage + frow * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
             }
         } else if (interior) {
             // interior tile (no row or column outside the matrix): no bounds tests, both roundings as packed conversions
@@ -547,7 +586,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                     x[2] = __uint_as_float(w.y << 16);
                     x[3] = __uint_as_float(w.y & 0xffff0000u);
                 }
-                *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
+                *reinterpret_cast<uint2*>(wstage + frow * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[m][n][j] = x[j];
                 mx = max3_raw(max3_raw(mx, x[0], x[1]), x[2], x[3]);
@@ -573,7 +612,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                     uint2 w;
                     w.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
                     w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(wstage + (16 * n + frow) * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
+                    *reinterpret_cast<uint2*>(wstage + frow * kBigStageRowBytes + (16 * m + 4 * g) * 2) = w;
                 } else if (qv && !(dbg & 1)) {
                     store_scores4<bf16_t>(scores + qi * ldc, pbase + 16 * m, P, v, vec_ok);
                 }
@@ -598,13 +637,17 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         }
         if (staged && !(dbg & 1)) {
             // stream this quarter (16 query rows) out now: its stores drain while the next quarter is being computed
-            const int64_t prow0 = p0 + wp * 128 + (lane & 15) * 8;          // first of this lane's 8 passage columns
+            const int64_t prow0 = p0e + wp * 128 + (lane & 15) * 8;         // first of this lane's 8 passage columns
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int r = 16 * n + 4 * i + (lane >> 4);
-                const int64_t qi = q0 + wq * 64 + r;
-                const uint4_t w = *reinterpret_cast<const uint4_t*>(wstage + r * kBigStageRowBytes + (lane & 15) * 16);
-                if (qi < Q) {
+                const int64_t qi = q0e + wq * 64 + r;
+                const uint4_t w = *reinterpret_cast<const uint4_t*>(wstage + (r & 15) * kBigStageRowBytes + (lane & 15) * 16);
+                if (interior) {
+                    // exactly ONE store instruction per (n, i) and wave: the next tile's first K-step counts them in its waits
+                    bf16_t* dst = scores + qi * ldc + prow0;
+                    asm volatile("global_store_dwordx4 %0, %1, off nt\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+                } else if (qi < Q) {
                     bf16_t* dst = scores + qi * ldc + prow0;
                     if (prow0 + 7 < P) {
                         if (dbg & 4) *reinterpret_cast<uint4_t*>(dst) = w;
@@ -627,11 +670,18 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
                 float mx = acc[0][n][0], sum = acc[0][n][1];
                 const float2 o = s_stat[wq * 64 + 16 * n + frow];
                 softmax_merge(mx, sum, o.x, o.y);
-                if (qi < Q) partial[(int64_t)pt * Q + qi] = make_float2(mx, sum);
+                if (qi < Q) partial[(int64_t)pte * Q + qi] = make_float2(mx, sum);
             }
         }
     }
+    // an edge tile's stores are not counted (their number depends on the bounds): drain them, and with them the next tile's first
+    // units, before the next tile starts; an interior tile leaves its 16 stores in flight
+    carry = have_next && interior && !(dbg & 1);
+    if (have_next && !carry) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#undef RPO_BIG_STAGE
 }
+
 
 // ------------------------------------------------------------------------------------------------
 // Skinny kernel: Q <= 64 (every shape the reference scripts produce: 8 x 48 ... 64 x 384).
@@ -1262,8 +1312,8 @@ static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) 
         }
     } else {
         // the 256 x 256 kernel runs one block per CU: take it only when its grid can fill most of the 256 CUs
-        const bool big = dtype == RPO_DT_BF16 &&
-                         rpo_cdiv(P, kBigTile) * rpo_cdiv(Q, kBigTile) >= 192;
+        const bool big = dtype == RPO_DT_BF16 && rpo_cdiv(P, kBigTile) * rpo_cdiv(Q, kBigTile) >= 192 &&
+                         P * d * 2 < ((int64_t)1 << 32) && Q * d * 2 < ((int64_t)1 << 32);     // 32-bit piece offsets
         pl.path = big ? PATH_TILE256 : PATH_TILE;
         pl.tp = pl.tq = big ? kBigTile : kTileP;
         if (!big) {
@@ -1345,9 +1395,13 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
                                           kBigLdsBytes);
                 attr_set256 = true;
             }
-            RPO_LAUNCH(sim_tile256_kernel<0>, dim3((unsigned)(pl.nPt * pl.nQt)), dim3(kBigThreads), kBigLdsBytes, st,
-                       (const bf16_t*)q, (const bf16_t*)p, Q, P, d, d, d, P, temperature, scale, do_stats ? 1 : 0,
-                       (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0);
+#ifndef RPO_SIM_PERSIST
+#define RPO_SIM_PERSIST 1       // 0: one block per tile (rounds 1-4), the A/B arm of profiles/r05_sim_tile256_persistent_ab.txt
+#endif
+            const int64_t ntile = (int64_t)pl.nPt * pl.nQt;
+            RPO_LAUNCH(sim_tile256_kernel<0>, dim3((unsigned)(RPO_SIM_PERSIST ? std::min<int64_t>(ntile, kBigPersistBlocks) : ntile)),
+                       dim3(kBigThreads), kBigLdsBytes, st, (const bf16_t*)q, (const bf16_t*)p, Q, P, d, d, d, P, temperature, scale,
+                       do_stats ? 1 : 0, (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0);
         }
     } else if (pl.path == PATH_SKINNY) {
         const int ng = Q <= 16 ? 4 : 1;
@@ -1547,14 +1601,16 @@ extern "C" int rpo_sim_gemm_nt(const void* a, int64_t rows_a, int64_t lda, const
         return RPO_ERR_UNSUPPORTED;
     const int64_t nPt = rpo_cdiv(rows_a, kBigTile), nQt = rpo_cdiv(rows_b, kBigTile);
     if (nPt * nQt > 0x7fffffff) return RPO_ERR_UNSUPPORTED;
+    // the kernel addresses its LDS-DMA pieces by 32-bit byte offsets from the operand bases
+    if (rows_a * lda * 2 >= ((int64_t)1 << 32) || rows_b * ldb * 2 >= ((int64_t)1 << 32)) return RPO_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
         attr_set = true;
     }
-    RPO_LAUNCH(sim_tile256_kernel<1>, dim3((unsigned)(nPt * nQt)), dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream,
-               (const bf16_t*)b, (const bf16_t*)a, rows_b, rows_a, K, lda, ldb, ldc, 1.0f, 0, 0, (bf16_t*)c, (float2*)nullptr,
-               (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0);
+    RPO_LAUNCH(sim_tile256_kernel<1>, dim3((unsigned)(RPO_SIM_PERSIST ? std::min<int64_t>(nPt * nQt, kBigPersistBlocks) : nPt * nQt)),
+               dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)b, (const bf16_t*)a, rows_b, rows_a, K, lda, ldb, ldc,
+               1.0f, 0, 0, (bf16_t*)c, (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0);
     return rpo_launch_status();
 }
 

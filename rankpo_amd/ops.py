@@ -163,8 +163,12 @@ class _InfoNCE(torch.autograd.Function):
         return dq, dp, None, None, None, None, None, None
 
 
-INFONCE_BWD_GEMM = "hip"     # "hip": the two products of the large backward on the forward's own MFMA frame (rpo_sim_gemm_nt);
-#                              "blaslt": torch.matmul -> hipBLASLt (rounds 1-4; the A/B arm, bench.py sweep reports both)
+# The two products of the large backward: "hip" = the forward's own MFMA frame (rpo_sim_gemm_nt), "blaslt" = torch.matmul ->
+# hipBLASLt (rounds 1-4), "auto" = whichever the sweep measured at least as fast (profiles/r05_sweep_fwd_bwd.md: the two meet at
+# reductions of 16384 -- 2.106 vs 2.096 ms at 16384^2 x 2048, 3.657 vs 3.640 at x 4096 -- and the library wins below, where the
+# hand-written path's five launches (dS, two transposes, two products) show: 0.252 vs 0.229 ms at 4096^2 x 4096).
+INFONCE_BWD_GEMM = "auto"
+INFONCE_BWD_HIP_MIN_K = 16384
 
 
 def sim_gemm_nt(b, a):
@@ -184,7 +188,8 @@ def _bwd_product(ds, x_all):
     first (rpo_transpose: 2 K d bytes each way, ~1 % of the product's time at sweep sizes) so that both operands are contiguous
     along the reduction, the layout of the forward kernel's LDS-DMA staging."""
     K, d = x_all.shape
-    if (INFONCE_BWD_GEMM == "hip" and ds.dtype == torch.bfloat16 and K % 64 == 0 and d % 8 == 0 and ds.stride(1) == 1
+    want_hip = INFONCE_BWD_GEMM == "hip" or (INFONCE_BWD_GEMM == "auto" and K >= INFONCE_BWD_HIP_MIN_K)
+    if (want_hip and ds.dtype == torch.bfloat16 and K % 64 == 0 and d % 8 == 0 and ds.stride(1) == 1
             and ds.stride(0) % 8 == 0 and ds.data_ptr() % 16 == 0):
         return sim_gemm_nt(ds, transpose2d(x_all))
     return ds @ x_all
