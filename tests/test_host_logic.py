@@ -538,6 +538,18 @@ def test_query_tile_table_properties():
                 assert q0s == sorted(q0s, reverse=True)
     legacy = ops.attn_tile_table([300, 5], "cpu").numpy()
     assert legacy.shape == (4, 2) and legacy[0, 1] == 256
+    # round 5: blocks of `block_m` queries x `heads_per_block` consecutive q heads of one kv head (the head_dim-128 forward's
+    # <WQ, HEADS> instantiations): every (sequence, tile, head) is covered exactly once by the blocks' head ranges
+    for block_m, hpb in ((64, 2), (128, 2), (64, 4), (256, 1)):
+        lens = [300, 64, 65, 1000]
+        t = ops.attn_tile_table(lens, "cpu", 32, 8, block_m=block_m, heads_per_block=hpb).numpy()
+        real = t[t[:, 1] < (1 << 30)]
+        assert (real[:, 2] % hpb == 0).all() and (real[:, 1] % block_m == 0).all()
+        got = sorted((s, q0, h + j) for s, q0, h in real.tolist() for j in range(hpb))
+        assert got == sorted((s, q0, h) for s, n in enumerate(lens) for q0 in range(0, n, block_m) for h in range(32))
+        assert all((h // 4) == ((h + hpb - 1) // 4) for _, _, h in real.tolist())     # a block's heads share one kv head
+    with pytest.raises(ValueError, match="heads_per_block"):
+        ops.attn_tile_table([300], "cpu", 32, 8, heads_per_block=3)
 
 
 def test_rotary_frequencies_survive_a_dtype_cast():
