@@ -469,6 +469,7 @@ def attention_standalone(timed, cfg, batch_lens, device, reps=6):
     same HIP events: what a call costs when nothing else has run since the previous call, against what it cost inside the step
     (`kernels[]`).  Rounds 2-4 quoted stand-alone rates from other boxes and other shapes (48 passages, no rotary) and read the
     difference as an in-step loss of 12 % / 7 %."""
+    import rankpo_amd.encoder
     from rankpo_amd import ops
     nh, nkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
     W = (nh + 2 * nkv) * hd
@@ -488,6 +489,7 @@ def attention_standalone(timed, cfg, batch_lens, device, reps=6):
         rope = (fr.cos().contiguous(), fr.sin().contiguous())
         cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=device)
         tiles = ops.attn_tile_table(lens, device, nh, nkv)
+        ft = ops.attn_fwd_tile_table(lens, device, nh, nkv, hd) if rankpo_amd.encoder.FWD128_ONE_WAVE else None
         kt = ops.attn_key_tile_table(lens, device, nkv, kb)      # the defaults the encoder's packed path uses
         views = lambda t: (t[:, :nh * hd].unflatten(1, (nh, hd)), t[:, nh * hd:(nh + nkv) * hd].unflatten(1, (nkv, hd)),
                            t[:, (nh + nkv) * hd:].unflatten(1, (nkv, hd)))
@@ -497,7 +499,8 @@ def attention_standalone(timed, cfg, batch_lens, device, reps=6):
         for on in (False, True):                                 # one untimed warm-up pair, then `reps` timed pairs
             timed.enabled = on
             for _ in range(reps if on else 1):
-                out, lse = ops.flash_attn_varlen_fwd(qv, kv_, vv, cu, tiles, scale, rope=rope)
+                out, lse = ops.flash_attn_varlen_fwd(qv, kv_, vv, cu, tiles if ft is None else ft, scale, rope=rope,
+                                                     q_block=128 if ft is None else 64)
                 ops.flash_attn_varlen_bwd(qv, kv_, vv, out, go, lse, cu, tiles, kt, scale, grads=views(dqkv), key_block=kb, rope=rope)
         torch.cuda.synchronize()
         del qkv, dqkv, go, out, lse
@@ -1147,6 +1150,8 @@ def main():
                     help="A/B: chunks of the token reduction for the q|k|v and o weight gradients (ops.WGRAD_SPLIT_T; 1 = one GEMM)")
     ap.add_argument("--fold-rope", type=int, default=2, choices=(0, 1, 2),
                     help="A/B: 2 = rotary folded into the attention forward (q) and backward epilogues, 1 = backward only, 0 = separate passes")
+    ap.add_argument("--fwd128", default="onewave", choices=("onewave", "classic"),
+                    help="A/B: head_dim-128 attention forward: the one-wave-per-SIMD kernel on its own 64-query x 4-head list, or the 128-query kernel of rounds 3-4")
     ap.add_argument("--lib", default=None,
                     help="A/B: another build of librankpo_hip.so (tools/exp/build_variant.sh) instead of the in-tree one, for an A/B of "
                          "kernel variants INSIDE the training step (stand-alone kernel A/Bs have ranked schedules the step did not)")
@@ -1263,6 +1268,7 @@ def main():
     if args.wgrad_split is not None:
         rankpo_amd.ops.WGRAD_SPLIT_T = args.wgrad_split
     rankpo_amd.encoder.FOLD_ROPE = args.fold_rope
+    rankpo_amd.encoder.FWD128_ONE_WAVE = args.fwd128 == "onewave"
     if args.dkdv_heaviest_first:
         rankpo_amd.ops.ATTN_SWEEP_DOWN = rankpo_amd.ops.ATTN_SWEEP_DOWN_HD128 = False
     if args.dkdv_tail is not None:

@@ -255,13 +255,18 @@ int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, c
  * rope_cos / rope_sin (both NULL, or both f32 [rope_period][hd / 2], 16-byte aligned; token t uses row t % rope_period): q
  * arrives UN-rotated and is rotated IN PLACE (q is written!) by the block that owns each (128 queries x head) piece -- the same
  * arithmetic as rpo_rope -- so that the separate rotary pass only has the k heads left; k must arrive rotated (every query
- * block reads it).  The backward entry point reads the rotated q from memory. */
+ * block reads it).  The backward entry point reads the rotated q from memory.
+ * q_block = the query rows one work-list entry stands for: 128 (0 means 128) for every head_dim, or 64 with head_dim 128 and
+ * (num_heads / num_kv_heads) % 4 == 0: an entry is then 64 queries x the FOUR consecutive q heads that begin at the entry's head
+ * (format 3: the head column, a multiple of 4; format 2: one launch block per (entry, group of 4 heads)), which share one kv head --
+ * the one-wave-per-SIMD forward (fa_fwd128w_kernel); out must be 16-byte aligned and out_stride % 8 == 0 there.  Anything else:
+ * RPO_ERR_UNSUPPORTED.  The backward's query list stays a 128-row list either way. */
 int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
                        int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles, int64_t tile_cols,
                        int64_t total_tokens,
                        int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, void* out,
                        int64_t out_stride, float* lse, int64_t lse_max_len, const float* rope_cos, const float* rope_sin,
-                       int64_t rope_period, rpo_stream_t stream);
+                       int64_t rope_period, int64_t q_block, rpo_stream_t stream);
 
 /* Backward of rpo_flash_attn_fwd, head_dim 64 or 128 (two launches: dQ, which also computes the row constants, then dK/dV; no
  * atomics, deterministic).  lse: f32 [num_heads][T] as written by the forward with lse_max_len == 0; delta: f32

@@ -64,7 +64,7 @@ SIGNATURES = {
     "rpo_add_rmsnorm_fwd": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "rpo_add_rmsnorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp]),
     "rpo_flash_attn_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp,
-                                     _i64, _vp, _i64, _vp, _vp, _i64, _vp]),
+                                     _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "rpo_flash_attn_bwd": (C.c_int, [_vp] * 5 + [_i64] * 5 + [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp, _vp,
                                      _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
     "rpo_lastq_attn_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),

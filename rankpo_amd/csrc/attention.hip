@@ -775,6 +775,332 @@ __global__ __launch_bounds__(64 * WQ * HEADS, WQ * HEADS == 4 ? 2 : 1) void fa_f
 // kernel, profiles/r05_fa_fwd128_ablation.txt the numbers.)
 
 // ------------------------------------------------------------------------------------------------------------------
+// head_dim 128, ONE WAVE PER SIMD (round 5; rpo_flash_attn_fwd's q_block = 64): block = 64 queries x the FOUR q heads of one kv head,
+// one head per wave (one staged K / V tile serves all four: half the K / V traffic per query row of a 128-query block, and every
+// wave walks the same number of key tiles).  The wave's O^T (128 registers), softmax denominators (16), Q^T fragments (64) and the K
+// fragments of the tile in flight (32) live in the accumulator file, the scores, V^T and P^T fragments in literal VGPRs; the
+// key-tile loop is two generated asm statements per 32-key tile (tools/gen/gen_fwd128w_body.py -> attention_fwd128w_gen.inc, register
+// map and pipeline in its docstring): P1 = the S^T chains of the NEXT tile with this tile's exponentials in their gaps, P2 = this
+// tile's O^T / l products with the next tile's exponents (e = c s - scale, in place) and the lane's largest e in theirs, plus the
+// wave's four LDS-DMA pieces of the tiles staged this iteration.  The stream is ISSUE-bound (a vector instruction holds the SIMD's
+// port 4 cycles, v_exp_f32 8, a 16x16x32 MFMA 8 of its 16), so the work that counts is the instruction count per tile:
+//   * the softmax scale is DEFERRED: it starts at tile 0's row maximum (statement FIRST) and moves only when some lane's exponent
+//     exceeds kFwDefer (one ballot between P2 and the next P1, then RESCALE: the cross-lane row maximum, O^T and l through VGPRs) --
+//     p <= 2^kFwDefer, no accuracy cost in floating point, but not bit-identical to the exact-maximum kernel;
+//   * no row-maximum reduction in the steady state (no lane above the threshold means no row above it);
+//   * round 5's ladder, cfg-5-like batch, stand-alone: 0.304 (first correct) -> 0.340 (no hazard padding between statements, K / V
+//     rings apart, slot immediates) -> 0.357 (64 queries x 4 heads) -> 0.365 (DMA in the stream, interleaved maxima) -> 0.415
+//     (exponent in P2, lane-only maximum, exponentials split 3 : 1 over P1 / P2 by issue cost) -> 0.436 (Q in / O out as whole rows
+//     through LDS) against 0.333-0.337 for fa_fwd128_kernel on the same boxes (profiles/r05_fa_fwd128w_ladder.md).
+// K / V: 8-KiB images (32 keys x 256 bytes, chunk ^= 2 (row & 7)) in a ring of four K tiles and a ring of four V tiles (tile j's K
+// rows are read two iterations before its V rows), one barrier per tile.  Q and O: a 16-KiB region per wave, whole 256-byte rows
+// between LDS and memory (per-lane fragment accesses at a row stride touch 16 lines of 32-64 bytes per instruction, and one wave
+// per SIMD has nobody to hide that behind).  Same fragment layouts and rotary fold as fa_fwd128_kernel.
+// ------------------------------------------------------------------------------------------------------------------
+#if defined(RPO_FW_VARIANT_INC)                      // timing experiments: the generator's output under its GEN_* switches (results may be
+#include "attention_fwd128w_gen_variant.inc"         // wrong); tools/exp/build_variant.sh writes the file into its build directory
+#else
+#include "attention_fwd128w_gen.inc"
+#endif
+#ifndef RPO_FW_EXP
+#define RPO_FW_EXP 0     // timing-only ablations: 2 no LDS-DMA staging inside the loop, 4 no barrier / ring wait
+#endif
+constexpr float kFwDefer = 8.0f;
+
+__global__ __launch_bounds__(256, 1) void fa_fwd128w_kernel(
+    const bf16_t* q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
+    int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
+    float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
+    int64_t lse_head_stride, int lse_packed, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod,
+    bf16_t* q_rw) {
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts0, ts1, ts2, ts3, ts4, ts5;
+    RPO_STAMP(ts0);
+#define RPO_FWS(VAR) RPO_STAMP(VAR)
+#define RPO_FWS_ADD(I, A, B) st_acc[I] += (B) - (A)
+#else
+#define RPO_FWS(VAR)
+#define RPO_FWS_ADD(I, A, B)
+#endif
+    constexpr int BN = kFa128BN;
+    constexpr int kImg = BN * kFa128Row;                 // one 32-key K or V tile: 8 KiB
+    constexpr int kVRing = 4 * kImg;                     // K ring: slots 0-3 at byte 0; V ring: slots 0-3 at byte 32768
+    // + a 16-KiB region per wave (64 rows of 256 bytes, chunk ^= 2 (row & 7) like a K tile): its Q rows on the way in (whole rows by
+    // LDS-DMA, then fragment reads), its O rows on the way out (fragment writes, then whole-row stores).  Per-lane fragment loads /
+    // stores at a row stride touched 16 lines of 32-64 bytes each, and one wave per SIMD has nobody to hide that behind: the
+    // prologue and the epilogue were 12.4 k + 10.4 k of a block's ~103 k cycles
+    constexpr int kIo = 64 * kFa128Row;
+    __shared__ __attribute__((aligned(16))) char smem[8 * kImg + 4 * kIo];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, fr = lane & 15;
+    const FaTile ft = fa_tile(tiles, tcols);
+    if (ft.q0 >= (1 << 30)) return;
+    const int seq = ft.seq, q0 = ft.q0;
+    // the block's four waves take the SAME 64 queries of four consecutive q heads (one kv head: the staged K / V tile serves all
+    // four, half the K / V traffic per query row of a 128-query block) -- every wave walks the same number of key tiles.  (A block of
+    // 256 queries of one head, 64 per wave, idles its early waves through the last key tiles: 10.5 % of the wave-tiles on cfg 5's shape.)
+    const int h = (tcols == 3 ? ft.h : ft.h * 4) + wave, hk = h / (nh / nkv);
+    const int64_t t0 = cu[seq];
+    const int len = cu[seq + 1] - (int)t0;
+    const int qw = q0;
+    const int last_q = min(q0 + 63, len - 1);
+    const int nkt = last_q / BN + 1;                                          // key tiles the block walks
+    const int na = nkt;
+
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+    unsigned long long ts6, ts7;
+    { int fence_ = len + nkt; asm volatile("" : "+s"(fence_)); }
+    RPO_FWS(ts6);
+    RPO_FWS_ADD(12, ts0, ts6);                           /* 12: tile entry and sequence bounds are here (two scalar round trips) */
+#endif
+    // staging: tile j's K rows go to K slot j % 4, its V rows to V slot j % 4; wave w carries pieces 2 w, 2 w + 1 (4 rows each) of
+    // either; lane l carries row 4 u + (l >> 4), physical chunk l & 15 = logical chunk (l & 15) ^ 2 (row & 7)
+    const int srow = lane >> 4;
+    const char* ksrc = reinterpret_cast<const char*>(k + t0 * sk + hk * kFa128HD);
+    const char* vsrc = reinterpret_cast<const char*>(v + t0 * sv + hk * kFa128HD);
+    const unsigned skb = (unsigned)sk * 2u, svb = (unsigned)sv * 2u;
+    auto stage = [&](const char* src, unsigned stride_b, int kt, int ring_off) {
+        char* base = smem + ring_off + (kt & 3) * kImg;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int u = 2 * wave + i;
+            const int trow = 4 * u + srow;
+            const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
+            const unsigned row = (unsigned)min(kt * BN + trow, len - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (row * stride_b + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, 0);
+        }
+    };
+    // Q: the wave's 64 rows (clamped to the sequence: the rows past its end are copies of its last one and are never stored) as
+    // sixteen 1-KiB LDS-DMA pieces, issued FIRST; the first K / V tiles behind them; the fragments are read once the wave's own
+    // pieces have landed (vmcnt: the tiles' twelve may still fly), rotated (rope_frag), written back, and parked in a[144:207]
+    // (the B operands of the S^T chains) for the whole kernel
+    char* const io = smem + 8 * kImg + wave * kIo;
+    {
+        const char* qsrc = reinterpret_cast<const char*>(q + t0 * sq + h * kFa128HD);
+        const unsigned sqb = (unsigned)sq * 2u;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int trow = 4 * u + srow;
+            const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
+            const unsigned row = (unsigned)min(qw + trow, len - 1);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc + ((size_t)row * sqb + lchunk * 16)),
+                                             (__attribute__((address_space(3))) void*)(io + u * 1024), 16, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < nkt) stage(ksrc, skb, j, 0);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+        if (j < nkt) stage(vsrc, svb, j, kVRing);
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+    RPO_FWS(ts7);
+    RPO_FWS_ADD(13, ts6, ts7);                           /* 13: Q pieces and first staging ISSUED */
+#endif
+    RPO_FW_INIT_ACC();                                                    // O^T = l = 0 (144 register writes under the loads' latency)
+    const int staged0 = 2 * (min(nkt, 4) + min(nkt, 2));                  // K / V pieces this wave has in flight behind its Q pieces
+    if (staged0 == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    short8_t bq[4][4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+            bq[n][ks] = *reinterpret_cast<const short8_t*>(io + (16 * n + fr) * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4));
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+    RPO_FWS(ts6);
+    RPO_FWS_ADD(14, ts7, ts6);                           /* 14: accumulators zeroed, Q pieces landed, fragments read */
+#endif
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int qi = qw + 16 * n + fr;
+        if (rcos && qi < len) {
+            const int64_t tr = ((t0 + qi) % rperiod) * (kFa128HD / 2) + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                rope_frag(bq[n][ks], bq[n][ks + 2], *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks),
+                          *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks + 4),
+                          *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks),
+                          *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks + 4));
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+                *reinterpret_cast<short8_t*>(q_rw + (t0 + qi) * sq + h * kFa128HD + 32 * ks + 8 * g) = bq[n][ks];
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4_t w = __builtin_bit_cast(uint4_t, bq[n][ks]);
+            RPO_FW_Q_TO_ACC(n, ks, w);
+        }
+    }
+    // loop-invariant per-lane LDS addresses (slot 0 of either ring; the statements add the slot as an immediate): K rows of k-step ks
+    // (row fr, chunk (4 ks + g) ^ 2 (fr & 7)), V^T blocks of hd tile c (row 4 g + qq, chunk (2 c + (pp >> 1)) ^ 2 (4 (g & 1) + qq))
+    const int qq = fr >> 2, pp = fr & 3;
+    const int vsw = 2 * (4 * (g & 1) + qq);
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned trv[8], krow[4];
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+        trv[c] = smem_base + kVRing + (4 * g + qq) * kFa128Row + (((2 * c + (pp >> 1)) ^ vsw) << 4) + 8 * (pp & 1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) krow[ks] = smem_base + fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
+    // the wave's two K pieces and two V pieces inside a 32-key tile: row 4 u + srow, logical chunk (l & 15) ^ 2 (row & 7): byte offsets
+    // from the tile's first row (rows past the sequence end exist only in its LAST tile, which hipcc's `stage` loads with the clamp)
+    unsigned pk[2], pv[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int trow = 4 * (2 * wave + i) + srow;
+        const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
+        pk[i] = (unsigned)trow * skb + lchunk * 16;
+        pv[i] = (unsigned)trow * svb + lchunk * 16;
+        asm volatile("" : "+v"(pk[i]), "+v"(pv[i]));
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(trv[c]));          // (kept as eight registers: no arithmetic inside the loop)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(krow[ks]));
+
+    auto needs_mask = [&](int j) { return (j * BN + BN - 1 > qw) || (j * BN + BN > len); };
+#define RPO_FW_MASK(GEN, J)                                                                                        \
+    do {                                                                                                           \
+        const int k0_ = (J) * BN;                                                                                  \
+        const int d0_ = min(qw + fr, len - 1) - k0_ - 4 * g, d1_ = min(qw + 16 + fr, len - 1) - k0_ - 4 * g;       \
+        const int d2_ = min(qw + 32 + fr, len - 1) - k0_ - 4 * g, d3_ = min(qw + 48 + fr, len - 1) - k0_ - 4 * g;  \
+        RPO_FW_MASK_##GEN(d0_, d1_, d2_, d3_);                                                                     \
+    } while (0)
+#define RPO_FW_CHECK(GEN, GROW)                                                                                    \
+    do {                                                                                                           \
+        if (__builtin_amdgcn_ballot_w64((GROW) > kFwDefer) != 0) RPO_FW_RESCALE_##GEN();                           \
+    } while (0)
+
+    // from here on v[64:227] and a[0:207] belong to the generated statements (hipcc's own code above used some of them)
+    RPO_FWS(ts1);
+    RPO_FWS_ADD(9, ts0, ts1);                            /* 9: Q loads, staging of the first tiles, rope, Q -> accumulator file */
+    RPO_FW_INIT();
+    RPO_FWS(ts2);
+    RPO_FWS_ADD(10, ts1, ts2);                           /* 10: INIT */
+    // everything issued so far has landed (Q loads, K tiles 0-3, V tiles 0-1); then everybody's has
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    RPO_FWS(ts1);
+    RPO_FWS_ADD(11, ts2, ts1);                           /* 11: first tiles landed + barrier */
+    float grow = 0.f;
+    if (na > 0) {
+        RPO_FW_KREAD(krow[0], krow[1], krow[2], krow[3]);                        // tile 0 (K slot 0)
+        RPO_FW_SCHAIN_A();
+        if (needs_mask(0)) RPO_FW_MASK(A, 0);
+        RPO_FW_FIRST_A(krow[0], krow[1], krow[2], krow[3], scale_log2e);         // tile 0's scale and exponents, tile 1's K rows (slot 1)
+    }
+    // one iteration: tile kt's exponentials + tile kt + 1's chains, then tile kt's products + tile kt + 1's maximum
+#define RPO_FW_ITER(S, NXT, KT)                                                                                    \
+    do {                                                                                                           \
+        const int kt_ = (KT);                                                                                      \
+        RPO_FWS(ts1);                                                                                              \
+        if (kt_ > 0 && !(RPO_FW_EXP & 4)) {                                                                        \
+            /* K(kt + 2) and V(kt) landed (both staged two iterations ago); the previous iteration's four pieces may fly */ \
+            if (kt_ + 3 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
+            RPO_FWS(ts2);                                                                                          \
+            RPO_FWS_ADD(0, ts1, ts2);                                     /* 0: wait for the ring */                \
+            __builtin_amdgcn_s_barrier();                                                                          \
+            RPO_FWS(ts3);                                                                                          \
+            RPO_FWS_ADD(1, ts2, ts3);                                     /* 1: barrier */                          \
+        }                                                                                                          \
+        RPO_FWS(ts2);                                                                                              \
+        /* K(kt + 4) goes to the K slot of tile kt (read two iterations ago), V(kt + 2) to the V slot of tile kt - 2: INSIDE the  */ \
+        /* stream (P2D) when both tiles lie wholly inside the sequence (no row clamp) and every wave of the block runs P2, else     */ \
+        /* by hipcc's `stage` here, behind the barrier                                                                            */ \
+        const bool instream_ = !(RPO_FW_EXP & 2) && (kt_ + 5) * BN <= len && kt_ + 4 < nkt && kt_ + 1 < na;      \
+        if (!(RPO_FW_EXP & 2) && !instream_) {                                                                     \
+            if (kt_ + 4 < nkt) stage(ksrc, skb, kt_ + 4, 0);                                                       \
+            if (kt_ + 2 < nkt) stage(vsrc, svb, kt_ + 2, kVRing);                                                  \
+        }                                                                                                          \
+        RPO_FWS(ts3);                                                                                              \
+        RPO_FWS_ADD(2, ts2, ts3);                                         /* 2: hipcc's staging (when not in-stream) */ \
+        if (kt_ < na) {                                                                                            \
+            if (kt_ + 1 < na) {                                                                                    \
+                RPO_FW_P1_S##S(trv[0], trv[1], trv[2], trv[3], trv[4], trv[5], trv[6], trv[7], scale_log2e);       \
+                RPO_FWS(ts4);                                                                                      \
+                RPO_FWS_ADD(3, ts3, ts4);                                 /* 3: P1 */                               \
+                if (needs_mask(kt_ + 1)) RPO_FW_MASK(NXT, kt_ + 1);                                                \
+                RPO_FWS(ts5);                                                                                      \
+                RPO_FWS_ADD(4, ts4, ts5);                                 /* 4: mask */                             \
+                if (instream_) {                                                                                   \
+                    const char* sk_ = ksrc + (size_t)(kt_ + 4) * BN * skb;                                         \
+                    const char* sv_ = vsrc + (size_t)(kt_ + 2) * BN * svb;                                         \
+                    const unsigned mk_ = smem_base + (kt_ & 3) * kImg + 2 * wave * 1024;                           \
+                    const unsigned mv_ = smem_base + kVRing + ((kt_ + 2) & 3) * kImg + 2 * wave * 1024;            \
+                    RPO_FW_P2D_S##S(grow, krow[0], krow[1], krow[2], krow[3], scale_log2e, pk[0], pk[1], pv[0], pv[1], sk_, sv_, \
+                                    mk_, mv_);                                                                     \
+                } else {                                                                                           \
+                    RPO_FW_P2_S##S(grow, krow[0], krow[1], krow[2], krow[3], scale_log2e);                         \
+                }                                                                                                  \
+                RPO_FW_CHECK(NXT, grow);                                                                           \
+                RPO_FWS(ts4);                                                                                      \
+                RPO_FWS_ADD(5, ts5, ts4);                                 /* 5: P2 + rescale check */               \
+                RPO_FWS_ADD(7, 0, 1);                                     /* 7: full iterations */                  \
+            } else {                                                                                               \
+                RPO_FW_P1L_S##S(trv[0], trv[1], trv[2], trv[3], trv[4], trv[5], trv[6], trv[7], scale_log2e);      \
+                RPO_FW_P2L();                                                                                      \
+            }                                                                                                      \
+        }                                                                                                          \
+    } while (0)
+    RPO_FWS(ts1);
+    RPO_FWS_ADD(6, ts0, ts1);                            /* 6: the block's prologue */
+    for (int kt = 0; kt < nkt; kt += 4) {
+        RPO_FW_ITER(0, B, kt);
+        if (kt + 1 < nkt) RPO_FW_ITER(1, A, kt + 1);
+        if (kt + 2 < nkt) RPO_FW_ITER(2, B, kt + 2);
+        if (kt + 3 < nkt) RPO_FW_ITER(3, A, kt + 3);
+    }
+#undef RPO_FW_ITER
+#undef RPO_FW_MASK
+#undef RPO_FW_CHECK
+    RPO_FWS(ts4);
+    // ---- epilogue: O[q][16c + 4g + r] = O^T / l into the wave's LDS region (8 bytes per lane and fragment), whole rows out of it
+    // (16 bytes per lane, 4 rows per instruction);  lse = mc ln 2 + ln l  (mc = maximum x scale log2e)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int qi = qw + 16 * n + fr;
+        float l, mc;
+        RPO_FW_READ_LM(n, l, mc);
+        const float inv = 1.0f / l;
+        char* lrow = io + (16 * n + fr) * kFa128Row + 8 * (g & 1);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float x0, x1, x2, x3;
+            RPO_FW_READ_O(c, n, x0, x1, x2, x3);
+            uint2_t w;
+            w.x = pack_bf16(x0 * inv, x1 * inv);
+            w.y = pack_bf16(x2 * inv, x3 * inv);
+            *reinterpret_cast<uint2_t*>(lrow + (((2 * c + (g >> 1)) ^ (2 * (fr & 7))) << 4)) = w;
+        }
+        if (g == 0 && qi < len && na > 0)
+            lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
+                mc * 0.6931471805599453f + logf(l);
+    }
+    if (na > 0) {
+        bf16_t* obase = o + (t0 + qw) * so + h * kFa128HD + 8 * (lane & 15);
+        int srow_e = lane >> 4;
+        asm volatile("" : "+v"(srow_e));                 // (re-derived here: the prologue's sixteen row numbers would otherwise be kept -- spilled -- across the whole kernel)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int trow = 4 * u + srow_e;
+            const uint4_t w = *reinterpret_cast<const uint4_t*>(io + trow * kFa128Row + (((lane & 15) ^ (2 * (trow & 7))) << 4));
+            if (qw + trow < len) *reinterpret_cast<uint4_t*>(obase + (int64_t)trow * so) = w;
+        }
+    }
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    RPO_FWS(ts5);
+    RPO_FWS_ADD(8, ts4, ts5);                            /* 8: epilogue, stores landed */
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_fa_stamp[wave * 16 + i], st_acc[i]);
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Backward.  Two launches, no atomics, deterministic:
 //   fa_bwd_dq_kernel     block = 128 queries of one (sequence, head): delta[h][t] = sum_d dO[t,h,d] O[t,h,d] in the prologue,
 //                        then the loop over key tiles <= diagonal:
@@ -3900,9 +4226,17 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
                                   int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles,
                                   int64_t tile_cols, int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim,
                                   float scale, void* out, int64_t out_stride, float* lse, int64_t lse_max_len,
-                                  const float* rope_cos, const float* rope_sin, int64_t rope_period, rpo_stream_t stream) {
+                                  const float* rope_cos, const float* rope_sin, int64_t rope_period, int64_t q_block,
+                                  rpo_stream_t stream) {
     if (!q || !k || !v || !cu_seqlens || !tiles || !out || !lse || ntiles <= 0 || total_tokens <= 0)
         return RPO_ERR_INVALID_ARG;
+    // q_block: query rows per work-list entry.  128 (or 0): every kernel.  64: head_dim 128 only -- an entry is 64 queries x the FOUR
+    // consecutive q heads that start at the entry's head (format 2: head = 4 x the launch's y index), all of one kv head:
+    // fa_fwd128w_kernel, one wave per SIMD
+    if (q_block == 0) q_block = 128;
+    if (q_block != 128 && !(q_block == 64 && head_dim == kFa128HD && num_kv_heads > 0 && num_heads % num_kv_heads == 0 &&
+                            (num_heads / num_kv_heads) % 4 == 0))
+        return RPO_ERR_UNSUPPORTED;
     // rope_cos / rope_sin (both or neither): q arrives UN-rotated and is rotated IN PLACE by the block that owns it (k must
     // arrive rotated: every query block reads it)
     if ((rope_cos == nullptr) != (rope_sin == nullptr) || (rope_cos && rope_period <= 0)) return RPO_ERR_INVALID_ARG;
@@ -3914,6 +4248,7 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
     if (q_stride % 8 || k_stride % 8 || v_stride % 8 || out_stride % 4 || !rpo_aligned16(q) || !rpo_aligned16(k) ||
         !rpo_aligned16(v) || (reinterpret_cast<uintptr_t>(out) & 7))
         return RPO_ERR_UNSUPPORTED;
+    if (q_block == 64 && (out_stride % 8 || !rpo_aligned16(out))) return RPO_ERR_UNSUPPORTED;      // whole-row stores, 16 bytes per lane
     hipStream_t st = (hipStream_t)stream;
     const float log2e = 1.4426950408889634f;
     dim3 grid((unsigned)ntiles, tile_cols == 3 ? 1u : (unsigned)num_heads);
@@ -3931,6 +4266,15 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
 #endif
     if (head_dim == kFa128HD && tile_cols != 3) grid.y = (unsigned)(num_heads / RPO_F128_HEADS);
 #define RPO_F128_KERNEL fa_fwd128_kernel<RPO_F128_WQ, RPO_F128_HEADS, RPO_F128_SUB, RPO_F128_KF>
+    if (q_block == 64) {
+        if (tile_cols != 3) grid.y = (unsigned)(num_heads / 4);
+        RPO_LAUNCH(fa_fwd128w_kernel, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
+                   k_stride, v_stride, cu_seqlens, tiles, (int)tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,
+                   (bf16_t*)out, out_stride, lse, lse_max_len > 0 ? num_heads * lse_max_len : 0,
+                   lse_max_len > 0 ? lse_max_len : total_tokens, lse_max_len > 0 ? 0 : 1, rope_cos, rope_sin, rope_period,
+                   (bf16_t*)const_cast<void*>(q));
+        return rpo_launch_status();
+    }
     if (head_dim == kFa128HD)
         RPO_LAUNCH((RPO_F128_KERNEL), grid, dim3(64 * RPO_F128_WQ * RPO_F128_HEADS), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
                    k_stride, v_stride, cu_seqlens, tiles, (int)tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,

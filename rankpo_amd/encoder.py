@@ -186,13 +186,17 @@ class RopeTables:
 FOLD_ROPE = 2        # packed training path: rotary + attention as ONE autograd node; 2 = q rotated by the attention forward block
 #                      that loads it + inverse rotary in the dQ / dK epilogues, 1 = the epilogues only, 0 = two nodes with
 #                      separate rpo_rope passes both ways (the A/B arms of `bench.py --fold-rope`)
+FWD128_ONE_WAVE = True   # head_dim 128 with 4 q heads per kv head: the forward walks its own list (64 queries x 4 heads per entry) with
+#                          the one-wave-per-SIMD kernel; False: the 128-query kernel of rounds 3-4 (the A/B arm of `bench.py --fwd128 classic`)
 
 
 class VarlenCtx:
-    """cu_seqlens (int32, device), the host copy of the lengths and the longest length of a packed batch."""
+    """cu_seqlens (int32, device), the host copy of the lengths and the longest length of a packed batch; the attention kernels'
+    work lists: `tiles` (128 queries per entry: forward and dQ), `k_tiles` (dK/dV), `fwd_tiles` (the forward's own list where it has
+    one -- head_dim 128: 64 queries x 4 q heads per entry, `ops.attn_fwd_tile_table` -- else None)."""
 
-    def __init__(self, cu, lens, max_len, tiles=None, k_tiles=None):
-        self.cu, self.lens, self.max_len, self.tiles, self.k_tiles = cu, lens, max_len, tiles, k_tiles
+    def __init__(self, cu, lens, max_len, tiles=None, k_tiles=None, fwd_tiles=None):
+        self.cu, self.lens, self.max_len, self.tiles, self.k_tiles, self.fwd_tiles = cu, lens, max_len, tiles, k_tiles, fwd_tiles
 
 
 def _varlen_causal_attention(q, k, v, ctx: VarlenCtx):
@@ -202,7 +206,8 @@ def _varlen_causal_attention(q, k, v, ctx: VarlenCtx):
         # without it PyTorch's flash-attention backward runs on the saved (out, padded lse)
         return _ops.flash_attn_varlen(q, k, v, ctx.cu, ctx.tiles, ctx.max_len, 1.0 / math.sqrt(q.shape[-1]),
                                       k_tiles=ctx.k_tiles,
-                                      key_block=_ops.ATTN_KEY_BLOCK if q.shape[-1] == 64 else _ops.ATTN_KEY_BLOCK_HD128)
+                                      key_block=_ops.ATTN_KEY_BLOCK if q.shape[-1] == 64 else _ops.ATTN_KEY_BLOCK_HD128,
+                                      fwd_tiles=ctx.fwd_tiles)
     if q.is_cuda and q.dtype in (torch.bfloat16, torch.float16):
         return torch.ops.aten._flash_attention_forward(q, k, v, ctx.cu, ctx.cu, ctx.max_len, ctx.max_len, 0.0, True,
                                                        False)[0]
@@ -305,7 +310,7 @@ class LlamaAttention(nn.Module):
             # buffer (no split / cat copies) with the inverse rotation already applied in the dQ / dK epilogues
             o = _ops.rope_flash_attn_varlen_qkv(qkv, rope.cos32, rope.sin32, self.nh, self.nkv, attn_mask.cu,
                                                 attn_mask.tiles, attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd,
-                                                fold_forward=FOLD_ROPE >= 2)
+                                                fold_forward=FOLD_ROPE >= 2, fwd_tiles=attn_mask.fwd_tiles)
             return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
         if fused:       # one in-place HIP pass over the q and k heads instead of neg / cat / 2 mul / add per tensor
             qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd, grad_inplace=True)
@@ -314,7 +319,8 @@ class LlamaAttention(nn.Module):
                 and x.dtype == torch.bfloat16):
             # A/B arm (FOLD_ROPE = False): the rotary pass and the attention as two autograd nodes
             o = _ops.flash_attn_varlen_qkv(qkv.view(L, -1), self.nh, self.nkv, attn_mask.cu, attn_mask.tiles,
-                                           attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd)
+                                           attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd,
+                                           fwd_tiles=attn_mask.fwd_tiles)
             return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
         if isinstance(attn_mask, VarlenCtx):
             # packed tokens [1, T, d]: variable-length causal flash attention, no pad tokens anywhere
@@ -594,15 +600,18 @@ class LlamaEncoder(nn.Module):
         N = len(lens)
         cu = torch.zeros(N + 1, dtype=torch.int32, device=x.device)
         cu[1:] = torch.tensor(lens, dtype=torch.int64).cumsum(0).to(torch.int32).to(x.device, non_blocking=True)
-        tiles = k_tiles = None
+        tiles = k_tiles = fwd_tiles = None
         if (x.is_cuda and self.config.head_dim in (64, 128) and x.dtype == torch.bfloat16
                 and self.hand_attention):                                                        # hand-written flash attention
             tiles = _ops.attn_tile_table(lens, x.device, self.config.num_attention_heads, self.config.num_key_value_heads)
+            if FWD128_ONE_WAVE:
+                fwd_tiles = _ops.attn_fwd_tile_table(lens, x.device, self.config.num_attention_heads,
+                                                     self.config.num_key_value_heads, self.config.head_dim)
             if torch.is_grad_enabled():
                 k_tiles = _ops.attn_key_tile_table(
                     lens, x.device, self.config.num_key_value_heads,
                     _ops.ATTN_KEY_BLOCK if self.config.head_dim == 64 else _ops.ATTN_KEY_BLOCK_HD128)
-        ctx = VarlenCtx(cu, lens, max(lens), tiles, k_tiles)
+        ctx = VarlenCtx(cu, lens, max(lens), tiles, k_tiles, fwd_tiles)
         last_idx = (cu[1:] - 1).to(torch.int64)
         x, delta = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1)
         li = len(self.layers) - 1

@@ -654,6 +654,16 @@ def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, blo
     return torch.from_numpy(np.concatenate(out, 0)).to(device, non_blocking=True)
 
 
+def attn_fwd_tile_table(lens, device, num_heads: int, num_kv_heads: int, head_dim: int):
+    """The FORWARD kernel's own work list where it has one: head_dim 128 with a multiple of 4 q heads per kv head -> entries of 64
+    queries x 4 q heads (`attn_tile_table(..., block_m=64, heads_per_block=4)`; pass it as `fwd_tiles`, the forward then runs with
+    q_block = 64); otherwise None (the forward walks the 128-row list the dQ kernel walks)."""
+    H = num_kv_heads if num_kv_heads > 0 else num_heads
+    if head_dim != 128 or num_heads <= 0 or num_heads % H or (num_heads // H) % 4:
+        return None
+    return attn_tile_table(lens, device, num_heads, num_kv_heads, block_m=64, heads_per_block=4)
+
+
 def _check_rope_tables(rope, hd, who):
     rc, rs = rope
     if (rc.dtype != torch.float32 or rs.dtype != torch.float32 or rc.shape != rs.shape or rc.dim() != 2
@@ -661,10 +671,12 @@ def _check_rope_tables(rope, hd, who):
         raise ValueError(f"{who}: rope must be (cos, sin), contiguous f32 [period, head_dim / 2]")
 
 
-def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0, rope=None):
+def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0, rope=None, q_block: int = 128):
     """q [T, nh, hd], k / v [T, nkv, hd], hd = 64 or 128 (last two dims contiguous, token stride free); returns
     (out [T, nh, hd] bf16, lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0).  rope = (cos, sin),
-    f32 [period, hd / 2]: q arrives UN-rotated and the kernel rotates it IN PLACE (k must arrive rotated), see the header."""
+    f32 [period, hd / 2]: q arrives UN-rotated and the kernel rotates it IN PLACE (k must arrive rotated), see the header.
+    q_block = the query rows per entry of `tiles`: 128, or 64 for a list from `attn_fwd_tile_table` (head_dim 128, entries of
+    64 queries x 4 q heads: the one-wave-per-SIMD forward)."""
     lib = _lib.load()
     if rope is not None:
         _check_rope_tables(rope, q.shape[-1], "flash_attn_varlen_fwd")
@@ -684,7 +696,7 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
                                      out.data_ptr(), nh * hd, lse.data_ptr(), padded_lse_len,
                                      rope[0].data_ptr() if rope is not None else None,
                                      rope[1].data_ptr() if rope is not None else None,
-                                     rope[0].shape[0] if rope is not None else 0, _stream(q)),
+                                     rope[0].shape[0] if rope is not None else 0, q_block, _stream(q)),
               "rpo_flash_attn_fwd")
     return out, lse
 
@@ -808,10 +820,11 @@ class _FlashAttnVarlen(torch.autograd.Function):
     k_tiles is None."""
 
     @staticmethod
-    def forward(ctx, q, k, v, cu, tiles, k_tiles, max_len, scale, key_block):
+    def forward(ctx, q, k, v, cu, tiles, k_tiles, max_len, scale, key_block, fwd_tiles=None):
         own_bwd = k_tiles is not None
-        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0 if own_bwd else max_len,
-                                         num_seqs=cu.numel() - 1)
+        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles if fwd_tiles is None else fwd_tiles, scale,
+                                         padded_lse_len=0 if own_bwd else max_len, num_seqs=cu.numel() - 1,
+                                         q_block=128 if fwd_tiles is None else 64)
         ctx.save_for_backward(q, k, v, out, lse, cu, tiles, k_tiles if own_bwd else cu)
         ctx.meta = (max_len, scale, own_bwd, key_block)
         return out
@@ -826,11 +839,11 @@ class _FlashAttnVarlen(torch.autograd.Function):
             z = torch.zeros((), dtype=torch.int64, device=q.device)
             dq, dk, dv = torch.ops.aten._flash_attention_backward(go.contiguous(), q, k, v, out, lse, cu, cu, max_len,
                                                                   max_len, 0.0, True, z, z, scale=scale)
-        return dq, dk, dv, None, None, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None, None, None
 
 
-def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale, k_tiles=None, key_block: int = ATTN_KEY_BLOCK):
-    return _FlashAttnVarlen.apply(q, k, v, cu, tiles, k_tiles, max_len, scale, key_block)
+def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale, k_tiles=None, key_block: int = ATTN_KEY_BLOCK, fwd_tiles=None):
+    return _FlashAttnVarlen.apply(q, k, v, cu, tiles, k_tiles, max_len, scale, key_block, fwd_tiles)
 
 
 class _FlashAttnVarlenQKV(torch.autograd.Function):
@@ -846,10 +859,11 @@ class _FlashAttnVarlenQKV(torch.autograd.Function):
                 x[:, nq + nk:].unflatten(1, (nkv, hd)))
 
     @staticmethod
-    def forward(ctx, qkv, nh, nkv, cu, tiles, k_tiles, scale, key_block):
+    def forward(ctx, qkv, nh, nkv, cu, tiles, k_tiles, scale, key_block, fwd_tiles=None):
         hd = qkv.shape[1] // (nh + 2 * nkv)
         q, k, v = _FlashAttnVarlenQKV._views(qkv, nh, nkv, hd)
-        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0, num_seqs=cu.numel() - 1)
+        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles if fwd_tiles is None else fwd_tiles, scale, padded_lse_len=0,
+                                         num_seqs=cu.numel() - 1, q_block=128 if fwd_tiles is None else 64)
         ctx.save_for_backward(qkv, out, lse, cu, tiles, k_tiles)
         ctx.meta = (nh, nkv, hd, scale, key_block)
         return out
@@ -862,7 +876,7 @@ class _FlashAttnVarlenQKV(torch.autograd.Function):
         dqkv = torch.empty_like(qkv)
         flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale,
                               grads=_FlashAttnVarlenQKV._views(dqkv, nh, nkv, hd), key_block=key_block)
-        return dqkv, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None
 
 
 class _RopeFlashAttnVarlenQKV(torch.autograd.Function):
@@ -872,7 +886,7 @@ class _RopeFlashAttnVarlenQKV(torch.autograd.Function):
     projection output and no separate pass re-reads and re-rounds the q / k gradient (0.28 ms per block on cfg 2)."""
 
     @staticmethod
-    def forward(ctx, qkv, cos, sin, nh, nkv, cu, tiles, k_tiles, scale, key_block, fold_forward):
+    def forward(ctx, qkv, cos, sin, nh, nkv, cu, tiles, k_tiles, scale, key_block, fold_forward, fwd_tiles=None):
         x = qkv.view(-1, qkv.shape[-1])                      # [T, W]; `qkv` itself may carry leading batch dims ([1, T, W])
         hd = x.shape[1] // (nh + 2 * nkv)
         lib = _lib.load()
@@ -887,8 +901,9 @@ class _RopeFlashAttnVarlenQKV(torch.autograd.Function):
         ctx.mark_dirty(qkv)
         ctx.set_materialize_grads(False)
         q, k, v = _FlashAttnVarlenQKV._views(x, nh, nkv, hd)
-        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles, scale, padded_lse_len=0, num_seqs=cu.numel() - 1,
-                                         rope=(cos, sin) if fold_forward else None)
+        out, lse = flash_attn_varlen_fwd(q, k, v, cu, tiles if fwd_tiles is None else fwd_tiles, scale, padded_lse_len=0,
+                                         num_seqs=cu.numel() - 1, rope=(cos, sin) if fold_forward else None,
+                                         q_block=128 if fwd_tiles is None else 64)
         ctx.save_for_backward(qkv, out, lse, cu, tiles, k_tiles, cos, sin)
         ctx.meta = (nh, nkv, hd, scale, key_block)
         return out, qkv
@@ -904,11 +919,11 @@ class _RopeFlashAttnVarlenQKV(torch.autograd.Function):
         flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, k_tiles, scale,
                               grads=_FlashAttnVarlenQKV._views(dqkv.view(-1, qkv.shape[-1]), nh, nkv, hd), key_block=key_block,
                               rope=(cos, sin))
-        return dqkv, None, None, None, None, None, None, None, None, None, None
+        return dqkv, None, None, None, None, None, None, None, None, None, None, None
 
 
 def rope_flash_attn_varlen_qkv(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None,
-                               head_dim: int = 64, fold_forward: bool = True):
+                               head_dim: int = 64, fold_forward: bool = True, fwd_tiles=None):
     """qkv: the FRESH output of the fused q|k|v projection, [T, (num_heads + 2 num_kv_heads) * head_dim] (leading dims of size 1
     allowed: [1, T, W]; pass the projection's own tensor, not a reshaped view of it) bf16, contiguous, NOT yet rotated (it is
     rotated in place here); cos / sin: f32 [period, head_dim / 2] (row t % period for token t) -> attention
@@ -922,19 +937,20 @@ def rope_flash_attn_varlen_qkv(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles
     if key_block == 64:
         raise ValueError("rope_flash_attn_varlen_qkv: the 64-key dK/dV kernel has no rotary epilogue; use rope_ + flash_attn_varlen_qkv")
     return _RopeFlashAttnVarlenQKV.apply(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block,
-                                         bool(fold_forward))[0]
+                                         bool(fold_forward), fwd_tiles)[0]
 
 
-def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None, head_dim: int = 64):
+def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None, head_dim: int = 64, fwd_tiles=None):
     """qkv: [T, (num_heads + 2 num_kv_heads) * head_dim] bf16, contiguous rows -> out [T, num_heads, head_dim]; head_dim 64
-    or 128; key_block (None: the head_dim's default) = the block_n `k_tiles` was built with."""
+    or 128; key_block (None: the head_dim's default) = the block_n `k_tiles` was built with; fwd_tiles: the forward's own list
+    (`attn_fwd_tile_table`) or None."""
     if head_dim not in (64, 128):
         raise ValueError("flash_attn_varlen_qkv: head_dim must be 64 or 128")
     if qkv.dim() != 2 or qkv.shape[1] != (num_heads + 2 * num_kv_heads) * head_dim or not qkv.is_contiguous():
         raise ValueError("flash_attn_varlen_qkv: qkv must be a contiguous [T, (nh + 2 nkv) * head_dim] tensor")
     if key_block is None:
         key_block = ATTN_KEY_BLOCK if head_dim == 64 else ATTN_KEY_BLOCK_HD128
-    return _FlashAttnVarlenQKV.apply(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block)
+    return _FlashAttnVarlenQKV.apply(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block, fwd_tiles)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -1029,5 +1045,5 @@ def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
 
 __all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
-           "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table",
+           "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table",
            "attn_key_tile_table"]

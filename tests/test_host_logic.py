@@ -550,6 +550,12 @@ def test_query_tile_table_properties():
         assert all((h // 4) == ((h + hpb - 1) // 4) for _, _, h in real.tolist())     # a block's heads share one kv head
     with pytest.raises(ValueError, match="heads_per_block"):
         ops.attn_tile_table([300], "cpu", 32, 8, heads_per_block=3)
+    # the forward's own list exists exactly where the one-wave kernel applies: head_dim 128, a multiple of 4 q heads per kv head
+    ft = ops.attn_fwd_tile_table([300, 64], "cpu", 32, 8, 128)
+    assert ft is not None and torch.equal(ft, ops.attn_tile_table([300, 64], "cpu", 32, 8, block_m=64, heads_per_block=4))
+    assert ops.attn_fwd_tile_table([300], "cpu", 16, 2, 128) is not None                  # 8 per kv head: two entries per tile
+    for nh, nkv, hd in ((32, 8, 64), (32, 16, 128), (12, 12, 128), (6, 2, 128)):
+        assert ops.attn_fwd_tile_table([300], "cpu", nh, nkv, hd) is None
 
 
 def test_rotary_frequencies_survive_a_dtype_cast():
@@ -820,6 +826,18 @@ def test_generated_dkdv128_bodies_are_in_sync():
     assert gen == open(os.path.join(root, "rankpo_amd", "csrc", "attention_dkdv128_gen.inc")).read()
 
 
+def test_generated_fwd128w_statements_are_in_sync():
+    """rankpo_amd/csrc/attention_fwd128w_gen.inc (the hand-placed statements of fa_fwd128w_kernel, the one-wave-per-SIMD head_dim-128
+    forward) is generated text: it must be what tools/gen/gen_fwd128w_body.py emits today (edit the generator, not the file)."""
+    import subprocess
+    import sys
+    root = os.path.join(os.path.dirname(__file__), "..")
+    env = {k: v for k, v in os.environ.items() if not k.startswith("GEN_")}
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_fwd128w_body.py")], capture_output=True,
+                         text=True, check=True, env=env).stdout
+    assert gen == open(os.path.join(root, "rankpo_amd", "csrc", "attention_fwd128w_gen.inc")).read()
+
+
 def test_no_valu_reads_a_transcendental_result_in_the_next_slot(tmp_path):
     """gfx950: a VALU instruction must not read the result of the v_exp_f32 / v_rcp_f32 / ... issued right in front of it (one wait
     state).  hipcc pads what it can see; the hand-placed asm streams and the one-instruction asm helpers it cannot.  Round 3's
@@ -839,6 +857,26 @@ def test_no_valu_reads_a_transcendental_result_in_the_next_slot(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_trans_hazard.py")] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     _check_dkdv_prefetch_registers(os.path.join(str(tmp_path), "attention.s"), root)
+    _check_fwd128w_register_ownership(os.path.join(str(tmp_path), "attention.s"), root)
+
+
+def _check_fwd128w_register_ownership(attention_s, root):
+    """fa_fwd128w_kernel's asm statements own v[64:227] and the accumulator file BETWEEN statements (scores, fragments, the softmax
+    scale, O^T / l / Q^T live there across hipcc's loop code): tools/check_fwd128w_isa.py reads the kernel's ISA -- nothing of hipcc's
+    behind RPO_FW_INIT names them, no spill, no scratch -- and the check has teeth (a planted use is found)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_fwd128w_isa", os.path.join(root, "tools", "check_fwd128w_isa.py"))
+    C = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(C)
+    isa = open(attention_s).read()
+    rep = C.check(isa)
+    assert rep["ok"], rep["problems"][:10]
+    assert rep["checked"] >= 1000 and rep["statements"] >= 100, rep      # the loop's own code and the statements were really seen
+    body = "\n".join(C.kernel_body(isa)[0])
+    at = body.rindex("s_barrier")                                         # hipcc's code at the top of a key-tile iteration
+    for planted in ("v_mov_b32_e32 v100, v1", "v_accvgpr_read_b32 v1, a17"):
+        bad = C.check(isa.replace(body, body[:at] + "s_barrier\n\t" + planted + "\n" + body[at + len("s_barrier"):]))
+        assert not bad["ok"] and planted in " ".join(bad["problems"]), bad
 
 
 def _check_dkdv_prefetch_registers(attention_s, root):

@@ -6,6 +6,7 @@ cd "$(dirname "$0")/../.."
 name=$1; shift
 tmp=$(mktemp -d)
 cp rankpo_amd/csrc/*.hip rankpo_amd/csrc/*.hpp rankpo_amd/csrc/*.inc rankpo_amd/csrc/Makefile "$tmp"/
+python3 tools/gen/gen_fwd128w_body.py > "$tmp/attention_fwd128w_gen_variant.inc"     # (-DRPO_FW_VARIANT_INC + GEN_* in the environment)
 sed -i "s|../../include/rankpo_hip.h|$(pwd)/include/rankpo_hip.h|" "$tmp/Makefile"
 sed -i "s|#include \"../../include/rankpo_hip.h\"|#include \"$(pwd)/include/rankpo_hip.h\"|" "$tmp/common.hpp"
 make -C "$tmp" -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wall -Wno-unused-function -fno-slp-vectorize -I$(pwd)/include $*" > /dev/null

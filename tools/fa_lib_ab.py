@@ -33,7 +33,7 @@ dq = {n: torch.empty_like(q) for n in libs}; dk = {n: torch.empty_like(k) for n 
 def fwd(n):
     return libs[n].rpo_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0), cu.data_ptr(),
                                       tiles.data_ptr(), tiles.shape[0], tiles.shape[1], T, nh, nkv, hd, SC, out[n].data_ptr(), nh * hd,
-                                      lse[n].data_ptr(), 0, None, None, 0, st)
+                                      lse[n].data_ptr(), 0, None, None, 0, 128, st)
 def bwd(n):
     return libs[n].rpo_flash_attn_bwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), out[n].data_ptr(), go.data_ptr(), q.stride(0), k.stride(0),
                                       v.stride(0), out[n].stride(0), go.stride(0), cu.data_ptr(), tiles.data_ptr(), tiles.shape[0],
