@@ -895,13 +895,32 @@ __global__ __launch_bounds__(256, 1) void fa_fwd128w_kernel(
 #pragma unroll
     for (int j = 0; j < 2; ++j)
         if (j < nkt) stage(vsrc, svb, j, kVRing);
+    // rotary fold: the cos / sin rows of the lane's queries (clamped like the Q rows), 16 + 16 floats per query.  The loads of query
+    // tiles 0, 1 are issued HERE, under the DMA pieces' flight; those of tiles 2, 3 behind the Q fragments' arrival, under the rotation
+    // of the first two (all of them here would be 128 live registers: hipcc then parks values in the accumulator file this kernel owns)
+    float4_t rc[2][2][2], rs[2][2][2];
+    auto load_rot = [&](int n0) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int64_t tr = ((t0 + min(qw + 16 * (n0 + n) + fr, len - 1)) % rperiod) * (kFa128HD / 2) + 8 * g;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    rc[n][ks][j] = *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks + 4 * j);
+                    rs[n][ks][j] = *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks + 4 * j);
+                }
+        }
+    };
+    if (rcos) load_rot(0);
 #if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
     RPO_FWS(ts7);
-    RPO_FWS_ADD(13, ts6, ts7);                           /* 13: Q pieces and first staging ISSUED */
+    RPO_FWS_ADD(13, ts6, ts7);                           /* 13: Q pieces, first staging and the rotary rows ISSUED */
 #endif
     RPO_FW_INIT_ACC();                                                    // O^T = l = 0 (144 register writes under the loads' latency)
     const int staged0 = 2 * (min(nkt, 4) + min(nkt, 2));                  // K / V pieces this wave has in flight behind its Q pieces
-    if (staged0 == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (staged0 == 12 && !rcos) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (staged0 == 12) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");          // (+ the 16 rotary-table loads)
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     short8_t bq[4][4];
 #pragma unroll
@@ -913,27 +932,47 @@ __global__ __launch_bounds__(256, 1) void fa_fwd128w_kernel(
     RPO_FWS(ts6);
     RPO_FWS_ADD(14, ts7, ts6);                           /* 14: accumulators zeroed, Q pieces landed, fragments read */
 #endif
+    if (rcos) {
+        // rotate, put the rotated fragments back where they came from in the wave's LDS region, and write the 64 rows out whole
+        // (16 bytes per lane, 4 rows per instruction: the fragments themselves are 16 rows x 64 bytes per store instruction)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int qi = qw + 16 * n + fr;
-        if (rcos && qi < len) {
-            const int64_t tr = ((t0 + qi) % rperiod) * (kFa128HD / 2) + 8 * g;
+        for (int half = 0; half < 2; ++half) {
+            float4_t c_[2][2][2], s_[2][2][2];
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-                rope_frag(bq[n][ks], bq[n][ks + 2], *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks),
-                          *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks + 4),
-                          *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks),
-                          *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks + 4));
+            for (int n = 0; n < 2; ++n)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                *reinterpret_cast<short8_t*>(q_rw + (t0 + qi) * sq + h * kFa128HD + 32 * ks + 8 * g) = bq[n][ks];
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) { c_[n][ks][j] = rc[n][ks][j]; s_[n][ks][j] = rs[n][ks][j]; }
+            if (half == 0) load_rot(2);                                   // (in flight under the rotation of tiles 0, 1)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int nn = 2 * half + n;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+                    rope_frag(bq[nn][ks], bq[nn][ks + 2], c_[n][ks][0], c_[n][ks][1], s_[n][ks][0], s_[n][ks][1]);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks)
+                    *reinterpret_cast<short8_t*>(io + (16 * nn + fr) * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4)) = bq[nn][ks];
+            }
         }
+        bf16_t* qbase = q_rw + (t0 + qw) * sq + h * kFa128HD + 8 * (lane & 15);
+        int srow_q = lane >> 4;
+        asm volatile("" : "+v"(srow_q));                 // (re-derived: see the epilogue)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int trow = 4 * u + srow_q;
+            const uint4_t w = *reinterpret_cast<const uint4_t*>(io + trow * kFa128Row + (((lane & 15) ^ (2 * (trow & 7))) << 4));
+            if (qw + trow < len) *reinterpret_cast<uint4_t*>(qbase + (int64_t)trow * sq) = w;
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const uint4_t w = __builtin_bit_cast(uint4_t, bq[n][ks]);
             RPO_FW_Q_TO_ACC(n, ks, w);
         }
-    }
     // loop-invariant per-lane LDS addresses (slot 0 of either ring; the statements add the slot as an immediate): K rows of k-step ks
     // (row fr, chunk (4 ks + g) ^ 2 (fr & 7)), V^T blocks of hd tile c (row 4 g + qq, chunk (2 c + (pp >> 1)) ^ 2 (4 (g & 1) + qq))
     const int qq = fr >> 2, pp = fr & 3;

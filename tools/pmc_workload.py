@@ -167,6 +167,7 @@ def attention(tag, nh, nkv, hd, N, L, seed):
     rope = (fr.cos().contiguous(), fr.sin().contiguous())
     cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
     tiles = ops.attn_tile_table(lens, DEV, nh, nkv)
+    ft = ops.attn_fwd_tile_table(lens, DEV, nh, nkv, hd)               # head_dim 128: the one-wave forward's own list (what the encoder passes)
     kb = ops.ATTN_KEY_BLOCK if hd == 64 else ops.ATTN_KEY_BLOCK_HD128
     kt = ops.attn_key_tile_table(lens, DEV, nkv, kb)
     views = lambda t: (t[:, :nh * hd].unflatten(1, (nh, hd)), t[:, nh * hd:(nh + nkv) * hd].unflatten(1, (nkv, hd)),
@@ -177,9 +178,10 @@ def attention(tag, nh, nkv, hd, N, L, seed):
     def fwd():
         # (each call rotates q in place once more: a rotation keeps magnitudes, and traffic / time do not depend on the angle)
         qv, kv_, vv = views(qkv)
-        state["out"], state["lse"] = ops.flash_attn_varlen_fwd(qv, kv_, vv, cu, tiles, scale, rope=rope)
+        state["out"], state["lse"] = ops.flash_attn_varlen_fwd(qv, kv_, vv, cu, tiles if ft is None else ft, scale, rope=rope,
+                                                               q_block=128 if ft is None else 64)
     pairs = sum(n * (n + 1) // 2 for n in lens)
-    fwd_k = ["fa_fwd_kernel"] if hd == 64 else ["fa_fwd128_kernel"]
+    fwd_k = ["fa_fwd_kernel"] if hd == 64 else ["fa_fwd128w_kernel" if ft is not None else "fa_fwd128_kernel"]
     bwd_k = ["fa_bwd_dq_kernel", "fa_bwd_dkdv4_kernel"] if hd == 64 else ["fa_bwd_dq128_kernel", "fa_bwd_dkdv128_kernel"]
     shape = f"{len(lens)} sequences (filler included), T = {T}, {nh} q heads / {nkv} kv heads, head_dim {hd}, rotary folded in"
     # algorithmic bytes with the fold: q, k, v read + out, lse written, + the rotated q written back and the cos / sin rows read
