@@ -256,10 +256,10 @@ int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, c
  * arrives UN-rotated and is rotated IN PLACE (q is written!) by the block that owns each (128 queries x head) piece -- the same
  * arithmetic as rpo_rope -- so that the separate rotary pass only has the k heads left; k must arrive rotated (every query
  * block reads it).  The backward entry point reads the rotated q from memory.
- * q_block = the query rows one work-list entry stands for: 128 (0 means 128) for every head_dim, or 64 with head_dim 128 and
- * (num_heads / num_kv_heads) % 4 == 0: an entry is then 64 queries x the FOUR consecutive q heads that begin at the entry's head
- * (format 3: the head column, a multiple of 4; format 2: one launch block per (entry, group of 4 heads)), which share one kv head --
- * the one-wave-per-SIMD forward (fa_fwd128w_kernel); out must be 16-byte aligned and out_stride % 8 == 0 there.  Anything else:
+ * q_block = the query rows one work-list entry stands for: 128 (0 means 128), or 64 where (num_heads / num_kv_heads) % 4 == 0: an
+ * entry is then 64 queries x the FOUR consecutive q heads that begin at the entry's head (format 3: the head column, a multiple
+ * of 4; format 2: one launch block per (entry, group of 4 heads)), which share one kv head -- the one-wave-per-SIMD forward
+ * (fa_fwd128w_kernel / fa_fwd64w_kernel); out must be 16-byte aligned and out_stride % 8 == 0 there.  Anything else:
  * RPO_ERR_UNSUPPORTED.  The backward's query list stays a 128-row list either way. */
 int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
                        int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles, int64_t tile_cols,

@@ -802,342 +802,36 @@ __global__ __launch_bounds__(64 * WQ * HEADS, WQ * HEADS == 4 ? 2 : 1) void fa_f
 #else
 #include "attention_fwd128w_gen.inc"
 #endif
+#include "attention_fwd64w_gen.inc"                  // the same statements at head_dim 64 (macros RPO_FW64_*)
 #ifndef RPO_FW_EXP
 #define RPO_FW_EXP 0     // timing-only ablations: 2 no LDS-DMA staging inside the loop, 4 no barrier / ring wait
 #endif
 constexpr float kFwDefer = 8.0f;
 
-__global__ __launch_bounds__(256, 1) void fa_fwd128w_kernel(
-    const bf16_t* q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v, int64_t sq, int64_t sk,
-    int64_t sv, const int* __restrict__ cu, const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e,
-    float scale, bf16_t* __restrict__ o, int64_t so, float* __restrict__ lse, int64_t lse_seq_stride,
-    int64_t lse_head_stride, int lse_packed, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod,
-    bf16_t* q_rw) {
-#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
-    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts0, ts1, ts2, ts3, ts4, ts5;
-    RPO_STAMP(ts0);
-#define RPO_FWS(VAR) RPO_STAMP(VAR)
-#define RPO_FWS_ADD(I, A, B) st_acc[I] += (B) - (A)
-#else
-#define RPO_FWS(VAR)
-#define RPO_FWS_ADD(I, A, B)
-#endif
-    constexpr int BN = kFa128BN;
-    constexpr int kImg = BN * kFa128Row;                 // one 32-key K or V tile: 8 KiB
-    constexpr int kVRing = 4 * kImg;                     // K ring: slots 0-3 at byte 0; V ring: slots 0-3 at byte 32768
-    // + a 16-KiB region per wave (64 rows of 256 bytes, chunk ^= 2 (row & 7) like a K tile): its Q rows on the way in (whole rows by
-    // LDS-DMA, then fragment reads), its O rows on the way out (fragment writes, then whole-row stores).  Per-lane fragment loads /
-    // stores at a row stride touched 16 lines of 32-64 bytes each, and one wave per SIMD has nobody to hide that behind: the
-    // prologue and the epilogue were 12.4 k + 10.4 k of a block's ~103 k cycles
-    constexpr int kIo = 64 * kFa128Row;
-    __shared__ __attribute__((aligned(16))) char smem[8 * kImg + 4 * kIo];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, fr = lane & 15;
-    const FaTile ft = fa_tile(tiles, tcols);
-    if (ft.q0 >= (1 << 30)) return;
-    const int seq = ft.seq, q0 = ft.q0;
-    // the block's four waves take the SAME 64 queries of four consecutive q heads (one kv head: the staged K / V tile serves all
-    // four, half the K / V traffic per query row of a 128-query block) -- every wave walks the same number of key tiles.  (A block of
-    // 256 queries of one head, 64 per wave, idles its early waves through the last key tiles: 10.5 % of the wave-tiles on cfg 5's shape.)
-    const int h = (tcols == 3 ? ft.h : ft.h * 4) + wave, hk = h / (nh / nkv);
-    const int64_t t0 = cu[seq];
-    const int len = cu[seq + 1] - (int)t0;
-    const int qw = q0;
-    const int last_q = min(q0 + 63, len - 1);
-    const int nkt = last_q / BN + 1;                                          // key tiles the block walks
-    const int na = nkt;
-
-#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
-    unsigned long long ts6, ts7;
-    { int fence_ = len + nkt; asm volatile("" : "+s"(fence_)); }
-    RPO_FWS(ts6);
-    RPO_FWS_ADD(12, ts0, ts6);                           /* 12: tile entry and sequence bounds are here (two scalar round trips) */
-#endif
-    // staging: tile j's K rows go to K slot j % 4, its V rows to V slot j % 4; wave w carries pieces 2 w, 2 w + 1 (4 rows each) of
-    // either; lane l carries row 4 u + (l >> 4), physical chunk l & 15 = logical chunk (l & 15) ^ 2 (row & 7)
-    const int srow = lane >> 4;
-    const char* ksrc = reinterpret_cast<const char*>(k + t0 * sk + hk * kFa128HD);
-    const char* vsrc = reinterpret_cast<const char*>(v + t0 * sv + hk * kFa128HD);
-    const unsigned skb = (unsigned)sk * 2u, svb = (unsigned)sv * 2u;
-    auto stage = [&](const char* src, unsigned stride_b, int kt, int ring_off) {
-        char* base = smem + ring_off + (kt & 3) * kImg;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int u = 2 * wave + i;
-            const int trow = 4 * u + srow;
-            const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
-            const unsigned row = (unsigned)min(kt * BN + trow, len - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (row * stride_b + lchunk * 16)),
-                                             (__attribute__((address_space(3))) void*)(base + u * 1024), 16, 0, 0);
-        }
-    };
-    // Q: the wave's 64 rows (clamped to the sequence: the rows past its end are copies of its last one and are never stored) as
-    // sixteen 1-KiB LDS-DMA pieces, issued FIRST; the first K / V tiles behind them; the fragments are read once the wave's own
-    // pieces have landed (vmcnt: the tiles' twelve may still fly), rotated (rope_frag), written back, and parked in a[144:207]
-    // (the B operands of the S^T chains) for the whole kernel
-    char* const io = smem + 8 * kImg + wave * kIo;
-    {
-        const char* qsrc = reinterpret_cast<const char*>(q + t0 * sq + h * kFa128HD);
-        const unsigned sqb = (unsigned)sq * 2u;
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int trow = 4 * u + srow;
-            const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
-            const unsigned row = (unsigned)min(qw + trow, len - 1);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qsrc + ((size_t)row * sqb + lchunk * 16)),
-                                             (__attribute__((address_space(3))) void*)(io + u * 1024), 16, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (j < nkt) stage(ksrc, skb, j, 0);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-        if (j < nkt) stage(vsrc, svb, j, kVRing);
-    // rotary fold: the cos / sin rows of the lane's queries (clamped like the Q rows), 16 + 16 floats per query.  The loads of query
-    // tiles 0, 1 are issued HERE, under the DMA pieces' flight; those of tiles 2, 3 behind the Q fragments' arrival, under the rotation
-    // of the first two (all of them here would be 128 live registers: hipcc then parks values in the accumulator file this kernel owns)
-    float4_t rc[2][2][2], rs[2][2][2];
-    auto load_rot = [&](int n0) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int64_t tr = ((t0 + min(qw + 16 * (n0 + n) + fr, len - 1)) % rperiod) * (kFa128HD / 2) + 8 * g;
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    rc[n][ks][j] = *reinterpret_cast<const float4_t*>(rcos + tr + 32 * ks + 4 * j);
-                    rs[n][ks][j] = *reinterpret_cast<const float4_t*>(rsin + tr + 32 * ks + 4 * j);
-                }
-        }
-    };
-    if (rcos) load_rot(0);
-#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
-    RPO_FWS(ts7);
-    RPO_FWS_ADD(13, ts6, ts7);                           /* 13: Q pieces, first staging and the rotary rows ISSUED */
-#endif
-    RPO_FW_INIT_ACC();                                                    // O^T = l = 0 (144 register writes under the loads' latency)
-    const int staged0 = 2 * (min(nkt, 4) + min(nkt, 2));                  // K / V pieces this wave has in flight behind its Q pieces
-    if (staged0 == 12 && !rcos) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (staged0 == 12) asm volatile("s_waitcnt vmcnt(28)" ::: "memory");          // (+ the 16 rotary-table loads)
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    short8_t bq[4][4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-            bq[n][ks] = *reinterpret_cast<const short8_t*>(io + (16 * n + fr) * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4));
-#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
-    RPO_FWS(ts6);
-    RPO_FWS_ADD(14, ts7, ts6);                           /* 14: accumulators zeroed, Q pieces landed, fragments read */
-#endif
-    if (rcos) {
-        // rotate, put the rotated fragments back where they came from in the wave's LDS region, and write the 64 rows out whole
-        // (16 bytes per lane, 4 rows per instruction: the fragments themselves are 16 rows x 64 bytes per store instruction)
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float4_t c_[2][2][2], s_[2][2][2];
-#pragma unroll
-            for (int n = 0; n < 2; ++n)
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) { c_[n][ks][j] = rc[n][ks][j]; s_[n][ks][j] = rs[n][ks][j]; }
-            if (half == 0) load_rot(2);                                   // (in flight under the rotation of tiles 0, 1)
-#pragma unroll
-            for (int n = 0; n < 2; ++n) {
-                const int nn = 2 * half + n;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
-                    rope_frag(bq[nn][ks], bq[nn][ks + 2], c_[n][ks][0], c_[n][ks][1], s_[n][ks][0], s_[n][ks][1]);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    *reinterpret_cast<short8_t*>(io + (16 * nn + fr) * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4)) = bq[nn][ks];
-            }
-        }
-        bf16_t* qbase = q_rw + (t0 + qw) * sq + h * kFa128HD + 8 * (lane & 15);
-        int srow_q = lane >> 4;
-        asm volatile("" : "+v"(srow_q));                 // (re-derived: see the epilogue)
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int trow = 4 * u + srow_q;
-            const uint4_t w = *reinterpret_cast<const uint4_t*>(io + trow * kFa128Row + (((lane & 15) ^ (2 * (trow & 7))) << 4));
-            if (qw + trow < len) *reinterpret_cast<uint4_t*>(qbase + (int64_t)trow * sq) = w;
-        }
-    }
-#pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const uint4_t w = __builtin_bit_cast(uint4_t, bq[n][ks]);
-            RPO_FW_Q_TO_ACC(n, ks, w);
-        }
-    // loop-invariant per-lane LDS addresses (slot 0 of either ring; the statements add the slot as an immediate): K rows of k-step ks
-    // (row fr, chunk (4 ks + g) ^ 2 (fr & 7)), V^T blocks of hd tile c (row 4 g + qq, chunk (2 c + (pp >> 1)) ^ 2 (4 (g & 1) + qq))
-    const int qq = fr >> 2, pp = fr & 3;
-    const int vsw = 2 * (4 * (g & 1) + qq);
-    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned trv[8], krow[4];
-#pragma unroll
-    for (int c = 0; c < 8; ++c)
-        trv[c] = smem_base + kVRing + (4 * g + qq) * kFa128Row + (((2 * c + (pp >> 1)) ^ vsw) << 4) + 8 * (pp & 1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) krow[ks] = smem_base + fr * kFa128Row + (((4 * ks + g) ^ (2 * (fr & 7))) << 4);
-    // the wave's two K pieces and two V pieces inside a 32-key tile: row 4 u + srow, logical chunk (l & 15) ^ 2 (row & 7): byte offsets
-    // from the tile's first row (rows past the sequence end exist only in its LAST tile, which hipcc's `stage` loads with the clamp)
-    unsigned pk[2], pv[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int trow = 4 * (2 * wave + i) + srow;
-        const unsigned lchunk = (unsigned)((lane & 15) ^ (2 * (trow & 7)));
-        pk[i] = (unsigned)trow * skb + lchunk * 16;
-        pv[i] = (unsigned)trow * svb + lchunk * 16;
-        asm volatile("" : "+v"(pk[i]), "+v"(pv[i]));
-    }
-#pragma unroll
-    for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(trv[c]));          // (kept as eight registers: no arithmetic inside the loop)
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) asm volatile("" : "+v"(krow[ks]));
-
-    auto needs_mask = [&](int j) { return (j * BN + BN - 1 > qw) || (j * BN + BN > len); };
-#define RPO_FW_MASK(GEN, J)                                                                                        \
-    do {                                                                                                           \
-        const int k0_ = (J) * BN;                                                                                  \
-        const int d0_ = min(qw + fr, len - 1) - k0_ - 4 * g, d1_ = min(qw + 16 + fr, len - 1) - k0_ - 4 * g;       \
-        const int d2_ = min(qw + 32 + fr, len - 1) - k0_ - 4 * g, d3_ = min(qw + 48 + fr, len - 1) - k0_ - 4 * g;  \
-        RPO_FW_MASK_##GEN(d0_, d1_, d2_, d3_);                                                                     \
-    } while (0)
-#define RPO_FW_CHECK(GEN, GROW)                                                                                    \
-    do {                                                                                                           \
-        if (__builtin_amdgcn_ballot_w64((GROW) > kFwDefer) != 0) RPO_FW_RESCALE_##GEN();                           \
-    } while (0)
-
-    // from here on v[64:227] and a[0:207] belong to the generated statements (hipcc's own code above used some of them)
-    RPO_FWS(ts1);
-    RPO_FWS_ADD(9, ts0, ts1);                            /* 9: Q loads, staging of the first tiles, rope, Q -> accumulator file */
-    RPO_FW_INIT();
-    RPO_FWS(ts2);
-    RPO_FWS_ADD(10, ts1, ts2);                           /* 10: INIT */
-    // everything issued so far has landed (Q loads, K tiles 0-3, V tiles 0-1); then everybody's has
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    RPO_FWS(ts1);
-    RPO_FWS_ADD(11, ts2, ts1);                           /* 11: first tiles landed + barrier */
-    float grow = 0.f;
-    if (na > 0) {
-        RPO_FW_KREAD(krow[0], krow[1], krow[2], krow[3]);                        // tile 0 (K slot 0)
-        RPO_FW_SCHAIN_A();
-        if (needs_mask(0)) RPO_FW_MASK(A, 0);
-        RPO_FW_FIRST_A(krow[0], krow[1], krow[2], krow[3], scale_log2e);         // tile 0's scale and exponents, tile 1's K rows (slot 1)
-    }
-    // one iteration: tile kt's exponentials + tile kt + 1's chains, then tile kt's products + tile kt + 1's maximum
-#define RPO_FW_ITER(S, NXT, KT)                                                                                    \
-    do {                                                                                                           \
-        const int kt_ = (KT);                                                                                      \
-        RPO_FWS(ts1);                                                                                              \
-        if (kt_ > 0 && !(RPO_FW_EXP & 4)) {                                                                        \
-            /* K(kt + 2) and V(kt) landed (both staged two iterations ago); the previous iteration's four pieces may fly */ \
-            if (kt_ + 3 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                                    \
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                  \
-            RPO_FWS(ts2);                                                                                          \
-            RPO_FWS_ADD(0, ts1, ts2);                                     /* 0: wait for the ring */                \
-            __builtin_amdgcn_s_barrier();                                                                          \
-            RPO_FWS(ts3);                                                                                          \
-            RPO_FWS_ADD(1, ts2, ts3);                                     /* 1: barrier */                          \
-        }                                                                                                          \
-        RPO_FWS(ts2);                                                                                              \
-        /* K(kt + 4) goes to the K slot of tile kt (read two iterations ago), V(kt + 2) to the V slot of tile kt - 2: INSIDE the  */ \
-        /* stream (P2D) when both tiles lie wholly inside the sequence (no row clamp) and every wave of the block runs P2, else     */ \
-        /* by hipcc's `stage` here, behind the barrier                                                                            */ \
-        const bool instream_ = !(RPO_FW_EXP & 2) && (kt_ + 5) * BN <= len && kt_ + 4 < nkt && kt_ + 1 < na;      \
-        if (!(RPO_FW_EXP & 2) && !instream_) {                                                                     \
-            if (kt_ + 4 < nkt) stage(ksrc, skb, kt_ + 4, 0);                                                       \
-            if (kt_ + 2 < nkt) stage(vsrc, svb, kt_ + 2, kVRing);                                                  \
-        }                                                                                                          \
-        RPO_FWS(ts3);                                                                                              \
-        RPO_FWS_ADD(2, ts2, ts3);                                         /* 2: hipcc's staging (when not in-stream) */ \
-        if (kt_ < na) {                                                                                            \
-            if (kt_ + 1 < na) {                                                                                    \
-                RPO_FW_P1_S##S(trv[0], trv[1], trv[2], trv[3], trv[4], trv[5], trv[6], trv[7], scale_log2e);       \
-                RPO_FWS(ts4);                                                                                      \
-                RPO_FWS_ADD(3, ts3, ts4);                                 /* 3: P1 */                               \
-                if (needs_mask(kt_ + 1)) RPO_FW_MASK(NXT, kt_ + 1);                                                \
-                RPO_FWS(ts5);                                                                                      \
-                RPO_FWS_ADD(4, ts4, ts5);                                 /* 4: mask */                             \
-                if (instream_) {                                                                                   \
-                    const char* sk_ = ksrc + (size_t)(kt_ + 4) * BN * skb;                                         \
-                    const char* sv_ = vsrc + (size_t)(kt_ + 2) * BN * svb;                                         \
-                    const unsigned mk_ = smem_base + (kt_ & 3) * kImg + 2 * wave * 1024;                           \
-                    const unsigned mv_ = smem_base + kVRing + ((kt_ + 2) & 3) * kImg + 2 * wave * 1024;            \
-                    RPO_FW_P2D_S##S(grow, krow[0], krow[1], krow[2], krow[3], scale_log2e, pk[0], pk[1], pv[0], pv[1], sk_, sv_, \
-                                    mk_, mv_);                                                                     \
-                } else {                                                                                           \
-                    RPO_FW_P2_S##S(grow, krow[0], krow[1], krow[2], krow[3], scale_log2e);                         \
-                }                                                                                                  \
-                RPO_FW_CHECK(NXT, grow);                                                                           \
-                RPO_FWS(ts4);                                                                                      \
-                RPO_FWS_ADD(5, ts5, ts4);                                 /* 5: P2 + rescale check */               \
-                RPO_FWS_ADD(7, 0, 1);                                     /* 7: full iterations */                  \
-            } else {                                                                                               \
-                RPO_FW_P1L_S##S(trv[0], trv[1], trv[2], trv[3], trv[4], trv[5], trv[6], trv[7], scale_log2e);      \
-                RPO_FW_P2L();                                                                                      \
-            }                                                                                                      \
-        }                                                                                                          \
-    } while (0)
-    RPO_FWS(ts1);
-    RPO_FWS_ADD(6, ts0, ts1);                            /* 6: the block's prologue */
-    for (int kt = 0; kt < nkt; kt += 4) {
-        RPO_FW_ITER(0, B, kt);
-        if (kt + 1 < nkt) RPO_FW_ITER(1, A, kt + 1);
-        if (kt + 2 < nkt) RPO_FW_ITER(2, B, kt + 2);
-        if (kt + 3 < nkt) RPO_FW_ITER(3, A, kt + 3);
-    }
-#undef RPO_FW_ITER
-#undef RPO_FW_MASK
-#undef RPO_FW_CHECK
-    RPO_FWS(ts4);
-    // ---- epilogue: O[q][16c + 4g + r] = O^T / l into the wave's LDS region (8 bytes per lane and fragment), whole rows out of it
-    // (16 bytes per lane, 4 rows per instruction);  lse = mc ln 2 + ln l  (mc = maximum x scale log2e)
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int qi = qw + 16 * n + fr;
-        float l, mc;
-        RPO_FW_READ_LM(n, l, mc);
-        const float inv = 1.0f / l;
-        char* lrow = io + (16 * n + fr) * kFa128Row + 8 * (g & 1);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            float x0, x1, x2, x3;
-            RPO_FW_READ_O(c, n, x0, x1, x2, x3);
-            uint2_t w;
-            w.x = pack_bf16(x0 * inv, x1 * inv);
-            w.y = pack_bf16(x2 * inv, x3 * inv);
-            *reinterpret_cast<uint2_t*>(lrow + (((2 * c + (g >> 1)) ^ (2 * (fr & 7))) << 4)) = w;
-        }
-        if (g == 0 && qi < len && na > 0)
-            lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
-                mc * 0.6931471805599453f + logf(l);
-    }
-    if (na > 0) {
-        bf16_t* obase = o + (t0 + qw) * so + h * kFa128HD + 8 * (lane & 15);
-        int srow_e = lane >> 4;
-        asm volatile("" : "+v"(srow_e));                 // (re-derived here: the prologue's sixteen row numbers would otherwise be kept -- spilled -- across the whole kernel)
-#pragma unroll
-        for (int u = 0; u < 16; ++u) {
-            const int trow = 4 * u + srow_e;
-            const uint4_t w = *reinterpret_cast<const uint4_t*>(io + trow * kFa128Row + (((lane & 15) ^ (2 * (trow & 7))) << 4));
-            if (qw + trow < len) *reinterpret_cast<uint4_t*>(obase + (int64_t)trow * so) = w;
-        }
-    }
-#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    RPO_FWS(ts5);
-    RPO_FWS_ADD(8, ts4, ts5);                            /* 8: epilogue, stores landed */
-    if (lane == 0)
-        for (int i = 0; i < 16; ++i) atomicAdd(&g_fa_stamp[wave * 16 + i], st_acc[i]);
-#endif
-}
+#define FWW_HD 128
+#define FWW(X) RPO_FW_##X
+#define FWW_KERNEL fa_fwd128w_kernel
+#define FWW_TRS trv[0], trv[1], trv[2], trv[3], trv[4], trv[5], trv[6], trv[7]
+#define FWW_KRS krow[0], krow[1], krow[2], krow[3]
+#include "attention_fwdw_kernel.inc"
+#undef FWW_HD
+#undef FWW
+#undef FWW_KERNEL
+#undef FWW_TRS
+#undef FWW_KRS
+// head_dim 64 (round 5): the same kernel source; 4-KiB images (rings of 16 + 16 KiB), 8-KiB Q / O regions, two DMA pieces per wave
+// and tile.  Half the matrix work per exponential: 16 + 20 MFMAs per tile around the same 32 exponentials per lane.
+#define FWW_HD 64
+#define FWW(X) RPO_FW64_##X
+#define FWW_KERNEL fa_fwd64w_kernel
+#define FWW_TRS trv[0], trv[1], trv[2], trv[3]
+#define FWW_KRS krow[0], krow[1]
+#include "attention_fwdw_kernel.inc"
+#undef FWW_HD
+#undef FWW
+#undef FWW_KERNEL
+#undef FWW_TRS
+#undef FWW_KRS
 
 // ------------------------------------------------------------------------------------------------------------------
 // Backward.  Two launches, no atomics, deterministic:
@@ -4273,8 +3967,8 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
     // consecutive q heads that start at the entry's head (format 2: head = 4 x the launch's y index), all of one kv head:
     // fa_fwd128w_kernel, one wave per SIMD
     if (q_block == 0) q_block = 128;
-    if (q_block != 128 && !(q_block == 64 && head_dim == kFa128HD && num_kv_heads > 0 && num_heads % num_kv_heads == 0 &&
-                            (num_heads / num_kv_heads) % 4 == 0))
+    if (q_block != 128 && !(q_block == 64 && (head_dim == kFa128HD || head_dim == kFaHD) && num_kv_heads > 0 &&
+                            num_heads % num_kv_heads == 0 && (num_heads / num_kv_heads) % 4 == 0))
         return RPO_ERR_UNSUPPORTED;
     // rope_cos / rope_sin (both or neither): q arrives UN-rotated and is rotated IN PLACE by the block that owns it (k must
     // arrive rotated: every query block reads it)
@@ -4305,6 +3999,15 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
 #endif
     if (head_dim == kFa128HD && tile_cols != 3) grid.y = (unsigned)(num_heads / RPO_F128_HEADS);
 #define RPO_F128_KERNEL fa_fwd128_kernel<RPO_F128_WQ, RPO_F128_HEADS, RPO_F128_SUB, RPO_F128_KF>
+    if (q_block == 64 && head_dim == kFaHD) {
+        if (tile_cols != 3) grid.y = (unsigned)(num_heads / 4);
+        RPO_LAUNCH(fa_fwd64w_kernel, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
+                   k_stride, v_stride, cu_seqlens, tiles, (int)tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale,
+                   (bf16_t*)out, out_stride, lse, lse_max_len > 0 ? num_heads * lse_max_len : 0,
+                   lse_max_len > 0 ? lse_max_len : total_tokens, lse_max_len > 0 ? 0 : 1, rope_cos, rope_sin, rope_period,
+                   (bf16_t*)const_cast<void*>(q));
+        return rpo_launch_status();
+    }
     if (q_block == 64) {
         if (tile_cols != 3) grid.y = (unsigned)(num_heads / 4);
         RPO_LAUNCH(fa_fwd128w_kernel, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,

@@ -186,8 +186,9 @@ class RopeTables:
 FOLD_ROPE = 2        # packed training path: rotary + attention as ONE autograd node; 2 = q rotated by the attention forward block
 #                      that loads it + inverse rotary in the dQ / dK epilogues, 1 = the epilogues only, 0 = two nodes with
 #                      separate rpo_rope passes both ways (the A/B arms of `bench.py --fold-rope`)
-FWD128_ONE_WAVE = True   # head_dim 128 with 4 q heads per kv head: the forward walks its own list (64 queries x 4 heads per entry) with
-#                          the one-wave-per-SIMD kernel; False: the 128-query kernel of rounds 3-4 (the A/B arm of `bench.py --fwd128 classic`)
+FWD128_ONE_WAVE = True   # head_dim 128 with 4 (8, ..) q heads per kv head: the forward walks its own list (64 queries x 4 heads per entry)
+#                          with the one-wave-per-SIMD kernel (ops.FWD_ONE_WAVE_HEAD_DIMS names the head dims); False: the 128-query kernel
+#                          of rounds 3-4 (the A/B arm of `bench.py --fwd128 classic`)
 
 
 class VarlenCtx:

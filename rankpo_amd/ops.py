@@ -654,12 +654,21 @@ def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, blo
     return torch.from_numpy(np.concatenate(out, 0)).to(device, non_blocking=True)
 
 
-def attn_fwd_tile_table(lens, device, num_heads: int, num_kv_heads: int, head_dim: int):
-    """The FORWARD kernel's own work list where it has one: head_dim 128 with a multiple of 4 q heads per kv head -> entries of 64
-    queries x 4 q heads (`attn_tile_table(..., block_m=64, heads_per_block=4)`; pass it as `fwd_tiles`, the forward then runs with
-    q_block = 64); otherwise None (the forward walks the 128-row list the dQ kernel walks)."""
+# head dims whose forward runs the one-wave-per-SIMD kernel by default where the head grouping allows.  The kernel exists for 64 as
+# well (same source, fa_fwd64w_kernel; tests cover it) and LOSES there: 0.280 against 0.313 of the MFMA peak for fa_fwd_kernel on
+# the cfg-2 passage batch (same run) -- head_dim 64 has half the matrix work per exponential, its loop is bound by the vector
+# instructions' issue slots, and a second wave per SIMD fills what one wave leaves at barriers and LDS waits
+# (profiles/r05_fa_fwd128w_ladder.md).
+FWD_ONE_WAVE_HEAD_DIMS = (128,)
+
+
+def attn_fwd_tile_table(lens, device, num_heads: int, num_kv_heads: int, head_dim: int, force: bool = False):
+    """The FORWARD kernel's own work list where it has one: a head_dim of FWD_ONE_WAVE_HEAD_DIMS (force: 64 or 128) with a multiple
+    of 4 q heads per kv head -> entries of 64 queries x 4 q heads (`attn_tile_table(..., block_m=64, heads_per_block=4)`; pass it as
+    `fwd_tiles`, the forward then runs with q_block = 64: the one-wave-per-SIMD kernels); otherwise None (the forward walks the
+    128-row list the dQ kernel walks)."""
     H = num_kv_heads if num_kv_heads > 0 else num_heads
-    if head_dim != 128 or num_heads <= 0 or num_heads % H or (num_heads // H) % 4:
+    if head_dim not in ((64, 128) if force else FWD_ONE_WAVE_HEAD_DIMS) or num_heads <= 0 or num_heads % H or (num_heads // H) % 4:
         return None
     return attn_tile_table(lens, device, num_heads, num_kv_heads, block_m=64, heads_per_block=4)
 
@@ -675,8 +684,8 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
     """q [T, nh, hd], k / v [T, nkv, hd], hd = 64 or 128 (last two dims contiguous, token stride free); returns
     (out [T, nh, hd] bf16, lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0).  rope = (cos, sin),
     f32 [period, hd / 2]: q arrives UN-rotated and the kernel rotates it IN PLACE (k must arrive rotated), see the header.
-    q_block = the query rows per entry of `tiles`: 128, or 64 for a list from `attn_fwd_tile_table` (head_dim 128, entries of
-    64 queries x 4 q heads: the one-wave-per-SIMD forward)."""
+    q_block = the query rows per entry of `tiles`: 128, or 64 for a list from `attn_fwd_tile_table` (entries of 64 queries x 4 q
+    heads: the one-wave-per-SIMD forward)."""
     lib = _lib.load()
     if rope is not None:
         _check_rope_tables(rope, q.shape[-1], "flash_attn_varlen_fwd")

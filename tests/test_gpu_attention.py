@@ -370,17 +370,18 @@ def test_flash_attn_fwd_head_dim_128(lens, nh, nkv, fused):
         ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, ops.attn_key_tile_table(lens, DEV, nkv), scale, key_block=256)
 
 
+@pytest.mark.parametrize("hd", [128, 64])
 @pytest.mark.parametrize("lens,nh,nkv,fused", [
     ([128], 4, 1, False), ([1], 4, 1, False), ([64, 1, 200, 129, 33, 31, 32, 65, 63], 8, 2, False),
     ([300, 17, 513, 128, 256, 5], 8, 1, True), ([1000, 777], 4, 1, True), ([4096, 2500], 32, 8, True)])
-def test_flash_attn_fwd_head_dim_128_one_wave(lens, nh, nkv, fused):
-    """fa_fwd128w_kernel (q_block = 64: entries of 64 queries x the 4 q heads of a group, one wave per SIMD, deferred softmax
-    scale, Q in / O out through LDS as whole rows) against the f32 reference and against the 128-query kernel, on both list
-    formats, the padded-lse layout, strided (fused-projection) views, the rotary fold, and through autograd with the
+def test_flash_attn_fwd_one_wave(lens, nh, nkv, fused, hd):
+    """fa_fwd128w_kernel / fa_fwd64w_kernel (q_block = 64: entries of 64 queries x the 4 q heads of a group, one wave per SIMD,
+    deferred softmax scale, Q in / O out through LDS as whole rows) against the f32 reference and against the 128-query kernel,
+    on both list formats, the padded-lse layout, strided (fused-projection) views, the rotary fold, and through autograd with the
     hand-written backward (which walks the 128-row list)."""
     from rankpo_amd import ops
-    torch.manual_seed(sum(lens) + 7)
-    T, hd = sum(lens), 128
+    torch.manual_seed(sum(lens) + 7 + hd)
+    T = sum(lens)
     if fused:
         qkv = torch.randn(T, (nh + 2 * nkv) * hd, device=DEV).to(torch.bfloat16)
         q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], -1)
@@ -394,7 +395,7 @@ def test_flash_attn_fwd_head_dim_128_one_wave(lens, nh, nkv, fused):
     ro, rl = ref_attention(q, k, v, lens, scale)
     t128 = ops.attn_tile_table(lens, DEV, nh, nkv)
     oc, lc = ops.flash_attn_varlen_fwd(q, k, v, cu, t128, scale)                       # the 128-query kernel
-    ft = ops.attn_fwd_tile_table(lens, DEV, nh, nkv, hd)
+    ft = ops.attn_fwd_tile_table(lens, DEV, nh, nkv, hd, force=True)
     assert ft is not None and ft.shape[1] == 3 and ft.shape[0] % 8 == 0
     outs = []
     for tiles in (ops.attn_tile_table(lens, DEV, block_m=64), ft):                     # format 2 (grid.y = head groups), format 3
@@ -419,31 +420,33 @@ def test_flash_attn_fwd_head_dim_128_one_wave(lens, nh, nkv, fused):
     assert torch.equal(qa, qb) and not torch.equal(qa, q.contiguous())
     assert (o_a.float() - o_b.float()).abs().max() <= 2.0 ** -6 and (l_a - l_b).abs().max() < 3e-3
     # autograd: one-wave forward + the hand-written backward on its own 128-row list
-    kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=ops.ATTN_KEY_BLOCK_HD128)
+    kb = ops.ATTN_KEY_BLOCK_HD128 if hd == 128 else ops.ATTN_KEY_BLOCK
+    kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=kb)
     go = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
     qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
     ref_attention(qr, kr, vr, lens, scale)[0].backward(go.float())
     qg, kg, vg = (t.detach().clone().requires_grad_(True) for t in (q, k, v))
-    og = ops.flash_attn_varlen(qg, kg, vg, cu, t128, max(lens), scale, k_tiles=kt, key_block=ops.ATTN_KEY_BLOCK_HD128, fwd_tiles=ft)
+    og = ops.flash_attn_varlen(qg, kg, vg, cu, t128, max(lens), scale, k_tiles=kt, key_block=kb, fwd_tiles=ft)
     assert torch.equal(og, out)
     og.backward(go)
     for name, a, b in (("dq", qg.grad, qr.grad), ("dk", kg.grad, kr.grad), ("dv", vg.grad, vr.grad)):
         assert (a.float() - b).abs().max() < 0.03 * max(1.0, b.abs().max().item()), name
 
 
-def test_flash_attn_fwd128_one_wave_rescales_and_refusals():
+@pytest.mark.parametrize("hd", [128, 64])
+def test_flash_attn_fwd_one_wave_rescales_and_refusals(hd):
     """The deferred scale: logits that keep growing along the sequence (every few tiles some row outgrows 2^8 times its scale: the
     RESCALE statements of both score generations run, many times) and logits far below zero (the scale starts at tile 0's row
     maximum, not at 0) still match the f32 reference; what the kernel is not built for is refused, not mis-run."""
     from rankpo_amd import ops
     from rankpo_amd._lib import RankPOHipError
     torch.manual_seed(5)
-    nh, nkv, hd = 8, 2, 128
+    nh, nkv = 8, 2
     lens = [1500, 700, 96]
     T = sum(lens)
     cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
     scale = 1.0 / math.sqrt(hd)
-    ft = ops.attn_fwd_tile_table(lens, DEV, nh, nkv, hd)
+    ft = ops.attn_fwd_tile_table(lens, DEV, nh, nkv, hd, force=True)
     pos = torch.cat([torch.arange(n, dtype=torch.float32) for n in lens]).to(DEV)
     base = torch.randn(T, nkv, hd, device=DEV)
     q = (torch.randn(T, nh, hd, device=DEV) * 2.0 + 1.5).to(torch.bfloat16)            # a common component: <q, k> grows with |k|
@@ -451,18 +454,16 @@ def test_flash_attn_fwd128_one_wave_rescales_and_refusals():
     for name, k in (("growing", ((base * 0.3 + 0.4) * (1.0 + pos / 60.0)[:, None, None]).to(torch.bfloat16)),
                     ("negative", (base * 0.2 - 3.0).to(torch.bfloat16))):
         ro, rl = ref_attention(q, k, v, lens, scale)
-        assert (rl.max() - rl.min()).item() > 50 or rl.max().item() < -20, name          # the logits really leave the easy range
+        assert (rl.max() - rl.min()).item() > 50 or rl.max().item() < -5, name          # the logits really leave the easy range
         out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, ft, scale, q_block=64)
         assert (out.float() - ro).abs().max() < 2.5e-2, name
         assert ((lse - rl).abs() / rl.abs().clamp(min=1.0)).max() < 2e-3, name
     # refusals
-    assert ops.attn_fwd_tile_table(lens, DEV, 8, 4, 128) is None and ops.attn_fwd_tile_table(lens, DEV, 8, 2, 64) is None
+    assert ops.attn_fwd_tile_table(lens, DEV, 8, 4, hd, force=True) is None and ops.attn_fwd_tile_table(lens, DEV, 8, 2, 96, force=True) is None
     k = base.to(torch.bfloat16)
     with pytest.raises(RankPOHipError, match="status -2"):                               # 2 q heads per kv head
         ops.flash_attn_varlen_fwd(q, torch.randn(T, 4, hd, device=DEV).to(torch.bfloat16),
                                   torch.randn(T, 4, hd, device=DEV).to(torch.bfloat16), cu, ft, scale, q_block=64)
-    with pytest.raises(RankPOHipError, match="status -2"):                               # head_dim 64
-        ops.flash_attn_varlen_fwd(q[..., :64].contiguous(), k[..., :64].contiguous(), v[..., :64].contiguous(), cu, ft, 0.125, q_block=64)
     with pytest.raises(RankPOHipError, match="status -2"):
         ops.flash_attn_varlen_fwd(q, k, v, cu, ft, scale, q_block=32)
 

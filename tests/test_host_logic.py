@@ -554,8 +554,10 @@ def test_query_tile_table_properties():
     ft = ops.attn_fwd_tile_table([300, 64], "cpu", 32, 8, 128)
     assert ft is not None and torch.equal(ft, ops.attn_tile_table([300, 64], "cpu", 32, 8, block_m=64, heads_per_block=4))
     assert ops.attn_fwd_tile_table([300], "cpu", 16, 2, 128) is not None                  # 8 per kv head: two entries per tile
-    for nh, nkv, hd in ((32, 8, 64), (32, 16, 128), (12, 12, 128), (6, 2, 128)):
-        assert ops.attn_fwd_tile_table([300], "cpu", nh, nkv, hd) is None
+    assert ops.attn_fwd_tile_table([300], "cpu", 32, 8, 64) is None                       # head_dim 64: the kernel exists, and loses
+    assert ops.attn_fwd_tile_table([300], "cpu", 32, 8, 64, force=True) is not None
+    for nh, nkv, hd in ((32, 8, 96), (32, 16, 128), (12, 12, 128), (6, 2, 64)):
+        assert ops.attn_fwd_tile_table([300], "cpu", nh, nkv, hd, force=True) is None
 
 
 def test_rotary_frequencies_survive_a_dtype_cast():
@@ -827,15 +829,17 @@ def test_generated_dkdv128_bodies_are_in_sync():
 
 
 def test_generated_fwd128w_statements_are_in_sync():
-    """rankpo_amd/csrc/attention_fwd128w_gen.inc (the hand-placed statements of fa_fwd128w_kernel, the one-wave-per-SIMD head_dim-128
-    forward) is generated text: it must be what tools/gen/gen_fwd128w_body.py emits today (edit the generator, not the file)."""
+    """rankpo_amd/csrc/attention_fwd128w_gen.inc / attention_fwd64w_gen.inc (the hand-placed statements of fa_fwd128w_kernel /
+    fa_fwd64w_kernel, the one-wave-per-SIMD forwards) are generated text: they must be what tools/gen/gen_fwd128w_body.py emits
+    today (edit the generator, not the files)."""
     import subprocess
     import sys
     root = os.path.join(os.path.dirname(__file__), "..")
     env = {k: v for k, v in os.environ.items() if not k.startswith("GEN_")}
-    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_fwd128w_body.py")], capture_output=True,
-                         text=True, check=True, env=env).stdout
-    assert gen == open(os.path.join(root, "rankpo_amd", "csrc", "attention_fwd128w_gen.inc")).read()
+    for hd in (128, 64):
+        gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_fwd128w_body.py"), str(hd)], capture_output=True,
+                             text=True, check=True, env=env).stdout
+        assert gen == open(os.path.join(root, "rankpo_amd", "csrc", f"attention_fwd{hd}w_gen.inc")).read(), hd
 
 
 def test_no_valu_reads_a_transcendental_result_in_the_next_slot(tmp_path):
@@ -869,14 +873,15 @@ def _check_fwd128w_register_ownership(attention_s, root):
     C = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(C)
     isa = open(attention_s).read()
-    rep = C.check(isa)
-    assert rep["ok"], rep["problems"][:10]
-    assert rep["checked"] >= 1000 and rep["statements"] >= 100, rep      # the loop's own code and the statements were really seen
-    body = "\n".join(C.kernel_body(isa)[0])
-    at = body.rindex("s_barrier")                                         # hipcc's code at the top of a key-tile iteration
-    for planted in ("v_mov_b32_e32 v100, v1", "v_accvgpr_read_b32 v1, a17"):
-        bad = C.check(isa.replace(body, body[:at] + "s_barrier\n\t" + planted + "\n" + body[at + len("s_barrier"):]))
-        assert not bad["ok"] and planted in " ".join(bad["problems"]), bad
+    for kern in ("fa_fwd128w_kernel", "fa_fwd64w_kernel"):
+        rep = C.check(isa, kern)
+        assert rep["ok"], (kern, rep["problems"][:10])
+        assert rep["checked"] >= 1000 and rep["statements"] >= 100, rep  # the loop's own code and the statements were really seen
+        body = "\n".join(C.kernel_body(isa, kern)[0])
+        at = body.rindex("s_barrier")                                     # hipcc's code at the top of a key-tile iteration
+        for planted in ("v_mov_b32_e32 v100, v1", "v_accvgpr_read_b32 v1, a17"):
+            bad = C.check(isa.replace(body, body[:at] + "s_barrier\n\t" + planted + "\n" + body[at + len("s_barrier"):]), kern)
+            assert not bad["ok"] and planted in " ".join(bad["problems"]), (kern, bad)
 
 
 def _check_dkdv_prefetch_registers(attention_s, root):

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Checks what fa_fwd128w_kernel (head_dim-128 forward, one wave per SIMD) relies on but hipcc cannot know: its asm statements own
+"""Checks what fa_fwd128w_kernel / fa_fwd64w_kernel (attention forward, one wave per SIMD) rely on but hipcc cannot know: its asm statements own
 LITERAL registers -- v[64:227] from RPO_FW_INIT on and the accumulator file from RPO_FW_INIT_ACC on -- which hipcc only sees in the
 statements' clobber lists.  In the kernel's ISA, OUTSIDE the ASMSTART / ASMEND brackets:
 
@@ -10,7 +10,7 @@ statements' clobber lists.  In the kernel's ISA, OUTSIDE the ASMSTART / ASMEND b
  (3) the kernel uses no scratch.
 
 usage: python tools/check_fwd128w_isa.py <attention.s>
-Importable: `check(isa_text)` -> report dict with `ok`, `problems` and the counts the test pins.
+Importable: `check(isa_text, kernel_name)` -> report dict with `ok`, `problems` and the counts the test pins.
 """
 import re
 import sys
@@ -40,8 +40,8 @@ def _names_owned_vgpr(t):
     return False
 
 
-def check(isa):
-    body, tail = kernel_body(isa)
+def check(isa, name="fa_fwd128w_kernel"):
+    body, tail = kernel_body(isa, name)
     init_at = next((i for i, l in enumerate(body) if INIT_MARK in l), None)
     acc_at = next((i for i, l in enumerate(body) if ACC_MARK in l), None)
     problems = []
@@ -75,9 +75,13 @@ def check(isa):
 
 
 if __name__ == "__main__":
-    rep = check(open(sys.argv[1]).read())
-    print("fa_fwd128w_kernel: %d instructions of hipcc's behind RPO_FW_INIT_ACC checked, %d asm statements: %s"
-          % (rep["checked"], rep["statements"], "ok" if rep["ok"] else "FAILED"))
-    for p in rep["problems"][:20]:
-        print("  ", p)
-    sys.exit(0 if rep["ok"] else 1)
+    isa_ = open(sys.argv[1]).read()
+    rc = 0
+    for kern in ("fa_fwd128w_kernel", "fa_fwd64w_kernel"):            # one source (attention_fwdw_kernel.inc), two statement sets
+        rep = check(isa_, kern)
+        print("%s: %d instructions of hipcc's behind RPO_FW_INIT_ACC checked, %d asm statements: %s"
+              % (kern, rep["checked"], rep["statements"], "ok" if rep["ok"] else "FAILED"))
+        for p in rep["problems"][:20]:
+            print("  ", p)
+        rc |= 0 if rep["ok"] else 1
+    sys.exit(rc)

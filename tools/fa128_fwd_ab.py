@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Same-process A/B of builds of librankpo_hip.so on the head_dim-128 attention FORWARD (C ABI, cfg 5's shape: 24 sequences of
-2048..4096 tokens, 32 / 8 heads), each arm with the query-tile work list of ITS block size:
+"""Same-process A/B of builds of librankpo_hip.so on the attention FORWARD (C ABI; head_dim 128, cfg 5's shape: 24 sequences of
+2048..4096 tokens, 32 / 8 heads; HD=64 in the environment: 48 such sequences at head_dim 64), each arm with the query-tile work list of
+ITS block size (64x4 = the one-wave-per-SIMD kernel, q_block 64):
     python tools/fa128_fwd_ab.py name=path.so[:block_m] ...        (block_m 128 when omitted; the in-tree build is always arm 0)
 Interleaved rounds, median per arm, outputs compared with arm 0 (every (WAVES, SUB) instantiation is bit-identical by design;
 the RPO_F128_EXP timing ablations are not)."""
@@ -17,7 +18,8 @@ for a in sys.argv[1:]:
     l.rpo_flash_attn_fwd.restype, l.rpo_flash_attn_fwd.argtypes = _lib.SIGNATURES["rpo_flash_attn_fwd"]
     arms.append((name, l, (int(bm or 128), int(hpb or 1))))
 DEV = "cuda"; torch.manual_seed(0)
-hd, nh, nkv, N, L = 128, 32, 8, int(os.environ.get("NSEQ", "24")), 4096
+hd = int(os.environ.get("HD", "128"))                 # HD=64: the cfg-2 passage batch of the tests (48 sequences)
+nh, nkv, N, L = 32, 8, int(os.environ.get("NSEQ", "24" if hd == 128 else "48")), 4096
 SC = 1.0 / hd ** 0.5
 lens = torch.randint(L // 2, L + 1, (N,)); lens[0] = L
 lens = lens.tolist(); T = sum(lens)
@@ -56,4 +58,4 @@ for name, _, bm in arms:
     same = "" if name == base else (f"  out identical {torch.equal(out[name], out[base])}, lse identical {torch.equal(lse[name], lse[base])}"
                                     f", max |d out| {(out[name].float() - out[base].float()).abs().max().item():.3g}"
                                     f", max |d lse| {(lse[name] - lse[base]).abs().max().item():.3g}")
-    print(f"fwd128 {name:14s} block_m {bm}: median {m:.3f} ms (min {ts[0]:.3f}) = {fl / m / 1e9:.0f} TFLOP/s = {fl / m / 1e9 / 2500:.3f} of peak{same}", flush=True)
+    print(f"fwd{hd} {name:14s} block_m {bm}: median {m:.3f} ms (min {ts[0]:.3f}) = {fl / m / 1e9:.0f} TFLOP/s = {fl / m / 1e9 / 2500:.3f} of peak{same}", flush=True)

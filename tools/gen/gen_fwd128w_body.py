@@ -38,6 +38,16 @@ Operands: P1: %0..%7 transposed-read addresses of V^T hd tiles 0..7 in V slot 0 
 import os
 import sys
 
+HD = int(sys.argv[1]) if len(sys.argv) > 1 else 128  # head_dim: 128 (attention_fwd128w_gen.inc, macros RPO_FW_*) or 64 (attention_fwd64w_gen.inc, RPO_FW64_*)
+assert HD in (64, 128)
+KS = HD // 32                                        # k-steps of the S^T chains
+NC = HD // 16                                        # hd tiles of O^T
+ROW = 2 * HD                                         # bytes of a K / V row in LDS
+IMG = 32 * ROW                                       # one 32-key image: 8 KiB (4 KiB at head_dim 64)
+HALF = 16 * ROW                                      # keys 16-31 inside an image
+PW = IMG // 4096                                     # LDS-DMA pieces of 1 KiB per wave and image (four waves)
+PRE = "RPO_FW_" if HD == 128 else "RPO_FW64_"
+A_O, A_L, A_Q, A_K = 0, 4 * 4 * NC, 4 * 4 * NC + 16, 4 * 4 * NC + 16 + 16 * KS      # accumulator file: O^T, l, Q^T, K fragments
 NO_VALU = os.environ.get("GEN_NO_VALU") == "1"       # timing experiments only (results are wrong): no exponentials, no row maximum
 B_VGPR = os.environ.get("GEN_B_VGPR") == "1"         # timing experiment: the chains' B operand from a VGPR instead of the Q^T AGPRs
 NO_LDS = os.environ.get("GEN_NO_LDS") == "1"         # timing experiment: no LDS reads inside P1 / P2
@@ -48,7 +58,7 @@ SPLIT = os.environ.get("GEN_SPLIT", "1") == "1"      # the exponentials of query
 SA = lambda m, n: 64 + 16 * m + 4 * n
 SB = lambda m, n: 96 + 16 * m + 4 * n
 AK_ACC = os.environ.get("GEN_AK_ACC", "1") == "1"    # K row fragments in a[208:239] (LDS reads can target the accumulator file) instead of v[128:159]
-AK = lambda ks, m: (208 if AK_ACC else 128) + 4 * (2 * ks + m)
+AK = lambda ks, m: (A_K if AK_ACC else 128) + 4 * (2 * ks + m)
 ak4 = lambda r: ("a[%d:%d]" if AK_ACC else "v[%d:%d]") % (r, r + 3)
 VT = lambda c: 160 + 4 * c
 PF = lambda n: 192 + 4 * n
@@ -56,21 +66,21 @@ MC = lambda n: 208 + n
 T0, T1, T2, T3 = 216, 217, 218, 219
 ONES = 224
 OA = lambda c, n: 4 * (4 * c + n)
-LA = lambda n: 128 + 4 * n
-QA = lambda n, ks: 144 + 16 * n + 4 * ks
+LA = lambda n: A_L + 4 * n
+QA = lambda n, ks: A_Q + 4 * KS * n + 4 * ks
 v4 = lambda r: "v[%d:%d]" % (r, r + 3)
 a4 = lambda r: "a[%d:%d]" % (r, r + 3)
 mf = "v_mfma_f32_16x16x32_bf16 "
 NEG = "0xf149f2ca"       # -1e30f
 ALL_V = ", ".join('"v%d"' % i for i in range(64, 228))
-ALL_A = ", ".join('"a%d"' % i for i in range(0, 240 if AK_ACC else 208))
+ALL_A = ", ".join('"a%d"' % i for i in range(0, A_K + 8 * KS if AK_ACC else A_K))
 PAD = [] if os.environ.get("GEN_NO_PAD") == "1" else ["s_nop 15", "s_nop 7"]   # >= 18 wait states: an MFMA's result read by a vector instruction
 
 
 def chain_mfmas(S):
     """S^T chains of one key tile into generation S: ks-major, the same accumulator comes round every 8 MFMAs."""
     out = []
-    for ks in range(4):
+    for ks in range(KS):
         for m in range(2):
             for n in range(4):
                 c_in = "0" if ks == 0 else v4(S(m, n))
@@ -83,7 +93,7 @@ def pv_mfmas():
     """O^T and l products of one key tile, query-tile major (P^T of tile n is needed from MFMA 9 n on)."""
     out = []
     for n in range(4):
-        for c in range(8):
+        for c in range(NC):
             out.append(mf + "%s, %s, %s, %s" % (a4(OA(c, n)), v4(VT(c)), v4(PF(n)), a4(OA(c, n))))
         out.append(mf + "%s, %s, %s, %s" % (a4(LA(n)), v4(ONES), v4(PF(n)), a4(LA(n))))
     return out
@@ -157,17 +167,17 @@ def off(o):
 
 def tr_reads(first_op, slot=0):
     out = []
-    for c in range(8):
-        out += ["ds_read_b64_tr_b16 v[%d:%d], %%%d%s" % (VT(c), VT(c) + 1, first_op + c, off(8192 * slot)),
-                "ds_read_b64_tr_b16 v[%d:%d], %%%d%s" % (VT(c) + 2, VT(c) + 3, first_op + c, off(8192 * slot + 4096))]
+    for c in range(NC):
+        out += ["ds_read_b64_tr_b16 v[%d:%d], %%%d%s" % (VT(c), VT(c) + 1, first_op + c, off(IMG * slot)),
+                "ds_read_b64_tr_b16 v[%d:%d], %%%d%s" % (VT(c) + 2, VT(c) + 3, first_op + c, off(IMG * slot + HALF))]
     return out
 
 
 def k_reads(first_op, slot=0):
     out = []
-    for ks in range(4):
+    for ks in range(KS):
         for m in range(2):
-            out.append("ds_read_b128 %s, %%%d%s" % (ak4(AK(ks, m)), first_op + ks, off(8192 * slot + 4096 * m)))
+            out.append("ds_read_b128 %s, %%%d%s" % (ak4(AK(ks, m)), first_op + ks, off(IMG * slot + HALF * m)))
     return out
 
 
@@ -219,24 +229,25 @@ def dma_ops(first_op):
     first_op: per-lane byte offsets of the wave's two K pieces and two V pieces inside a tile (VGPR), the two tiles' global bases
     (SGPR pairs), the LDS addresses of the wave's first K / V piece (SGPR; the second piece lies 1024 bytes behind)."""
     vk0, vk1, vv0, vv1, sk, sv, mk, mv = range(first_op, first_op + 8)
-    return [["s_mov_b32 m0, %%%d" % mk, "s_nop 0", "global_load_lds_dwordx4 %%%d, %%%d" % (vk0, sk)],
-            ["s_add_u32 m0, m0, 0x400", "s_nop 0", "global_load_lds_dwordx4 %%%d, %%%d" % (vk1, sk)],
-            ["s_mov_b32 m0, %%%d" % mv, "s_nop 0", "global_load_lds_dwordx4 %%%d, %%%d" % (vv0, sv)],
-            ["s_add_u32 m0, m0, 0x400", "s_nop 0", "global_load_lds_dwordx4 %%%d, %%%d" % (vv1, sv)]]
+    k0 = ["s_mov_b32 m0, %%%d" % mk, "s_nop 0", "global_load_lds_dwordx4 %%%d, %%%d" % (vk0, sk)]
+    k1 = ["s_add_u32 m0, m0, 0x400", "s_nop 0", "global_load_lds_dwordx4 %%%d, %%%d" % (vk1, sk)]
+    v0 = ["s_mov_b32 m0, %%%d" % mv, "s_nop 0", "global_load_lds_dwordx4 %%%d, %%%d" % (vv0, sv)]
+    v1 = ["s_add_u32 m0, m0, 0x400", "s_nop 0", "global_load_lds_dwordx4 %%%d, %%%d" % (vv1, sv)]
+    return [k0, k1, v0, v1] if PW == 2 else [k0, v0]              # (head_dim 64: one K and one V piece per wave; VK1 / VV1 unused)
 
 
 def p2(S_next, pv=True, mx=True, kslot=0, dma=False, S_cur=None):
     """(pv) O^T / l products of the tile whose P^T is in PF; (mx) exponents of S_next in place, grow, and the K rows (K slot kslot) of
     the tile after it.  The vector work starts behind the SECOND product: the last chain MFMA of P1 is then >= 18 wait states back
     (a statement that reads S_next right behind P1 -- the mask, P2NOPV -- pads for itself)."""
-    ops = (["v_mov_b32 %0, 0"] if NO_VALU else arg_ops(S_next, "%5", "%0")) if mx else []
+    ops = (["v_mov_b32 %0, 0"] if NO_VALU else arg_ops(S_next, "%%%d" % (KS + 1), "%0")) if mx else []
     lds = k_reads(1, kslot) if (mx and not NO_LDS) else []
     if pv:
-        ex = exp_ops(S_cur, (3,)) if (mx and SPLIT and not NO_VALU) else []          # P^T[3]: operand of the products from MFMA 27 on
-        out = weave(pv_mfmas(), ex + ops, RATE2, lds, 1, need={27: len(ex)} if ex else None, first_gap=2, free=len(ex))
-        if dma:                                                   # one piece behind MFMAs 11, 17, 23, 29 (the K row reads are out by 8)
-            pieces = dma_ops(6)
-            for gi, at in reversed(list(enumerate((11, 17, 23, 29)))):
+        ex = exp_ops(S_cur, (3,)) if (mx and SPLIT and not NO_VALU) else []          # P^T[3]: operand of the products from MFMA 3 (NC + 1) on
+        out = weave(pv_mfmas(), ex + ops, RATE2, lds, 1, need={3 * (NC + 1): len(ex)} if ex else None, first_gap=2, free=len(ex))
+        if dma:                                                   # one piece behind MFMAs 11, 17, 23, 29 of 36 (8, 14 of 20): the K row reads are out by then
+            pieces = dma_ops(KS + 2)
+            for gi, at in reversed(list(enumerate((11, 17, 23, 29) if HD == 128 else (8, 14)))):
                 k = [i for i, t in enumerate(out) if t.startswith("v_mfma")][at]
                 out[k + 1:k + 1] = pieces[gi]
     else:
@@ -259,7 +270,7 @@ def first(S, kslot=1):
     """Tile 0 (generation S, scores masked already): MC[n] = c x the row maximum, e = c s - MC[n]; O and l are zero, nothing to
     scale.  Also the K rows of tile 1.  %0..%3 K row addresses, %4 = c."""
     out = PAD + ([] if NO_LDS else k_reads(0, kslot))
-    out += ["v_mul_f32 v%d, %s, v%d" % (S(m, n) + r, "%4", S(m, n) + r) for n in range(4) for m in range(2) for r in range(4)]
+    out += ["v_mul_f32 v%d, %s, v%d" % (S(m, n) + r, "%%%d" % KS, S(m, n) + r) for n in range(4) for m in range(2) for r in range(4)]
     out += lane_max(S) + row_max()
     out += ["v_mov_b32 v%d, v%d" % (MC(n), TT[n]) for n in range(4)]
     out += shift_ops(S, TT)
@@ -279,7 +290,7 @@ def rescale(S):
     out += ["v_exp_f32 v%d, v%d" % (TU[n], TU[n]) for n in range(4)]
     out.append("s_nop 0")
     for n in range(4):
-        regs = [OA(c, n) + r for c in range(8) for r in range(4)] + [LA(n) + r for r in range(4)]
+        regs = [OA(c, n) + r for c in range(NC) for r in range(4)] + [LA(n) + r for r in range(4)]
         for i in range(0, len(regs), 4):                          # four at a time through v[212:215] (free: MN is gone)
             grp = regs[i:i + 4]
             out += ["v_accvgpr_read_b32 v%d, a%d" % (212 + j, a) for j, a in enumerate(grp)]
@@ -306,45 +317,47 @@ def emit_block(lines_, head, tail):
 CLOB = "        : " + ALL_V + ", " + ALL_A + ', "vcc", "memory")'
 print("// GENERATED by tools/gen/gen_fwd128w_body.py -- do not edit (tests/test_host_logic.py checks that the two stay in sync).")
 print("// Register map, operand lists and the pipeline: the generator's docstring.")
-TRS = ", ".join("TR%d" % i for i in range(8))
-tr_in = ", ".join('"v"(TR%d)' % i for i in range(8))
+TRS = ", ".join("TR%d" % i for i in range(NC))
+tr_in = ", ".join('"v"(TR%d)' % i for i in range(NC))
+KRS = ", ".join("R%d" % i for i in range(KS))
+kr_in = ", ".join('"v"(R%d)' % i for i in range(KS))
 GEN = (SA, SB)
 for it in range(4):                      # iteration t = it (mod 4): current generation t % 2, V slot t % 4, K slot (t + 2) % 4
     cur, nxt = GEN[it & 1], GEN[(it + 1) & 1]
     body = p1(cur, nxt, True, it)
     print("// %d instructions" % len(body))
-    emit_block(body, "#define RPO_FW_P1_S%d(%s, SCL)" % (it, TRS), ["        :", "        : " + tr_in + ', "s"(SCL)', CLOB])
-    emit_block(p1(cur, None, False, it), "#define RPO_FW_P1L_S%d(%s, SCL)" % (it, TRS),
+    emit_block(body, "#define " + PRE + "P1_S%d(%s, SCL)" % (it, TRS), ["        :", "        : " + tr_in + ', "s"(SCL)', CLOB])
+    emit_block(p1(cur, None, False, it), "#define " + PRE + "P1L_S%d(%s, SCL)" % (it, TRS),
                ["        :", "        : " + tr_in + ', "s"(SCL)', CLOB])
     body = p2(nxt, True, True, (it + 2) & 3, False, cur)
     print("// %d instructions" % len(body))
-    emit_block(body, "#define RPO_FW_P2_S%d(GROW, R0, R1, R2, R3, SCL)" % it,
-               ['        : "=&v"(GROW)', '        : "v"(R0), "v"(R1), "v"(R2), "v"(R3), "s"(SCL)', CLOB])
-    emit_block(p2(nxt, True, True, (it + 2) & 3, True, cur), "#define RPO_FW_P2D_S%d(GROW, R0, R1, R2, R3, SCL, VK0, VK1, VV0, VV1, SK, SV, MK, MV)" % it,
-               ['        : "=&v"(GROW)', '        : "v"(R0), "v"(R1), "v"(R2), "v"(R3), "s"(SCL), "v"(VK0), "v"(VK1), "v"(VV0), "v"(VV1), '
+    emit_block(body, "#define " + PRE + "P2_S%d(GROW, %s, SCL)" % (it, KRS),
+               ['        : "=&v"(GROW)', "        : " + kr_in + ', "s"(SCL)', CLOB])
+    emit_block(p2(nxt, True, True, (it + 2) & 3, True, cur), "#define " + PRE + "P2D_S%d(GROW, %s, SCL, VK0, VK1, VV0, VV1, SK, SV, MK, MV)" % (it, KRS),
+               ['        : "=&v"(GROW)', "        : " + kr_in + ', "s"(SCL), "v"(VK0), "v"(VK1), "v"(VV0), "v"(VV1), '
                 '"s"(SK), "s"(SV), "s"(MK), "s"(MV)', CLOB])
-emit_block(first(SA), "#define RPO_FW_FIRST_A(R0, R1, R2, R3, SCL)",       # prologue: tile 0's scale and exponents, tile 1's K rows
-           ["        :", '        : "v"(R0), "v"(R1), "v"(R2), "v"(R3), "s"(SCL)', CLOB])
-emit_block(p2(None, True, False) + PAD, "#define RPO_FW_P2L()", ["        :", "        :", CLOB])   # (+ pad: the epilogue reads O^T)
-emit_block(k_reads(0) + ["s_waitcnt lgkmcnt(0)"], "#define RPO_FW_KREAD(R0, R1, R2, R3)",
-           ["        :", '        : "v"(R0), "v"(R1), "v"(R2), "v"(R3)', CLOB])
-emit_block(chain_mfmas(SA) + PAD, "#define RPO_FW_SCHAIN_A()", ["        :", "        :", CLOB])
+emit_block(first(SA), "#define " + PRE + "FIRST_A(%s, SCL)" % KRS,       # prologue: tile 0's scale and exponents, tile 1's K rows
+           ["        :", "        : " + kr_in + ', "s"(SCL)', CLOB])
+emit_block(p2(None, True, False) + PAD, "#define " + PRE + "P2L()", ["        :", "        :", CLOB])   # (+ pad: the epilogue reads O^T)
+emit_block(k_reads(0) + ["s_waitcnt lgkmcnt(0)"], "#define " + PRE + "KREAD(%s)" % KRS,
+           ["        :", "        : " + kr_in, CLOB])
+emit_block(chain_mfmas(SA) + PAD, "#define " + PRE + "SCHAIN_A()", ["        :", "        :", CLOB])
 for name, S in (("A", SA), ("B", SB)):
-    emit_block(mask(S), "#define RPO_FW_MASK_%s(D0, D1, D2, D3)" % name,
+    emit_block(mask(S), "#define " + PRE + "MASK_%s(D0, D1, D2, D3)" % name,
                ["        :", '        : "v"(D0), "v"(D1), "v"(D2), "v"(D3)', CLOB])
 for name, S in (("A", SA), ("B", SB)):
-    emit_block(rescale(S), "#define RPO_FW_RESCALE_%s()" % name, ["        :", "        :", CLOB])
-emit_block(["v_accvgpr_write_b32 a%d, 0" % i for i in range(144)], "#define RPO_FW_INIT_ACC()",      # (early: under the first loads' latency;
-           ["        :", "        :", "        : " + ", ".join('"a%d"' % i for i in range(144)) + ")"])   # hipcc's code has no use for the accumulator file)
+    emit_block(rescale(S), "#define " + PRE + "RESCALE_%s()" % name, ["        :", "        :", CLOB])
+emit_block(["v_accvgpr_write_b32 a%d, 0" % i for i in range(A_Q)], "#define " + PRE + "INIT_ACC()",      # (early: under the first loads' latency;
+           ["        :", "        :", "        : " + ", ".join('"a%d"' % i for i in range(A_Q)) + ")"])   # hipcc's code has no use for the accumulator file)
 init = []
 init += ["v_mov_b32 v%d, 0x3f803f80" % (ONES + i) for i in range(4)]
 init += ["v_mov_b32 v%d, 0" % MC(n) for n in range(4)]
-emit_block(init, "#define RPO_FW_INIT()", ["        :", "        :", CLOB])
+emit_block(init, "#define " + PRE + "INIT()", ["        :", "        :", CLOB])
 # Q^T fragment (n, ks) -> a[144 + 16 n + 4 ks ...]: four 32-bit operands (an operand's sub-registers cannot be named)
-print("#define RPO_FW_Q_TO_ACC(N, KS, W)" + " " * 60 + "\\")
+print("#define " + PRE + "Q_TO_ACC(N, KS, W)" + " " * 60 + "\\")
 print("    do {" + " " * 100 + "\\")
 for n in range(4):
-    for ks in range(4):
+    for ks in range(KS):
         r = QA(n, ks)
         print("        if ((N) == %d && (KS) == %d)" % (n, ks) + " " * 70 + "\\")
         print('            asm volatile("v_accvgpr_write_b32 a%d, %%0\\n\\tv_accvgpr_write_b32 a%d, %%1\\n\\tv_accvgpr_write_b32 a%d, %%2\\n\\t"' % (r, r + 1, r + 2) + "  \\")
@@ -352,16 +365,16 @@ for n in range(4):
         print('                         : "a%d", "a%d", "a%d", "a%d");' % (r, r + 1, r + 2, r + 3) + " " * 40 + "\\")
 print("    } while (0)")
 # epilogue: O^T[c][n] (4 registers) and l[n], MC[n] out of the literal registers
-print("#define RPO_FW_READ_O(C, N, X0, X1, X2, X3)" + " " * 50 + "\\")
+print("#define " + PRE + "READ_O(C, N, X0, X1, X2, X3)" + " " * 50 + "\\")
 print("    do {" + " " * 100 + "\\")
-for c in range(8):
+for c in range(NC):
     for n in range(4):
         r = OA(c, n)
         print("        if ((C) == %d && (N) == %d)" % (c, n) + " " * 70 + "\\")
         print('            asm volatile("v_accvgpr_read_b32 %%0, a%d\\n\\tv_accvgpr_read_b32 %%1, a%d\\n\\tv_accvgpr_read_b32 %%2, a%d\\n\\t"' % (r, r + 1, r + 2) + "  \\")
         print('                         "v_accvgpr_read_b32 %%3, a%d" : "=v"(X0), "=v"(X1), "=v"(X2), "=v"(X3));' % (r + 3) + "  \\")
 print("    } while (0)")
-print("#define RPO_FW_READ_LM(N, L, M)" + " " * 60 + "\\")
+print("#define " + PRE + "READ_LM(N, L, M)" + " " * 60 + "\\")
 print("    do {" + " " * 100 + "\\")
 for n in range(4):
     print("        if ((N) == %d)" % n + " " * 80 + "\\")
