@@ -806,7 +806,13 @@ __global__ __launch_bounds__(64 * WQ * HEADS, WQ * HEADS == 4 ? 2 : 1) void fa_f
 #ifndef RPO_FW_EXP
 #define RPO_FW_EXP 0     // timing-only ablations: 2 no LDS-DMA staging inside the loop, 4 no barrier / ring wait
 #endif
-constexpr float kFwDefer = 8.0f;
+#ifndef RPO_FW_NT
+#define RPO_FW_NT 0      // A/B: 1 the Q pieces (read once) by non-temporal LDS-DMA, 2 the O rows by non-temporal stores, 4 the rotated Q rows
+#endif
+#ifndef RPO_FW_DEFER
+#define RPO_FW_DEFER 8.0f
+#endif
+constexpr float kFwDefer = RPO_FW_DEFER;
 
 #define FWW_HD 128
 #define FWW(X) RPO_FW_##X
