@@ -284,14 +284,17 @@ int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_st
  * rope_cos / rope_sin (both NULL, or both f32 [rope_period][hd / 2], 16-byte aligned; token t uses row t % rope_period; the
  * tables rpo_rope rotated q and k with): dq and dk then leave as the gradients w.r.t. the PRE-rotary q / k -- the inverse
  * rotation of rpo_rope(backward = 1) applied in the kernels' epilogues in f32 before the one rounding to bf16, instead of a
- * separate pass over d(q|k).  Not offered with key_block 64 (RPO_ERR_UNSUPPORTED). */
+ * separate pass over d(q|k).  Not offered with key_block 64 (RPO_ERR_UNSUPPORTED).
+ * q_block = the query rows one entry of q_tiles stands for: 128 (0 means 128), or 64 with head_dim 64 and
+ * (num_heads / num_kv_heads) % 4 == 0 -- the 64-query x 4-head entries of rpo_flash_attn_fwd's q_block = 64, walked by the
+ * one-wave-per-SIMD dQ kernel (fa_bwd_dq64w_kernel; dq 16-byte aligned, dq_stride % 8 == 0).  Anything else: RPO_ERR_UNSUPPORTED. */
 int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, int64_t q_stride,
                        int64_t k_stride, int64_t v_stride, int64_t out_stride, int64_t dout_stride,
                        const int* cu_seqlens, const int* q_tiles, int64_t n_q_tiles, int64_t q_tile_cols, const int* k_tiles,
                        int64_t n_k_tiles, int64_t key_block, int64_t sweep_down, int64_t total_tokens, int64_t num_heads,
                        int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta, void* dq, void* dk, void* dv,
                        int64_t dq_stride, int64_t dk_stride, int64_t dv_stride, const float* rope_cos, const float* rope_sin,
-                       int64_t rope_period, rpo_stream_t stream);
+                       int64_t rope_period, int64_t q_block, rpo_stream_t stream);
 
 /* One-query-per-sequence attention (rankpo_amd/csrc/lastq_attention.hip): the attention of the LAST block of a last-token-pooled
  * encoder.  The reference pools `last_hidden_state[n, last real token]` (modeling.py:224-230, rankpo_trainer.py:409-413), so the

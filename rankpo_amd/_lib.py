@@ -66,7 +66,7 @@ SIGNATURES = {
     "rpo_flash_attn_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp,
                                      _i64, _vp, _i64, _vp, _vp, _i64, _i64, _vp]),
     "rpo_flash_attn_bwd": (C.c_int, [_vp] * 5 + [_i64] * 5 + [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, _f32, _vp, _vp,
-                                     _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _vp]),
+                                     _vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _i64, _i64, _vp]),
     "rpo_lastq_attn_fwd": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _vp]),
     "rpo_lastq_attn_bwd": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _f32, _vp, _i64, _vp, _i64, _vp,
                                      _vp, _i64, _vp, _vp, _i64, _i64, _vp]),

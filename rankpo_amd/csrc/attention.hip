@@ -1083,6 +1083,266 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// dQ at head_dim 64, ONE WAVE PER SIMD (round 5; rpo_flash_attn_bwd's q_block = 64): the construction of fa_fwd128w_kernel applied to
+// fa_bwd_dq_kernel.  Block = 64 queries x the four q heads of one kv head (one head per wave: the staged K / V tiles serve four waves,
+// the K / V fragments four query tiles instead of two: half the LDS reads per MFMA); dQ^T (64 registers), Q^T and dO^T fragments
+// (32 + 32) and the K / V row fragments of the tile in flight live in the accumulator file; the key-tile loop is two generated asm
+// statements per 32-key tile (tools/gen/gen_dq64w_body.py -> attention_dq64w_gen.inc, pipeline and register map in its docstring).
+// No online softmax here (p = exp2(c S - lse log2e) from the saved lse), so no rescale statements: X1 / X2 and a mask.
+// Q, dO and O come in as whole 128-byte rows through a 24-KiB LDS region per wave (delta = sum dO O from the fragments, as
+// fa_bwd_dq_kernel computes it; both row constants are written for the dK/dV kernel); dQ goes out through the same region.
+// K ring: eight 4-KiB images (a K tile is read by rows two iterations before its transposed reads); V ring: four.
+// ------------------------------------------------------------------------------------------------------------------
+#include "attention_dq64w_gen.inc"
+
+__global__ __launch_bounds__(256, 1) void fa_bwd_dq64w_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ dout, int64_t sq, int64_t sk, int64_t sv, int64_t sdo, const int* __restrict__ cu,
+    const int* __restrict__ tiles, int tcols, int nh, int nkv, float scale_log2e, float scale,
+    const float* __restrict__ lse, const bf16_t* __restrict__ o, int64_t so, float* __restrict__ nl_out,
+    float* __restrict__ nd_out, int64_t T, bf16_t* __restrict__ dq, int64_t sdq, const float* __restrict__ rcos,
+    const float* __restrict__ rsin, int64_t rperiod) {
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_DQ)
+    unsigned long long st_acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, ts0, ts1, ts2, ts3, ts4;
+    RPO_STAMP(ts0);
+#define DQS(VAR) RPO_STAMP(VAR)
+#define DQS_ADD(I, A, B) st_acc[I] += (B) - (A)
+#else
+#define DQS(VAR)
+#define DQS_ADD(I, A, B)
+#endif
+    constexpr int BN = 32, ROW_ = 2 * kFaHD, kImg = BN * ROW_;           // 4-KiB images
+    constexpr int kVRing = 8 * kImg;                                     // K ring: slots 0-7 at byte 0; V ring: slots 0-3 behind it
+    constexpr int kIo = 64 * ROW_;                                       // 64 rows of one of Q / dO / O (8 KiB)
+    __shared__ __attribute__((aligned(16))) char smem[12 * kImg + 4 * 3 * kIo];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, fr = lane & 15;
+    const FaTile ft = fa_tile(tiles, tcols);
+    if (ft.q0 >= (1 << 30)) return;
+    const int seq = ft.seq, q0 = ft.q0;
+    const int h = (tcols == 3 ? ft.h : ft.h * 4) + wave, hk = h / (nh / nkv);
+    const int64_t t0 = cu[seq];
+    const int len = cu[seq + 1] - (int)t0;
+    const int qw = q0;
+    const int nkt = min(q0 + 63, len - 1) / BN + 1;                      // key tiles the block walks (every wave the same)
+#define DQ_SWZ(R) ((R) & 7)
+    // staging: a 4-KiB image = 4 pieces of 1 KiB (8 rows of 128 bytes); wave w carries piece w of the K and of the V image; lane l
+    // carries row 8 w + (l >> 3), physical chunk l & 7 = logical chunk (l & 7) ^ (row & 7)
+    const int srow = lane >> 3, lcol = lane & 7;
+    const char* ksrc = reinterpret_cast<const char*>(k + t0 * sk + hk * kFaHD);
+    const char* vsrc = reinterpret_cast<const char*>(v + t0 * sv + hk * kFaHD);
+    const unsigned skb = (unsigned)sk * 2u, svb = (unsigned)sv * 2u;
+    auto stage = [&](const char* src, unsigned stride_b, int kt, char* image) {
+        const int trow = 8 * wave + srow;
+        const unsigned lchunk = (unsigned)(lcol ^ DQ_SWZ(trow));
+        const unsigned row = (unsigned)min(kt * BN + trow, len - 1);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (row * stride_b + lchunk * 16)),
+                                         (__attribute__((address_space(3))) void*)(image + wave * 1024), 16, 0, 0);
+    };
+    // Q, dO, O: the wave's 64 rows of each (clamped to the sequence) as 8 + 8 + 8 LDS-DMA pieces, then K tiles 0-3 and V tiles 0-3
+    char* const io = smem + 12 * kImg + wave * (3 * kIo);
+    {
+        const char* src[3] = {reinterpret_cast<const char*>(q + t0 * sq + h * kFaHD), reinterpret_cast<const char*>(dout + t0 * sdo + h * kFaHD),
+                              reinterpret_cast<const char*>(o + t0 * so + h * kFaHD)};
+        const unsigned strb[3] = {(unsigned)sq * 2u, (unsigned)sdo * 2u, (unsigned)so * 2u};
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int trow = 8 * u + srow;
+                const unsigned lchunk = (unsigned)(lcol ^ DQ_SWZ(trow));
+                const unsigned row = (unsigned)min(qw + trow, len - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[a] + ((size_t)row * strb[a] + lchunk * 16)),
+                                                 (__attribute__((address_space(3))) void*)(io + a * kIo + u * 1024), 16, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (j < nkt) { stage(ksrc, skb, j, smem + j * kImg); stage(vsrc, svb, j, smem + kVRing + j * kImg); }
+    // the saved lse of the lane's four queries (clamped rows: duplicates that are never stored)
+    float lq[4], dl[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) lq[n] = lse[(int64_t)h * T + t0 + min(qw + 16 * n + fr, len - 1)];
+    RPO_DQ_INIT_ACC();                                                    // dQ^T = 0 under the loads' latency
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                         // (the first K / V tiles are everybody's)
+    // fragments: lane (g, fr) = query 16 n + fr, hd 32 ks + 8 g .. + 7; delta = sum_d dO O over the row: the lane's 16 columns, then
+    // the four lanes of the row
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const unsigned fo = (16 * n + fr) * ROW_ + (((4 * ks + g) ^ DQ_SWZ(fr)) << 4);
+            const short8_t bq = *reinterpret_cast<const short8_t*>(io + fo);
+            const short8_t bdo = *reinterpret_cast<const short8_t*>(io + kIo + fo);
+            const short8_t ov = *reinterpret_cast<const short8_t*>(io + 2 * kIo + fo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) part = fmaf(bf16_to_f32((bf16_t)bdo[e]), bf16_to_f32((bf16_t)ov[e]), part);
+            const uint4_t wq = __builtin_bit_cast(uint4_t, bq), wd = __builtin_bit_cast(uint4_t, bdo);
+            RPO_DQ_Q_TO_ACC(n, ks, wq);
+            RPO_DQ_DO_TO_ACC(n, ks, wd);
+        }
+        part += __shfl_xor(part, 16, 64);
+        part += __shfl_xor(part, 32, 64);
+        dl[n] = -part;
+        const int qi = qw + 16 * n + fr;
+        if (qi < len && g == 0) {
+            nl_out[(int64_t)h * T + t0 + qi] = -lq[n] / scale;
+            nd_out[(int64_t)h * T + t0 + qi] = dl[n];
+        }
+        lq[n] *= 1.4426950408889634f;                                     // p = exp2(c S - lse log2e)
+    }
+    // loop-invariant per-lane LDS addresses (slot 0 of either ring): K / V rows of k-step ks (row fr, chunk (4 ks + g) ^ (fr & 7)), K^T
+    // blocks of hd tile c (row 4 g + qq, chunk (2 c + (pp >> 1)) ^ (row & 7))
+    const int qq = fr >> 2, pp = fr & 3;
+    const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned trk[4], krow[2], vrow[2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) trk[c] = smem_base + (4 * g + qq) * ROW_ + (((2 * c + (pp >> 1)) ^ DQ_SWZ(4 * g + qq)) << 4) + 8 * (pp & 1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        krow[ks] = smem_base + fr * ROW_ + (((4 * ks + g) ^ DQ_SWZ(fr)) << 4);
+        vrow[ks] = krow[ks] + kVRing;
+    }
+    unsigned pk, pv;                                                      // the wave's piece inside a tile: byte offsets from the tile's first row
+    {
+        const int trow = 8 * wave + srow;
+        const unsigned lchunk = (unsigned)(lcol ^ DQ_SWZ(trow));
+        pk = (unsigned)trow * skb + lchunk * 16;
+        pv = (unsigned)trow * svb + lchunk * 16;
+        asm volatile("" : "+v"(pk), "+v"(pv));
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) asm volatile("" : "+v"(trk[c]));
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) asm volatile("" : "+v"(krow[ks]), "+v"(vrow[ks]));
+    auto needs_mask = [&](int j) { return (j * BN + BN - 1 > qw) || (j * BN + BN > len); };
+#define DQ_MASK(GEN, J)                                                                                            \
+    do {                                                                                                           \
+        const int k0_ = (J) * BN;                                                                                  \
+        const int d0_ = min(qw + fr, len - 1) - k0_ - 4 * g, d1_ = min(qw + 16 + fr, len - 1) - k0_ - 4 * g;       \
+        const int d2_ = min(qw + 32 + fr, len - 1) - k0_ - 4 * g, d3_ = min(qw + 48 + fr, len - 1) - k0_ - 4 * g;  \
+        RPO_DQ_MASK_##GEN(d0_, d1_, d2_, d3_);                                                                     \
+    } while (0)
+    // from here on v[64:215] and a[0:159] belong to the generated statements
+    RPO_DQ_INIT(lq[0], lq[1], lq[2], lq[3], dl[0], dl[1], dl[2], dl[3]);
+    RPO_DQ_READ0(krow[0], krow[1], vrow[0], vrow[1]);
+    RPO_DQ_CHAIN0();
+    if (needs_mask(0)) DQ_MASK(A, 0);
+    RPO_DQ_PRE0(krow[0], krow[1], scale_log2e);
+#define DQ_ITER(S, NXT, KT)                                                                                        \
+    do {                                                                                                           \
+        const int kt_ = (KT);                                                                                      \
+        DQS(ts1);                                                                                                  \
+        /* K(kt + 2) and V(kt + 1) landed (staged two / three iterations ago); the previous iteration's two pieces may fly.  The  */ \
+        /* barrier also orders this iteration's DMA (V(kt + 4) -> the slot of V(kt)) behind every wave's reads of V(kt)           */ \
+        if (kt_ + 3 < nkt) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                        \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        DQS(ts2);                                                                                                  \
+        DQS_ADD(0, ts1, ts2);                                             /* 0: ring wait */                        \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        DQS(ts3);                                                                                                  \
+        DQS_ADD(1, ts2, ts3);                                             /* 1: barrier */                          \
+        const bool instream_ = (kt_ + 5) * BN <= len && kt_ + 4 < nkt && kt_ + 1 < nkt;                            \
+        if (!instream_ && kt_ + 4 < nkt) {                                                                         \
+            stage(ksrc, skb, kt_ + 4, smem + ((kt_ + 4) & 7) * kImg);                                              \
+            stage(vsrc, svb, kt_ + 4, smem + kVRing + (kt_ & 3) * kImg);                                           \
+        }                                                                                                          \
+        DQS(ts2);                                                                                                  \
+        DQS_ADD(2, ts3, ts2);                                             /* 2: hipcc staging */                    \
+        if (kt_ + 1 < nkt) {                                                                                       \
+            RPO_DQ_X1_S##S(trk[0], trk[1], trk[2], trk[3], vrow[0], vrow[1]);                                      \
+            DQS(ts3);                                                                                              \
+            DQS_ADD(3, ts2, ts3);                                         /* 3: X1 */                               \
+            if (needs_mask(kt_ + 1)) DQ_MASK(NXT, kt_ + 1);                                                        \
+            DQS(ts4);                                                                                              \
+            DQS_ADD(4, ts3, ts4);                                         /* 4: mask */                             \
+            if (instream_) {                                                                                       \
+                const char* sk_ = ksrc + (size_t)(kt_ + 4) * BN * skb;                                             \
+                const char* sv_ = vsrc + (size_t)(kt_ + 4) * BN * svb;                                             \
+                const unsigned mk_ = smem_base + ((kt_ + 4) & 7) * kImg + wave * 1024;                             \
+                const unsigned mv_ = smem_base + kVRing + (kt_ & 3) * kImg + wave * 1024;                          \
+                RPO_DQ_X2D_S##S(krow[0], krow[1], scale_log2e, pk, pv, sk_, sv_, mk_, mv_);                        \
+            } else {                                                                                               \
+                RPO_DQ_X2_S##S(krow[0], krow[1], scale_log2e);                                                     \
+            }                                                                                                      \
+            DQS(ts3);                                                                                              \
+            DQS_ADD(5, ts4, ts3);                                         /* 5: X2 */                               \
+            DQS_ADD(7, 0, 1);                                             /* 7: full iterations */                  \
+        } else {                                                                                                   \
+            RPO_DQ_X1L_S##S(trk[0], trk[1], trk[2], trk[3], vrow[0], vrow[1]);                                     \
+            RPO_DQ_X2L();                                                                                          \
+        }                                                                                                          \
+    } while (0)
+    DQS(ts1);
+    DQS_ADD(6, ts0, ts1);                                                 /* 6: prologue */
+    for (int kt = 0; kt < nkt; kt += 8) {
+        DQ_ITER(0, B, kt);
+        if (kt + 1 < nkt) DQ_ITER(1, A, kt + 1);
+        if (kt + 2 < nkt) DQ_ITER(2, B, kt + 2);
+        if (kt + 3 < nkt) DQ_ITER(3, A, kt + 3);
+        if (kt + 4 < nkt) DQ_ITER(4, B, kt + 4);
+        if (kt + 5 < nkt) DQ_ITER(5, A, kt + 5);
+        if (kt + 6 < nkt) DQ_ITER(6, B, kt + 6);
+        if (kt + 7 < nkt) DQ_ITER(7, A, kt + 7);
+    }
+#undef DQ_ITER
+#undef DQ_MASK
+    DQS(ts4);
+    // ---- epilogue: dQ[q][16c + 4g + r] = scale dQ^T (inverse rotation: rows 16 c + 4 g + r pair with 16 (c + 2) + 4 g + r) into the
+    // wave's LDS region, whole rows out of it
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int qi = qw + 16 * n + fr;
+        float4_t acc[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            float x0, x1, x2, x3;
+            RPO_DQ_READ_DQ(c, n, x0, x1, x2, x3);
+            acc[c] = float4_t{x0 * scale, x1 * scale, x2 * scale, x3 * scale};
+        }
+        if (rcos) {
+            const int64_t tr = ((t0 + min(qi, len - 1)) % rperiod) * (kFaHD / 2) + 4 * g;
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                inv_rope4(acc[c], acc[c + 2], *reinterpret_cast<const float4_t*>(rcos + tr + 16 * c),
+                          *reinterpret_cast<const float4_t*>(rsin + tr + 16 * c));
+        }
+        char* lrow = io + (16 * n + fr) * ROW_ + 8 * (g & 1);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint2_t w;
+            w.x = pack_bf16(acc[c][0], acc[c][1]);
+            w.y = pack_bf16(acc[c][2], acc[c][3]);
+            *reinterpret_cast<uint2_t*>(lrow + (((2 * c + (g >> 1)) ^ DQ_SWZ(fr)) << 4)) = w;
+        }
+    }
+    {
+        bf16_t* dbase = dq + (t0 + qw) * sdq + h * kFaHD + 8 * lcol;
+        int srow_e = lane >> 3;
+        asm volatile("" : "+v"(srow_e));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int trow = 8 * u + srow_e;
+            const uint4_t w = *reinterpret_cast<const uint4_t*>(io + trow * ROW_ + ((lcol ^ DQ_SWZ(trow)) << 4));
+            if (qw + trow < len) *reinterpret_cast<uint4_t*>(dbase + (int64_t)trow * sdq) = w;
+        }
+    }
+#if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_DQ)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    DQS(ts3);
+    DQS_ADD(8, ts4, ts3);                                                 /* 8: epilogue, stores landed */
+    if (lane == 0)
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_fa_stamp[wave * 16 + i], st_acc[i]);
+#endif
+#undef DQ_SWZ
+#undef DQS
+#undef DQS_ADD
+}
+
 constexpr int kFaDkdvThreads = 512;
 
 // ---- dK / dV ---------------------------------------------------------------------------------------------------------
@@ -4044,9 +4304,17 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
                                   int64_t q_tile_cols, const int* k_tiles, int64_t n_k_tiles, int64_t key_block,
                                   int64_t sweep_down, int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim, float scale, const float* lse, float* delta,
                                   void* dq, void* dk, void* dv, int64_t dq_stride, int64_t dk_stride, int64_t dv_stride,
-                                  const float* rope_cos, const float* rope_sin, int64_t rope_period, rpo_stream_t stream) {
+                                  const float* rope_cos, const float* rope_sin, int64_t rope_period, int64_t q_block,
+                                  rpo_stream_t stream) {
     if (!q || !k || !v || !out || !dout || !cu_seqlens || !q_tiles || !k_tiles || !lse || !delta || !dq || !dk || !dv)
         return RPO_ERR_INVALID_ARG;
+    // q_block: query rows per entry of q_tiles.  128 (or 0): fa_bwd_dq_kernel / fa_bwd_dq128_kernel.  64: head_dim 64 only -- an entry
+    // is 64 queries x the four consecutive q heads that start at the entry's head (rpo_flash_attn_fwd's q_block = 64 format):
+    // fa_bwd_dq64w_kernel, one wave per SIMD; dq must be 16-byte aligned with dq_stride % 8 == 0 there
+    if (q_block == 0) q_block = 128;
+    if (q_block != 128 && !(q_block == 64 && head_dim == kFaHD && num_kv_heads > 0 && num_heads % num_kv_heads == 0 &&
+                            (num_heads / num_kv_heads) % 4 == 0 && dq_stride % 8 == 0 && rpo_aligned16(dq)))
+        return RPO_ERR_UNSUPPORTED;
     // rope_cos / rope_sin (both or neither): dq / dk leave as gradients w.r.t. the PRE-rotary q / k (inverse rotation in the
     // epilogues); not offered by the 8-wave dK/dV kernel (key_block 64), whose epilogue splits a row's halves over two passes
     if ((rope_cos == nullptr) != (rope_sin == nullptr) || (rope_cos && rope_period <= 0)) return RPO_ERR_INVALID_ARG;
@@ -4098,10 +4366,16 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
                        dk_stride, dv_stride, (int)n_k_tiles, gshift128, rope_cos, rope_sin, rope_period);
         return rpo_launch_status();
     }
-    RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0,
-               st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
-               dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse,
-               (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride, rope_cos, rope_sin, rope_period);
+    if (q_block == 64)
+        RPO_LAUNCH(fa_bwd_dq64w_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)(num_heads / 4)), dim3(256), 0,
+                   st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
+                   dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse,
+                   (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride, rope_cos, rope_sin, rope_period);
+    else
+        RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0,
+                   st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
+                   dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse,
+                   (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride, rope_cos, rope_sin, rope_period);
     int rc = rpo_launch_status();
     if (rc != RPO_OK) return rc;
     const unsigned dkdv_grid = (unsigned)(((n_k_tiles + 7) / 8) * 8);

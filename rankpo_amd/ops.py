@@ -787,11 +787,13 @@ def _attn_key_tile_table(lens, device, num_kv_heads, block_n, group_order=False)
 
 
 def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles, scale, grads=None,
-                          key_block: int = ATTN_KEY_BLOCK, sweep_down=None, rope=None):
+                          key_block: int = ATTN_KEY_BLOCK, sweep_down=None, rope=None, q_block: int = 128):
     """grads: optional preallocated (dq, dk, dv) [T, heads, hd] views with arbitrary token strides (e.g. the three column
     blocks of ONE fused d(q|k|v) buffer).  key_block: keys per entry of `k_tiles` (`attn_key_tile_table`'s block_n): 256 or 64 at
     head_dim 64, 128 at head_dim 128.  rope = (cos, sin), f32 [period, hd / 2] (the tables q and k were rotated with): dq / dk
-    come back as the gradients w.r.t. the PRE-rotary q / k (inverse rotation in the kernels' epilogues, include/rankpo_hip.h)."""
+    come back as the gradients w.r.t. the PRE-rotary q / k (inverse rotation in the kernels' epilogues, include/rankpo_hip.h).
+    q_block = the query rows per entry of `q_tiles`: 128, or 64 (head_dim 64: a list of 64-query x 4-head entries,
+    `attn_tile_table(..., block_m=64, heads_per_block=4)`, for the one-wave-per-SIMD dQ kernel)."""
     lib = _lib.load()
     if rope is not None:
         _check_rope_tables(rope, q.shape[-1], "flash_attn_varlen_bwd")
@@ -818,7 +820,7 @@ def flash_attn_varlen_bwd(q, k, v, out, dout, lse, cu_seqlens, q_tiles, k_tiles,
                                      dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), dq.stride(0), dk.stride(0), dv.stride(0),
                                      rope[0].data_ptr() if rope is not None else None,
                                      rope[1].data_ptr() if rope is not None else None,
-                                     rope[0].shape[0] if rope is not None else 0,
+                                     rope[0].shape[0] if rope is not None else 0, q_block,
                                      _stream(q)), "rpo_flash_attn_bwd")
     return dq, dk, dv
 

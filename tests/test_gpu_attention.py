@@ -468,6 +468,51 @@ def test_flash_attn_fwd_one_wave_rescales_and_refusals(hd):
         ops.flash_attn_varlen_fwd(q, k, v, cu, ft, scale, q_block=32)
 
 
+@pytest.mark.parametrize("lens,nh,nkv,fused", [
+    ([128], 4, 1, False), ([1], 4, 1, False), ([64, 1, 200, 129, 33, 31, 32, 65, 63], 8, 2, False),
+    ([300, 17, 513, 128, 256, 5], 8, 1, True), ([1000, 777], 4, 1, True), ([4096, 2500], 32, 8, True)])
+def test_flash_attn_dq_one_wave_head_dim_64(lens, nh, nkv, fused):
+    """fa_bwd_dq64w_kernel (rpo_flash_attn_bwd's q_block = 64: 64 queries x 4 q heads per block, one wave per SIMD, generated
+    statements) against fa_bwd_dq_kernel and the f32 reference: dq, and -- through the row constants it writes for the dK/dV
+    kernel -- dk and dv; both list formats; strided views; the rotary epilogue."""
+    from rankpo_amd import ops
+    torch.manual_seed(sum(lens) + 11)
+    T, hd = sum(lens), 64
+    if fused:
+        qkv = torch.randn(T, (nh + 2 * nkv) * hd, device=DEV).to(torch.bfloat16)
+        q, k, v = qkv.split([nh * hd, nkv * hd, nkv * hd], -1)
+        q, k, v = q.view(T, nh, hd), k.view(T, nkv, hd), v.view(T, nkv, hd)
+    else:
+        q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+        k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+        v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    scale = 1.0 / math.sqrt(hd)
+    t128 = ops.attn_tile_table(lens, DEV, nh, nkv)
+    kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=ops.ATTN_KEY_BLOCK)
+    out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, t128, scale)
+    go = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+    qr, kr, vr = (t.detach().float().requires_grad_(True) for t in (q, k, v))
+    ref_attention(qr, kr, vr, lens, scale)[0].backward(go.float())
+    g_old = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, t128, kt, scale)
+    res = []
+    for tl in (ops.attn_tile_table(lens, DEV, block_m=64), ops.attn_tile_table(lens, DEV, nh, nkv, block_m=64, heads_per_block=4)):
+        g_new = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tl, kt, scale, q_block=64)
+        for name, a, b, c in zip(("dq", "dk", "dv"), g_new, (qr.grad, kr.grad, vr.grad), g_old):
+            assert (a.float() - b).abs().max() < 0.03 * max(1.0, b.abs().max().item()), name
+            rel, rel_old = ((a.float() - b).norm() / b.norm()).item(), ((c.float() - b).norm() / b.norm()).item()
+            assert rel <= 1.3 * rel_old + 1e-4, (name, rel, rel_old)
+        assert torch.equal(g_new[1], g_old[1]) and torch.equal(g_new[2], g_old[2])      # the row constants are the old kernel's, bit for bit
+        res.append(g_new[0])
+    assert torch.equal(res[0], res[1])                                                   # the list is only a schedule
+    ang = torch.rand(T, hd // 2, device=DEV) * 6.283
+    rope = (ang.cos().contiguous(), ang.sin().contiguous())
+    a = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, t128, kt, scale, rope=rope)
+    b = ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tl, kt, scale, rope=rope, q_block=64)
+    assert (a[0].float() - b[0].float()).abs().max() <= 2.0 ** -5 * max(1.0, a[0].float().abs().max().item())
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
 def test_flash_attn_bwd128_speed_report():
     """Prints the head_dim-128 backward rate next to PyTorch's flash-attention backward op on a cfg-5-like passage batch (not a gate)."""
     from rankpo_amd import ops

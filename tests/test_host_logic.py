@@ -840,6 +840,9 @@ def test_generated_fwd128w_statements_are_in_sync():
         gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_fwd128w_body.py"), str(hd)], capture_output=True,
                              text=True, check=True, env=env).stdout
         assert gen == open(os.path.join(root, "rankpo_amd", "csrc", f"attention_fwd{hd}w_gen.inc")).read(), hd
+    gen = subprocess.run([sys.executable, os.path.join(root, "tools", "gen", "gen_dq64w_body.py")], capture_output=True, text=True,
+                         check=True, env=env).stdout                      # the head_dim-64 dQ kernel of the same make
+    assert gen == open(os.path.join(root, "rankpo_amd", "csrc", "attention_dq64w_gen.inc")).read()
 
 
 def test_no_valu_reads_a_transcendental_result_in_the_next_slot(tmp_path):
@@ -873,7 +876,7 @@ def _check_fwd128w_register_ownership(attention_s, root):
     C = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(C)
     isa = open(attention_s).read()
-    for kern in ("fa_fwd128w_kernel", "fa_fwd64w_kernel"):
+    for kern in ("fa_fwd128w_kernel", "fa_fwd64w_kernel", "fa_bwd_dq64w_kernel"):
         rep = C.check(isa, kern)
         assert rep["ok"], (kern, rep["problems"][:10])
         assert rep["checked"] >= 1000 and rep["statements"] >= 100, rep  # the loop's own code and the statements were really seen

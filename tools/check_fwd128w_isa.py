@@ -16,8 +16,11 @@ import re
 import sys
 
 INIT_MARK = "v_mov_b32 v224, 0x3f803f80"          # first instruction of RPO_FW_INIT: the bf16 ones
-ACC_MARK = "v_accvgpr_write_b32 a0, 0"            # first instruction of RPO_FW_INIT_ACC
+ACC_MARK = "v_accvgpr_write_b32 a0, 0"            # first instruction of RPO_FW_INIT_ACC / RPO_DQ_INIT_ACC
 LO, HI = 64, 227
+# kernel -> (first instruction of its INIT statement, owned VGPR range): the forwards, and the head_dim-64 dQ kernel of the same make
+KERNELS = {"fa_fwd128w_kernel": (INIT_MARK, 64, 227), "fa_fwd64w_kernel": (INIT_MARK, 64, 227),
+           "fa_bwd_dq64w_kernel": ("v_mov_b32 v192, ", 64, 215)}
 
 
 def kernel_body(isa, name="fa_fwd128w_kernel"):
@@ -30,19 +33,20 @@ def kernel_body(isa, name="fa_fwd128w_kernel"):
     return lines[start[0]:end], tail
 
 
-def _names_owned_vgpr(t):
+def _names_owned_vgpr(t, lo=LO, hi=HI):
     for m in re.finditer(r"\bv(\d+)\b", t):
-        if LO <= int(m.group(1)) <= HI:
+        if lo <= int(m.group(1)) <= hi:
             return True
     for m in re.finditer(r"\bv\[(\d+):(\d+)\]", t):
-        if int(m.group(2)) >= LO and int(m.group(1)) <= HI:
+        if int(m.group(2)) >= lo and int(m.group(1)) <= hi:
             return True
     return False
 
 
 def check(isa, name="fa_fwd128w_kernel"):
     body, tail = kernel_body(isa, name)
-    init_at = next((i for i, l in enumerate(body) if INIT_MARK in l), None)
+    init_mark, lo, hi = KERNELS.get(name, (INIT_MARK, LO, HI))
+    init_at = next((i for i, l in enumerate(body) if init_mark in l), None)
     acc_at = next((i for i, l in enumerate(body) if ACC_MARK in l), None)
     problems = []
     if init_at is None or acc_at is None or acc_at > init_at:
@@ -64,8 +68,8 @@ def check(isa, name="fa_fwd128w_kernel"):
         checked += 1
         if re.search(r"\ba\d+\b|\ba\[\d+", t):
             problems.append("line %d names an accumulator register outside the statements: %s" % (i, t))
-        if i > init_at and _names_owned_vgpr(t):
-            problems.append("line %d names a VGPR of v[%d:%d] outside the statements: %s" % (i, LO, HI, t))
+        if i > init_at and _names_owned_vgpr(t, lo, hi):
+            problems.append("line %d names a VGPR of v[%d:%d] outside the statements: %s" % (i, lo, hi, t))
         if t.startswith("scratch_"):
             problems.append("line %d: scratch access: %s" % (i, t))
     m = re.search(r"ScratchSize:\s*(\d+)", tail)
@@ -77,7 +81,7 @@ def check(isa, name="fa_fwd128w_kernel"):
 if __name__ == "__main__":
     isa_ = open(sys.argv[1]).read()
     rc = 0
-    for kern in ("fa_fwd128w_kernel", "fa_fwd64w_kernel"):            # one source (attention_fwdw_kernel.inc), two statement sets
+    for kern in KERNELS:
         rep = check(isa_, kern)
         print("%s: %d instructions of hipcc's behind RPO_FW_INIT_ACC checked, %d asm statements: %s"
               % (kern, rep["checked"], rep["statements"], "ok" if rep["ok"] else "FAILED"))

@@ -39,7 +39,7 @@ def bwd(n):
                                       v.stride(0), out[n].stride(0), go.stride(0), cu.data_ptr(), tiles.data_ptr(), tiles.shape[0],
                                       tiles.shape[1], kt.data_ptr(), kt.shape[0], KB, 0, T, nh, nkv, hd, SC, lse[n].data_ptr(),
                                       delta.data_ptr(), dq[n].data_ptr(), dk[n].data_ptr(), dv[n].data_ptr(), q.stride(0), k.stride(0),
-                                      v.stride(0), None, None, 0, st)
+                                      v.stride(0), None, None, 0, 128, st)
 def t(fn, n=5):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()

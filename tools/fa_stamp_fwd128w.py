@@ -11,7 +11,8 @@ lib.rpo_flash_attn_fwd.restype, lib.rpo_flash_attn_fwd.argtypes = _lib.SIGNATURE
 lib.rpo_debug_fa_stamps.restype = C.c_int
 lib.rpo_debug_fa_stamps.argtypes = [C.c_void_p, C.c_int]
 DEV = "cuda"; torch.manual_seed(0)
-hd, nh, nkv, N, L = 128, 32, 8, 24, 4096
+hd = int(os.environ.get("HD", "128"))
+nh, nkv, N, L = 32, 8, 24 if hd == 128 else 48, 4096
 lens = torch.randint(L // 2, L + 1, (N,)); lens[0] = L
 lens = lens.tolist(); T = sum(lens)
 q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
