@@ -1058,7 +1058,7 @@ def optimizer_state_bytes(nparam, es, world, partitioned):
     return nparam * (es * 2 + ((12 + es) / max(1, world) if partitioned else 12))
 
 
-def modelled_peak_bytes(free_blocks, nparam, es, hidden, inter, nl, tok_pad, world=1, partitioned=False):
+def modelled_peak_bytes(free_blocks, nparam, es, hidden, inter, nl, tok_pad, world=1, partitioned=False, block_inputs=2):
     """Worst-case (every row at full length) peak of allocated HBM with `free_blocks` of the nl blocks un-checkpointed:
       states  +  checkpointed blocks x their kept INPUTS  +  free blocks x their kept activations  +  the block in flight.
     A block's input is TWO [tokens, d] tensors -- the residual stream travels as (x, delta) because the add is fused into the
@@ -1067,16 +1067,17 @@ def modelled_peak_bytes(free_blocks, nparam, es, hidden, inter, nl, tok_pad, wor
     40.6 in flight; allocator slack is on top of that, not inside it).  Kept activations per token of a free block: x, norm(x),
     q|k|v, attention out, x', norm(x'), gate|up (the SwiGLU product is recomputed) <= es (6.5 d + 2 ff), measured 0.75 of that
     on Llama-3.2-1B.  The block in flight (recomputed activations + d(gate|up), d(product), the transposed product ...) was
-    calibrated on the cfg-5 peak: 2.4 kept-block units.  cfg 2 (all 16 blocks free): modelled 187 GiB, measured 198."""
+    calibrated on the cfg-5 peak: 2.4 kept-block units.  cfg 2 (all 16 blocks free): modelled 187 GiB, measured 198.
+    block_inputs = 1 when the encoder forms x + delta in front of a checkpointed block (encoder.CKPT_SINGLE_INPUT, round 5)."""
     per_layer = tok_pad * int(ACT_KEEP_FRACTION * es * (6.5 * hidden + 2 * inter))
-    return (optimizer_state_bytes(nparam, es, world, partitioned) + (nl - free_blocks) * 2 * tok_pad * hidden * es
+    return (optimizer_state_bytes(nparam, es, world, partitioned) + (nl - free_blocks) * block_inputs * tok_pad * hidden * es
             + free_blocks * per_layer + WORKING_SET_BLOCKS * per_layer)
 
 
-def plan_free_blocks(hbm_usable, nparam, es, hidden, inter, nl, tok_pad, world=1, partitioned=False):
+def plan_free_blocks(hbm_usable, nparam, es, hidden, inter, nl, tok_pad, world=1, partitioned=False, block_inputs=2):
     """How many of the nl blocks may run WITHOUT activation checkpointing: the largest count whose modelled worst-case peak
     stays within PLAN_HBM_FRACTION of the usable HBM (0 when even full checkpointing does not: the pre-size step decides)."""
-    shape = (nparam, es, hidden, inter, nl, tok_pad, world, partitioned)
+    shape = (nparam, es, hidden, inter, nl, tok_pad, world, partitioned, block_inputs)
     free = 0
     while free < nl and modelled_peak_bytes(free + 1, *shape) <= PLAN_HBM_FRACTION * hbm_usable:
         free += 1
@@ -1084,14 +1085,14 @@ def plan_free_blocks(hbm_usable, nparam, es, hidden, inter, nl, tok_pad, world=1
 
 
 def plan_checkpointing(hbm_usable, nparam, es, hidden, inter, nl, tok_pad, world=1, multi=False, partition_mode="auto",
-                       per_block_control=True):
+                       per_block_control=True, block_inputs=2):
     """-> (checkpointed blocks: 0 = none, -1 = all for encoders without per-block control, else the first k; partition the
     optimizer state?).  `auto` partitions exactly when the replicated state would force blocks to be checkpointed."""
     shape = (nparam, es, hidden, inter, nl, tok_pad, world)
     partition = multi and partition_mode == "on"
     if multi and partition_mode == "auto":
-        partition = world > 1 and plan_free_blocks(hbm_usable, *shape, partitioned=False) < nl
-    free = plan_free_blocks(hbm_usable, *shape, partitioned=partition)
+        partition = world > 1 and plan_free_blocks(hbm_usable, *shape, partitioned=False, block_inputs=block_inputs) < nl
+    free = plan_free_blocks(hbm_usable, *shape, partitioned=partition, block_inputs=block_inputs)
     ckpt = nl - free
     if not per_block_control:
         ckpt = 0 if free == nl else -1
@@ -1106,6 +1107,19 @@ def presize_is_tight(peak, hbm_usable, oom=False):
 def checkpoint_more(now_ckpt, nl):
     """A quarter more of the blocks, or None when every block is checkpointed already (nothing left to give)."""
     return None if now_ckpt >= nl else min(nl, now_ckpt + max(1, nl // 4))
+
+
+def checkpoint_fewer(peak, hbm_usable, now_ckpt, nparam, es, hidden, inter, nl, tok_pad, block_inputs=2, reserve=0):
+    """After the worst-case step has been MEASURED (peak bytes, with now_ckpt blocks checkpointed) and was not tight: how many blocks
+    to checkpoint instead -- as many fewer as the model says fit under PLAN_HBM_FRACTION of the usable HBM with `reserve` bytes kept
+    aside (the transposed d(gate|up) buffer the run is about to take).  The plan is made from a model that errs on the safe side
+    (cfg 5 with one kept input per block: modelled 234 GiB, measured 204); this hands the difference back once, and the step is
+    measured again afterwards.  Never below 0, never more than now_ckpt."""
+    per_free = tok_pad * int(ACT_KEEP_FRACTION * es * (6.5 * hidden + 2 * inter)) - block_inputs * tok_pad * hidden * es
+    if now_ckpt <= 0 or per_free <= 0:
+        return max(0, now_ckpt)
+    room = PLAN_HBM_FRACTION * hbm_usable - peak - reserve
+    return now_ckpt - max(0, min(now_ckpt, int(room // per_free)))
 
 
 def transposed_dgu_bytes(inter, tok_pad, es):
@@ -1152,6 +1166,8 @@ def main():
                     help="A/B: 2 = rotary folded into the attention forward (q) and backward epilogues, 1 = backward only, 0 = separate passes")
     ap.add_argument("--fwd128", default="onewave", choices=("onewave", "classic"),
                     help="A/B: head_dim-128 attention forward: the one-wave-per-SIMD kernel on its own 64-query x 4-head list, or the 128-query kernel of rounds 3-4")
+    ap.add_argument("--ckpt-inputs", type=int, default=1, choices=(1, 2),
+                    help="A/B: tensors a checkpointed block keeps as its input: 1 = x + delta formed in front of the checkpoint (round 5), 2 = the (x, delta) pair of rounds 2-4")
     ap.add_argument("--lib", default=None,
                     help="A/B: another build of librankpo_hip.so (tools/exp/build_variant.sh) instead of the in-tree one, for an A/B of "
                          "kernel variants INSIDE the training step (stand-alone kernel A/Bs have ranked schedules the step did not)")
@@ -1269,6 +1285,7 @@ def main():
         rankpo_amd.ops.WGRAD_SPLIT_T = args.wgrad_split
     rankpo_amd.encoder.FOLD_ROPE = args.fold_rope
     rankpo_amd.encoder.FWD128_ONE_WAVE = args.fwd128 == "onewave"
+    rankpo_amd.encoder.CKPT_SINGLE_INPUT = args.ckpt_inputs == 1
     if args.dkdv_heaviest_first:
         rankpo_amd.ops.ATTN_SWEEP_DOWN = rankpo_amd.ops.ATTN_SWEEP_DOWN_HD128 = False
     if args.dkdv_tail is not None:
@@ -1302,7 +1319,7 @@ def main():
     # the plan itself: pure functions above (tested without a GPU)
     plan_ckpt, partition = plan_checkpointing(hbm_usable, nparam, es, cfg.hidden_size, cfg.intermediate_size, nl, tok_pad,
                                               world=world, multi=multi, partition_mode=args.partition_optimizer,
-                                              per_block_control=hasattr(enc, "layers"))
+                                              per_block_control=hasattr(enc, "layers"), block_inputs=args.ckpt_inputs)
     if ckpt == -2:
         ckpt = plan_ckpt
     if ckpt != 0 and hasattr(enc, "layers"):
@@ -1390,6 +1407,27 @@ def main():
             can_more = more is not None
             note(f"allocator pre-sized on a full-length batch: peak mem {peak / 2**30:.1f} GiB of {hbm_usable / 2**30:.1f} usable"
                  + (" -- OUT OF MEMORY" if oom else "") + (f"; tight: checkpointing more blocks ({now_ckpt} of {nl} so far)" if tight and can_more else ""))
+            if not tight and not oom and hasattr(enc, "layers") and args.ckpt_layers == -2 and not mem_guard.get("loosened") \
+                    and mem_guard["retries"] == 0 and now_ckpt > 0:
+                # the measured peak leaves room under the plan's own budget: hand it back, once, and measure again
+                dgu_need = transposed_dgu_bytes(getattr(cfg, "intermediate_size", 0), tok_pad, es)
+                reserve = 2 * dgu_need if ("llama" in arch and not args.no_dgu_t and not args.no_prod_t
+                                           and dgu_need > rankpo_amd.ops.SWIGLU_DGU_T_MAX_BYTES) else 0
+                fewer = checkpoint_fewer(peak, hbm_usable, now_ckpt, nparam, es, cfg.hidden_size, cfg.intermediate_size, nl, tok_pad,
+                                         args.ckpt_inputs, reserve)
+                if multi:
+                    fw = torch.tensor([float(fewer)], device=device)
+                    dist.all_reduce(fw, op=dist.ReduceOp.MAX)
+                    fewer = int(fw.item())
+                mem_guard["loosened"] = now_ckpt - fewer
+                if fewer < now_ckpt:
+                    note(f"the measured peak leaves room under the plan: {fewer} blocks checkpointed instead of {now_ckpt}; measuring again")
+                    ckpt = fewer
+                    model.gradient_checkpointing_enable(layers=ckpt)
+                    ts.opt.reducer.zero_()
+                    torch.cuda.empty_cache()
+                    torch.cuda.reset_peak_memory_stats(device)
+                    continue
             if not tight or not can_more:
                 if oom:
                     raise SystemExit(f"bench: the worst-case step does not fit in {hbm_usable / 2**30:.1f} GiB of HBM with every block checkpointed")
@@ -1431,7 +1469,8 @@ def main():
         if "llama" in arch:
             run_ckpt = nl if ckpt < 0 else ckpt
             mem_guard["modelled_peak_GiB"] = round(modelled_peak_bytes(nl - run_ckpt, nparam, es, cfg.hidden_size, cfg.intermediate_size,
-                                                                       nl, tok_pad, world, ts.opt.partition) / 2 ** 30, 1)
+                                                                       nl, tok_pad, world, ts.opt.partition, args.ckpt_inputs) / 2 ** 30, 1)
+            mem_guard["checkpoint_inputs_per_block"] = args.ckpt_inputs
         mem_guard.update(checkpointed_blocks_run=(nl if ckpt < 0 else ckpt),
                          presize_peak_GiB=round(torch.cuda.max_memory_allocated(device) / 2 ** 30, 1),
                          presize_peak_over_usable=round(torch.cuda.max_memory_allocated(device) / hbm_usable, 3))

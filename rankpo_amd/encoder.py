@@ -186,6 +186,12 @@ class RopeTables:
 FOLD_ROPE = 2        # packed training path: rotary + attention as ONE autograd node; 2 = q rotated by the attention forward block
 #                      that loads it + inverse rotary in the dQ / dK epilogues, 1 = the epilogues only, 0 = two nodes with
 #                      separate rpo_rope passes both ways (the A/B arms of `bench.py --fold-rope`)
+CKPT_SINGLE_INPUT = True  # a CHECKPOINTED block receives the residual stream as ONE tensor: x + delta is formed before the checkpoint
+#                           boundary (one elementwise pass per checkpointed block) instead of inside the block's first add + RMSNorm, so
+#                           that the checkpoint keeps one [tokens, d] tensor per block, not two: 50 GiB at cfg 5 (32 blocks x 206 848
+#                           tokens x 4096 x 2 bytes), which the plan spends on un-checkpointed blocks.  (HF forms the sum in bf16 and
+#                           normalises the rounded sum: this is the reference's own arithmetic; the fused kernel normalises the
+#                           unrounded f32 sum.)  False: rounds 2-4 (the A/B arm of `bench.py --ckpt-inputs 2`)
 FWD128_ONE_WAVE = True   # head_dim 128 with 4 (8, ..) q heads per kv head: the forward walks its own list (64 queries x 4 heads per entry)
 #                          with the one-wave-per-SIMD kernel (ops.FWD_ONE_WAVE_HEAD_DIMS names the head dims); False: the 128-query kernel
 #                          of rounds 3-4 (the A/B arm of `bench.py --fwd128 classic`)
@@ -540,6 +546,8 @@ class LlamaEncoder(nn.Module):
         delta = None
         for i, layer in enumerate(self.layers if upto is None else self.layers[:upto]):
             if ck and i < nck:
+                if CKPT_SINGLE_INPUT and delta is not None:
+                    x, delta = x + delta, None
                 x, delta = checkpoint(layer, x, delta, rope, ctx, use_reentrant=False)
             else:
                 x, delta = layer(x, delta, rope, ctx)
@@ -619,6 +627,8 @@ class LlamaEncoder(nn.Module):
         ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
         nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
         if ck and li < nck:
+            if CKPT_SINGLE_INPUT and delta is not None:
+                x, delta = x + delta, None
             last = checkpoint(self.layers[li].forward_last_rows, x, delta, rope, ctx, last_idx, use_reentrant=False)
         else:
             last = self.layers[li].forward_last_rows(x, delta, rope, ctx, last_idx)         # [N, d]

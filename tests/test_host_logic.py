@@ -1054,6 +1054,20 @@ def test_memory_guard_plans_cfg2_and_cfg5_without_a_gpu():
     # the calibration point: state + two kept input tensors per block + the block in flight (profiles/r05_cfg5_memory_summary.txt)
     assert abs(bench.modelled_peak_bytes(0, *_LLAMA_8B, _TOK_CONTRASTIVE) / _GIB - 253.4) < 2.0
     assert abs(bench.optimizer_state_bytes(_LLAMA_8B[0], 2, 1, False) / _GIB - 111.8) < 0.2
+    # round 5: x + delta is formed in front of a checkpointed block, which then keeps ONE input tensor: 50.5 GiB less at cfg 5,
+    # spent on two un-checkpointed blocks (each 17 GiB of activations instead of 1.6 GiB of input)
+    assert abs(bench.modelled_peak_bytes(0, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) / _GIB - (253.7 - 50.5)) < 0.5
+    assert bench.plan_free_blocks(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) == 2
+    assert bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) == (30, False)
+    assert bench.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, block_inputs=1) == (0, False)
+    # ... and what the measured worst-case step leaves under the plan's own budget goes back, once: cfg 5 measured 204.4 GiB with 30
+    # blocks checkpointed (modelled 234); with 2 x 11 GiB set aside for the transposed d(gate|up) buffer one more block runs free
+    shape8 = _LLAMA_8B + (_TOK_CONTRASTIVE,)
+    assert bench.checkpoint_fewer(int(204.4 * _GIB), usable, 30, *shape8, block_inputs=1, reserve=2 * int(11.0 * _GIB)) == 29
+    assert bench.checkpoint_fewer(int(204.4 * _GIB), usable, 30, *shape8, block_inputs=1) == 28
+    assert bench.checkpoint_fewer(int(243.0 * _GIB), usable, 30, *shape8, block_inputs=1) == 30          # no room: nothing changes
+    assert bench.checkpoint_fewer(int(60.0 * _GIB), usable, 2, *shape8, block_inputs=1) == 0             # never below zero
+    assert bench.checkpoint_fewer(int(60.0 * _GIB), usable, 0, *shape8, block_inputs=1) == 0
     # 8 ranks: `auto` partitions the optimizer state exactly because the replicated state forces checkpointing, and gives the
     # freed 70 GiB back to activations
     ckpt, part = bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="auto")

@@ -1,8 +1,16 @@
 set -e
-cd $GRAFT_REPO_ROOT
-o=gpurun_out/r5y
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+o=gpurun_out/r5z
 mkdir -p $o
-(ONLY=old timeout -k 10 100 python3 tools/fa_dq64_ab.py 2>&1 | grep bwd64
-ONLY=new timeout -k 10 100 python3 tools/fa_dq64_ab.py 2>&1 | grep bwd64
-for n in x0 x4 noval; do echo "== $n"; LIB=tools/exp/librankpo_hip_dq_$n.so ONLY=new timeout -k 10 100 python3 tools/fa_dq64_ab.py 2>&1 | grep bwd64; done) > $o/dq64_variants.txt 2>&1
-cat $o/dq64_variants.txt
+N="--no-cpu-baseline --no-sweep"
+timeout -k 10 400 python3 bench.py --workload cfg5 --steps 3 --warmup 1 $N > $o/bench_cfg5_auto.json 2> $o/bench_cfg5_auto.err || echo failed
+timeout -k 10 400 python3 bench.py --workload cfg5 --steps 3 --warmup 1 $N --ckpt-inputs 2 > $o/bench_cfg5_auto_ck2.json 2> $o/bench_cfg5_auto_ck2.err || echo failed
+timeout -k 10 400 python3 bench.py --workload cfg5r --steps 3 --warmup 1 $N > $o/bench_cfg5r_auto.json 2> $o/bench_cfg5r_auto.err || echo failed
+timeout -k 10 400 python3 bench.py --workload cfg5r --steps 3 --warmup 1 $N --ckpt-inputs 2 > $o/bench_cfg5r_auto_ck2.json 2> $o/bench_cfg5r_auto_ck2.err || echo failed
+python3 - <<'PY'
+import json
+for f in ("bench_cfg5_auto", "bench_cfg5_auto_ck2", "bench_cfg5r_auto", "bench_cfg5r_auto_ck2"):
+    d = json.loads(open(f"gpurun_out/r5z/{f}.json").read().strip().split("\n")[-1])
+    print(f, d["value"], d["ms_per_step"], d.get("peak_mem_GiB"), d["config"]["memory_guard"], d.get("step_loss_parity", {}).get("pass"))
+PY
+grep -n "leaves room\|pre-sized" $o/bench_cfg5_auto.err | cut -c1-200
