@@ -145,7 +145,11 @@ def test_product_bert_vs_oracle_and_grads():
     assert (got - ref)[m.bool()].abs().max() < 3e-5
 
 
-def test_gradient_checkpointing_is_exact():
+@pytest.mark.parametrize("single_input", [True, False])
+def test_gradient_checkpointing_is_exact(single_input, monkeypatch):
+    """Checkpointed blocks compute what un-checkpointed ones do, whether the checkpoint keeps the residual stream as one tensor
+    (x + delta formed in front of the block: encoder.CKPT_SINGLE_INPUT, round 5) or as the (x, delta) pair of rounds 2-4."""
+    monkeypatch.setattr(PE, "CKPT_SINGLE_INPUT", single_input)
     torch.manual_seed(4)
     cfg = PE.llama_config(pad_token_id=0, **LLAMA_CFGS[0])
     enc = PE.LlamaEncoder(cfg).train()
