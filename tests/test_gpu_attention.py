@@ -513,6 +513,34 @@ def test_flash_attn_dq_one_wave_head_dim_64(lens, nh, nkv, fused):
     assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
 
 
+@pytest.mark.parametrize("hd", [128, 64])
+def test_one_wave_kernels_on_a_long_sequence(hd):
+    """16 k tokens in one sequence (512 key tiles: the K / V rings of the one-wave kernels wrap 64-128 times, the eight statement
+    variants of the dQ kernel and the four of the forward come round many times) beside a short one, against the 128-query
+    kernels -- forward at both head dims, and the head_dim-64 dQ kernel."""
+    from rankpo_amd import ops
+    torch.manual_seed(3 + hd)
+    lens, nh, nkv = [16384 + 37, 70], 4, 1
+    T = sum(lens)
+    q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+    k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+    v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    scale = 1.0 / math.sqrt(hd)
+    t128 = ops.attn_tile_table(lens, DEV, nh, nkv)
+    t64 = ops.attn_fwd_tile_table(lens, DEV, nh, nkv, hd, force=True)
+    o_a, l_a = ops.flash_attn_varlen_fwd(q, k, v, cu, t128, scale)
+    o_b, l_b = ops.flash_attn_varlen_fwd(q, k, v, cu, t64, scale, q_block=64)
+    assert (o_a.float() - o_b.float()).abs().max() <= 2.0 ** -6 and (l_a - l_b).abs().max() < 3e-3
+    if hd == 64:
+        kt = ops.attn_key_tile_table(lens, DEV, nkv, block_n=ops.ATTN_KEY_BLOCK)
+        go = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+        g_a = ops.flash_attn_varlen_bwd(q, k, v, o_a, go, l_a, cu, t128, kt, scale)
+        g_b = ops.flash_attn_varlen_bwd(q, k, v, o_a, go, l_a, cu, t64, kt, scale, q_block=64)
+        assert (g_a[0].float() - g_b[0].float()).abs().max() <= 2.0 ** -6 * max(1.0, g_a[0].float().abs().max().item())
+        assert torch.equal(g_a[1], g_b[1]) and torch.equal(g_a[2], g_b[2])
+
+
 def test_flash_attn_bwd128_speed_report():
     """Prints the head_dim-128 backward rate next to PyTorch's flash-attention backward op on a cfg-5-like passage batch (not a gate)."""
     from rankpo_amd import ops
