@@ -1168,6 +1168,8 @@ def main():
                     help="A/B: head_dim-128 attention forward: the one-wave-per-SIMD kernel on its own 64-query x 4-head list, or the 128-query kernel of rounds 3-4")
     ap.add_argument("--ckpt-inputs", type=int, default=1, choices=(1, 2),
                     help="A/B: tensors a checkpointed block keeps as its input: 1 = x + delta formed in front of the checkpoint (round 5), 2 = the (x, delta) pair of rounds 2-4")
+    ap.add_argument("--recompute-output", action="store_true",
+                    help="A/B: a recomputed (checkpointed) block also recomputes its own OUTPUT -- the SwiGLU product and the down projection -- as rounds 2-4 did (ops.SKIP_RECOMPUTED_OUTPUT = False)")
     ap.add_argument("--lib", default=None,
                     help="A/B: another build of librankpo_hip.so (tools/exp/build_variant.sh) instead of the in-tree one, for an A/B of "
                          "kernel variants INSIDE the training step (stand-alone kernel A/Bs have ranked schedules the step did not)")
@@ -1286,6 +1288,7 @@ def main():
     rankpo_amd.encoder.FOLD_ROPE = args.fold_rope
     rankpo_amd.encoder.FWD128_ONE_WAVE = args.fwd128 == "onewave"
     rankpo_amd.encoder.CKPT_SINGLE_INPUT = args.ckpt_inputs == 1
+    rankpo_amd.ops.SKIP_RECOMPUTED_OUTPUT = not args.recompute_output
     if args.dkdv_heaviest_first:
         rankpo_amd.ops.ATTN_SWEEP_DOWN = rankpo_amd.ops.ATTN_SWEEP_DOWN_HD128 = False
     if args.dkdv_tail is not None:

@@ -197,6 +197,13 @@ FWD128_ONE_WAVE = True   # head_dim 128 with 4 (8, ..) q heads per kv head: the 
 #                          of rounds 3-4 (the A/B arm of `bench.py --fwd128 classic`)
 
 
+def _checkpoint_contexts():
+    """torch.utils.checkpoint's `context_fn`: (context of the forward, context of the recomputation) -- the latter tells the ops
+    that what a block computes LAST is wasted there (`ops.recomputing`)."""
+    import contextlib
+    return contextlib.nullcontext(), _ops.recomputing()
+
+
 class VarlenCtx:
     """cu_seqlens (int32, device), the host copy of the lengths and the longest length of a packed batch; the attention kernels'
     work lists: `tiles` (128 queries per entry: forward and dQ), `k_tiles` (dK/dV), `fwd_tiles` (the forward's own list where it has
@@ -548,7 +555,7 @@ class LlamaEncoder(nn.Module):
             if ck and i < nck:
                 if CKPT_SINGLE_INPUT and delta is not None:
                     x, delta = x + delta, None
-                x, delta = checkpoint(layer, x, delta, rope, ctx, use_reentrant=False)
+                x, delta = checkpoint(layer, x, delta, rope, ctx, use_reentrant=False, context_fn=_checkpoint_contexts)
             else:
                 x, delta = layer(x, delta, rope, ctx)
         return x, delta
@@ -629,7 +636,8 @@ class LlamaEncoder(nn.Module):
         if ck and li < nck:
             if CKPT_SINGLE_INPUT and delta is not None:
                 x, delta = x + delta, None
-            last = checkpoint(self.layers[li].forward_last_rows, x, delta, rope, ctx, last_idx, use_reentrant=False)
+            last = checkpoint(self.layers[li].forward_last_rows, x, delta, rope, ctx, last_idx, use_reentrant=False,
+                              context_fn=_checkpoint_contexts)
         else:
             last = self.layers[li].forward_last_rows(x, delta, rope, ctx, last_idx)         # [N, d]
         pooled = self.norm(last)

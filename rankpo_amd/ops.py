@@ -423,6 +423,23 @@ def linear(x, w, bias=None):
     return torch.nn.functional.linear(x, w, bias)
 
 
+class recomputing:
+    """Context of a checkpointed block's RECOMPUTATION (torch.utils.checkpoint's `context_fn`, encoder._run_layers): what a block
+    computes last -- the SwiGLU product and the down projection, `_SwiGLUDown.forward` -- feeds nothing the backward reads (the
+    checkpoint keeps the recomputed SAVED tensors and drops the block's outputs), so under this context that forward returns an
+    uninitialised tensor of the right shape instead: one [tokens, ff] pass and one GEMM per checkpointed block and step less
+    (Llama-3-8B at 206 848 tokens: 17 of a block's ~56 ms of recomputation)."""
+    depth = 0
+
+    def __enter__(self):
+        recomputing.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        recomputing.depth -= 1
+        return False
+
+
 class _SwiGLUDown(torch.autograd.Function):
     """y = (silu(g) * u) @ W^T with gu = [g | u] the output of ONE fused gate|up projection.  Saves gu and W only: the
     [tokens, ff] product (the largest activation of the block) is recomputed by one fused pass in backward."""
@@ -433,8 +450,10 @@ class _SwiGLUDown(torch.autograd.Function):
         gu = gu.contiguous()
         ff = gu.shape[-1] // 2
         rows = gu.numel() // (2 * ff)
-        prod = _swiglu_fwd(lib, gu, torch.empty(gu.shape[:-1] + (ff,), dtype=gu.dtype, device=gu.device), rows, ff)
         ctx.save_for_backward(gu, weight)
+        if recomputing.depth > 0 and SKIP_RECOMPUTED_OUTPUT:      # the output of a recomputed block is never read
+            return torch.empty(gu.shape[:-1] + (weight.shape[0],), dtype=gu.dtype, device=gu.device)
+        prod = _swiglu_fwd(lib, gu, torch.empty(gu.shape[:-1] + (ff,), dtype=gu.dtype, device=gu.device), rows, ff)
         return torch.nn.functional.linear(prod, weight)
 
     @staticmethod
@@ -660,6 +679,7 @@ def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, blo
 # instructions' issue slots, and a second wave per SIMD fills what one wave leaves at barriers and LDS waits
 # (profiles/r05_fa_fwd128w_ladder.md).
 FWD_ONE_WAVE_HEAD_DIMS = (128,)
+SKIP_RECOMPUTED_OUTPUT = True   # see `recomputing`; False: the A/B arm of `bench.py --recompute-output`
 
 
 def attn_fwd_tile_table(lens, device, num_heads: int, num_kv_heads: int, head_dim: int, force: bool = False):
@@ -1056,5 +1076,5 @@ def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
 
 __all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
-           "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table",
+           "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table", "recomputing",
            "attn_key_tile_table"]

@@ -111,6 +111,52 @@ def test_bench_path_parity_bf16_packed_filler(hd, ckpt):
     assert rep["fast_path"]["cos_max_err"] < 2e-2
 
 
+@pytest.mark.parametrize("hd", [64, 128])
+def test_checkpointed_blocks_skip_their_recomputed_output_and_keep_one_input(hd):
+    """Round 5's two changes to checkpointed blocks change no result that is read: (1) under `ops.recomputing` a block's LAST
+    computation -- the SwiGLU product and the down projection -- is skipped (its output is dropped by the checkpoint anyway): loss
+    and EVERY weight gradient are bit-identical to the run that recomputes it, and the skip really happens (one `rpo_swiglu_fwd`
+    less per checkpointed block); (2) the checkpoint keeps x + delta instead of the pair (the reference's own arithmetic: the sum
+    rounded to bf16, then normalised): gradients agree with the pair form to bf16 round-off."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE, ops, _lib
+    cfg, enc, model = _model(PE, rankpo_amd, seed=3, hd=hd)
+    model.gradient_checkpointing_enable()
+    batch, _ = _batch()
+    gb = {k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in batch.items()}
+    lib = _lib.load()
+    calls = {"n": 0}
+    real = lib.rpo_swiglu_fwd
+
+    def counting(*a):
+        calls["n"] += 1
+        return real(*a)
+
+    def run(skip, single):
+        ops.SKIP_RECOMPUTED_OUTPUT, PE.CKPT_SINGLE_INPUT = skip, single
+        enc.zero_grad()
+        calls["n"] = 0
+        lib.rpo_swiglu_fwd = counting
+        try:
+            out = model(**gb)
+            out.loss.backward()
+        finally:
+            lib.rpo_swiglu_fwd = real
+        return out.loss.item(), {n: p.grad.detach().clone() for n, p in enc.named_parameters()}, calls["n"]
+    try:
+        l_skip, g_skip, n_skip = run(True, True)
+        l_full, g_full, n_full = run(False, True)
+        l_pair, g_pair, _ = run(True, False)
+    finally:
+        ops.SKIP_RECOMPUTED_OUTPUT, PE.CKPT_SINGLE_INPUT = True, True
+    assert l_skip == l_full and all(torch.equal(g_skip[n], g_full[n]) for n in g_skip)
+    assert n_full - n_skip == cfg.num_hidden_layers, (n_full, n_skip)              # one product pass per checkpointed block less
+    assert abs(l_skip - l_pair) < 2e-3 * max(1.0, abs(l_pair))
+    num = sum((g_skip[n].float() - g_pair[n].float()).norm() ** 2 for n in g_skip) ** 0.5
+    den = sum(g_pair[n].float().norm() ** 2 for n in g_pair) ** 0.5
+    assert (num / den).item() < 2e-2, (num / den).item()
+
+
 def test_filler_sequence_changes_nothing():
     """pack_fill on / off (256-token rounding of the packed batch): same pooled rows, same loss, same weight gradients.
     The filler is a sequence of its own, its pooled row is dropped and it has no gradient, so it adds exact zeros to every
