@@ -1,7 +1,7 @@
 # round 5, final evidence call E1 (one MI355X) at HEAD: the whole GPU suite, the headline workload as the driver runs it, the PMC passes
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-o=gpurun_out/r6a
+o=gpurun_out/r6g
 mkdir -p $o
 timeout -k 10 800 python3 -m pytest tests -x -q -m gpu > $o/pytest_gpu.log 2>&1 || true
 tail -3 $o/pytest_gpu.log
@@ -11,7 +11,7 @@ bash tools/pmc_run.sh $o/pmc > $o/pmc_run.log 2>&1
 python3 - <<'PY'
 import json
 for f in ("bench_default", "bench_driver_like"):
-    d = json.loads(open(f"gpurun_out/r6a/{f}.json").read().strip().split("\n")[-1])
+    d = json.loads(open(f"gpurun_out/r6g/{f}.json").read().strip().split("\n")[-1])
     print(f, d["value"], d["ms_per_step"], d["roofline"]["kernel"], d["roofline"]["frac"], d["step_roofline"]["frac"], d["step_loss_parity"]["pass"])
 PY
 echo callE1 done

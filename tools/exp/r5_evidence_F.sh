@@ -2,7 +2,7 @@
 # the N > 1 code path at world 1 over RCCL and as 4 ranks on one GPU
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-o=gpurun_out/r6b
+o=gpurun_out/r6h
 mkdir -p $o
 N="--no-cpu-baseline --no-sweep"
 python3 bench.py --workload cfg5 --steps 3 --warmup 1 $N > $o/bench_cfg5.json 2> $o/bench_cfg5.err
@@ -19,7 +19,7 @@ python3 bench.py --gpus 4 --share-gpu --workload tiny --steps 2 --warmup 1 --no-
 python3 - <<'PY'
 import json
 for f in ("bench_cfg5", "bench_cfg5_profiled", "bench_cfg5r", "bench_cfg4", "bench_cfg1", "bench_cfg2_profiled", "forcedist_w1", "forcedist_w1_partitioned", "rehearsal_4ranks"):
-    d = json.loads(open(f"gpurun_out/r6b/{f}.json").read().strip().split("\n")[-1])
+    d = json.loads(open(f"gpurun_out/r6h/{f}.json").read().strip().split("\n")[-1])
     c = d.get("comm", {})
     print(f, d["value"], d["ms_per_step"], d.get("peak_mem_GiB"), c.get("ranks_seen"), c.get("params_in_sync"))
 PY
