@@ -6,6 +6,7 @@ done by librankpo_hip.so.  There is no fallback: tensors must live on a HIP devi
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from dataclasses import dataclass
 
 import torch
@@ -429,14 +430,18 @@ class recomputing:
     checkpoint keeps the recomputed SAVED tensors and drops the block's outputs), so under this context that forward returns an
     uninitialised tensor of the right shape instead: one [tokens, ff] pass and one GEMM per checkpointed block and step less
     (Llama-3-8B at 206 848 tokens: 17 of a block's ~56 ms of recomputation)."""
-    depth = 0
+    _tls = threading.local()      # per thread: autograd runs the recomputation on ITS thread, and only that thread's forwards are recomputations
+
+    @staticmethod
+    def active():
+        return getattr(recomputing._tls, "depth", 0) > 0
 
     def __enter__(self):
-        recomputing.depth += 1
+        recomputing._tls.depth = getattr(recomputing._tls, "depth", 0) + 1
         return self
 
     def __exit__(self, *exc):
-        recomputing.depth -= 1
+        recomputing._tls.depth -= 1
         return False
 
 
@@ -451,7 +456,7 @@ class _SwiGLUDown(torch.autograd.Function):
         ff = gu.shape[-1] // 2
         rows = gu.numel() // (2 * ff)
         ctx.save_for_backward(gu, weight)
-        if recomputing.depth > 0 and SKIP_RECOMPUTED_OUTPUT:      # the output of a recomputed block is never read
+        if SKIP_RECOMPUTED_OUTPUT and recomputing.active():      # the output of a recomputed block is never read
             return torch.empty(gu.shape[:-1] + (weight.shape[0],), dtype=gu.dtype, device=gu.device)
         prod = _swiglu_fwd(lib, gu, torch.empty(gu.shape[:-1] + (ff,), dtype=gu.dtype, device=gu.device), rows, ff)
         return torch.nn.functional.linear(prod, weight)
