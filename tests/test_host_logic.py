@@ -1039,6 +1039,39 @@ _LLAMA_1B = (1_235_828_736 + 7 * 2048, 2, 2048, 8192, 16)      # parameters, byt
 _LLAMA_8B = (7_504_953_344, 2, 4096, 14336, 32)
 
 
+def test_recomputation_context_is_seen_only_by_the_recomputation():
+    """encoder._checkpoint_contexts hands torch.utils.checkpoint a recomputation context (ops.recomputing) under which a block's last
+    computation may be skipped: it must be active during the recomputation inside backward -- on whichever thread autograd runs it --
+    and at no other time (first forward, un-checkpointed calls, after backward)."""
+    import torch
+    from torch.utils.checkpoint import checkpoint
+    from rankpo_amd import encoder as PE, ops
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            seen.append(ops.recomputing.active())
+            ctx.save_for_backward(x)
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            return g * 2.0
+    x = torch.ones(3, requires_grad=True)
+    y = checkpoint(lambda t: Probe.apply(t).sum(), x, use_reentrant=False, context_fn=PE._checkpoint_contexts)
+    assert seen == [False] and not ops.recomputing.active()
+    y.backward()
+    assert seen == [False, True] and not ops.recomputing.active() and torch.equal(x.grad, torch.full((3,), 2.0))
+    Probe.apply(x).sum().backward()                                  # no checkpoint: never a recomputation
+    assert seen == [False, True, False]
+    with ops.recomputing():
+        with ops.recomputing():
+            assert ops.recomputing.active()
+        assert ops.recomputing.active()                              # nests
+    assert not ops.recomputing.active()
+
+
 def test_memory_guard_plans_cfg2_and_cfg5_without_a_gpu():
     """The checkpointing plan is a pure function of (usable bytes, model shape, world): bench.py's round-4 cfg-5 run died of a
     memory decision that only a GPU run could exercise (gpurun_out/r5h).  Pinned here against what the GPU measured:
