@@ -1057,7 +1057,8 @@ def test_recomputation_context_is_seen_only_by_the_recomputation():
 
         @staticmethod
         def backward(ctx, g):
-            return g * 2.0
+            (x_,) = ctx.saved_tensors                                # (unpacking is what triggers the recomputation)
+            return g * 2.0 + 0.0 * x_
     x = torch.ones(3, requires_grad=True)
     y = checkpoint(lambda t: Probe.apply(t).sum(), x, use_reentrant=False, context_fn=PE._checkpoint_contexts)
     assert seen == [False] and not ops.recomputing.active()
