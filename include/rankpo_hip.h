@@ -42,7 +42,7 @@ typedef enum {
     RPO_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after the launch */
 } rpo_status;
 
-typedef enum { RPO_DT_F32 = 0, RPO_DT_BF16 = 1 } rpo_dtype;
+typedef enum { RPO_DT_F32 = 0, RPO_DT_BF16 = 1, RPO_DT_F16 = 2 } rpo_dtype;
 typedef enum { RPO_POOL_LAST = 0, RPO_POOL_CLS = 1 } rpo_pool_mode;
 /* INBATCH: scores [Q,P], target_i = i * (P / Q)  (modeling.py:292-302)
  * FIRST:   scores [Q,G] with G = P / Q, row i scored against p rows i*G .. i*G+G-1, target 0 (305-311) */
@@ -50,6 +50,11 @@ typedef enum { RPO_TARGET_INBATCH = 0, RPO_TARGET_FIRST = 1 } rpo_target_mode;
 typedef enum { RPO_LOSS_SIGMOID = 0, RPO_LOSS_HINGE = 1 } rpo_loss_type;
 
 int rpo_version(void);
+/* What this build of the library contains beyond the default: a bit set of rpo_build_flag.  RPO_BUILD_ONEWAVE64: the head_dim-64
+ * one-wave-per-SIMD attention kernels (q_block = 64 at head_dim 64 in rpo_flash_attn_fwd / _bwd; `make ONEWAVE64=1`).  They are
+ * correct and measured 4-10 % slower than the default kernels at head_dim 64, so the default build answers RPO_ERR_UNSUPPORTED there. */
+typedef enum { RPO_BUILD_ONEWAVE64 = 1 } rpo_build_flag;
+int rpo_build_flags(void);
 const char* rpo_status_string(int status);
 /* hipGetErrorString of the HIP error behind the calling thread's most recent RPO_ERR_LAUNCH (diagnostics). */
 const char* rpo_last_hip_error(void);
@@ -252,6 +257,8 @@ int rpo_add_rmsnorm_bwd(const void* dy, const void* x_new, const void* weight, c
  * out: [T, num_heads * hd] (token stride out_stride), lse = log sum_j exp(scale * <q_i, k_j>)
  * over the keys j <= i of the same sequence, f32, laid out [num_heads][T] when lse_max_len == 0 or padded
  * [N][num_heads][lse_max_len] (the layout PyTorch's flash-attention backward reads) when lse_max_len > 0.
+ * lse may be NULL: a forward-only caller (ModelForInference.encode, modeling.py:473-554; the RankPO ref_model under
+ * inference_mode, rankpo_trainer.py:468-477) -- no row statistics are written, nothing else changes.
  * rope_cos / rope_sin (both NULL, or both f32 [rope_period][hd / 2], 16-byte aligned; token t uses row t % rope_period): q
  * arrives UN-rotated and is rotated IN PLACE (q is written!) by the block that owns each (128 queries x head) piece -- the same
  * arithmetic as rpo_rope -- so that the separate rotary pass only has the k heads left; k must arrive rotated (every query

@@ -12,10 +12,11 @@ LIB_PATH = os.path.join(_HERE, "csrc", "librankpo_hip.so")
 
 # enums of include/rankpo_hip.h
 RPO_OK = 0
-RPO_DT_F32, RPO_DT_BF16 = 0, 1
+RPO_DT_F32, RPO_DT_BF16, RPO_DT_F16 = 0, 1, 2
 RPO_POOL_LAST, RPO_POOL_CLS = 0, 1
 RPO_TARGET_INBATCH, RPO_TARGET_FIRST = 0, 1
 RPO_LOSS_SIGMOID, RPO_LOSS_HINGE = 0, 1
+RPO_BUILD_ONEWAVE64 = 1
 RPO_NUM_METRICS = 9
 METRIC_KEYS = (
     "rankpo_loss", "sft_loss", "rewards/chosen", "rewards/rejected", "rewards/accuracies",
@@ -40,6 +41,7 @@ _vp, _i64, _i32, _f32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_size
 # name -> (restype, argtypes); mirrors include/rankpo_hip.h one to one
 SIGNATURES = {
     "rpo_version": (C.c_int, []),
+    "rpo_build_flags": (C.c_int, []),
     "rpo_status_string": (C.c_char_p, [C.c_int]),
     "rpo_last_hip_error": (C.c_char_p, []),
     "rpo_pool_normalize_fwd": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp]),

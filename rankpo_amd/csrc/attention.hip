@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
             w.y = pack_bf16(oacc[c][n][2] * inv, oacc[c][n][3] * inv);
             *reinterpret_cast<uint2*>(orow + 16 * c + 4 * g) = w;
         }
-        if (g == 0)
+        if (g == 0 && lse)                               // lse NULL: forward-only caller (no backward will read it)
             lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
                 mrun[n] * scale + logf(l);
     }
@@ -763,7 +763,7 @@ __global__ __launch_bounds__(64 * WQ * HEADS, WQ * HEADS == 4 ? 2 : 1) void fa_f
             w.y = pack_bf16(oacc[c][n][2] * inv, oacc[c][n][3] * inv);
             *reinterpret_cast<uint2*>(orow + 16 * c + 4 * g) = w;
         }
-        if (g == 0)
+        if (g == 0 && lse)                               // lse NULL: forward-only caller (no backward will read it)
             lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
                 mrun[n] * scale + logf(l);
     }
@@ -802,7 +802,9 @@ __global__ __launch_bounds__(64 * WQ * HEADS, WQ * HEADS == 4 ? 2 : 1) void fa_f
 #else
 #include "attention_fwd128w_gen.inc"
 #endif
-#include "attention_fwd64w_gen.inc"                  // the same statements at head_dim 64 (macros RPO_FW64_*)
+#ifdef RPO_ONEWAVE64                                 // `make ONEWAVE64=1`: the head_dim-64 one-wave kernels (fa_fwd64w_kernel, fa_bwd_dq64w_kernel).
+#include "attention_fwd64w_gen.inc"                  // Built, tested and measured in round 5; they LOSE 4-10 % to the two-waves-per-SIMD kernels
+#endif                                               // at head_dim 64, so the default library leaves their ~6000 generated lines out
 #ifndef RPO_FW_EXP
 #define RPO_FW_EXP 0     // timing-only ablations: 2 no LDS-DMA staging inside the loop, 4 no barrier / ring wait
 #endif
@@ -825,6 +827,7 @@ constexpr float kFwDefer = RPO_FW_DEFER;
 #undef FWW_KERNEL
 #undef FWW_TRS
 #undef FWW_KRS
+#ifdef RPO_ONEWAVE64
 // head_dim 64 (round 5): the same kernel source; 4-KiB images (rings of 16 + 16 KiB), 8-KiB Q / O regions, two DMA pieces per wave
 // and tile.  Half the matrix work per exponential: 16 + 20 MFMAs per tile around the same 32 exponentials per lane.
 #define FWW_HD 64
@@ -838,6 +841,7 @@ constexpr float kFwDefer = RPO_FW_DEFER;
 #undef FWW_KERNEL
 #undef FWW_TRS
 #undef FWW_KRS
+#endif  // RPO_ONEWAVE64
 
 // ------------------------------------------------------------------------------------------------------------------
 // Backward.  Two launches, no atomics, deterministic:
@@ -1094,6 +1098,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
 // fa_bwd_dq_kernel computes it; both row constants are written for the dK/dV kernel); dQ goes out through the same region.
 // K ring: eight 4-KiB images (a K tile is read by rows two iterations before its transposed reads); V ring: four.
 // ------------------------------------------------------------------------------------------------------------------
+#ifdef RPO_ONEWAVE64
 #include "attention_dq64w_gen.inc"
 
 __global__ __launch_bounds__(256, 1) void fa_bwd_dq64w_kernel(
@@ -1342,6 +1347,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dq64w_kernel(
 #undef DQS
 #undef DQS_ADD
 }
+#endif  // RPO_ONEWAVE64
 
 constexpr int kFaDkdvThreads = 512;
 
@@ -4221,13 +4227,21 @@ extern "C" int rpo_debug_fa_stamps(unsigned long long* out64, int reset) {
 }
 #endif
 
+extern "C" int rpo_build_flags(void) {
+#ifdef RPO_ONEWAVE64
+    return RPO_BUILD_ONEWAVE64;
+#else
+    return 0;
+#endif
+}
+
 extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, int64_t q_stride, int64_t k_stride,
                                   int64_t v_stride, const int* cu_seqlens, const int* tiles, int64_t ntiles,
                                   int64_t tile_cols, int64_t total_tokens, int64_t num_heads, int64_t num_kv_heads, int64_t head_dim,
                                   float scale, void* out, int64_t out_stride, float* lse, int64_t lse_max_len,
                                   const float* rope_cos, const float* rope_sin, int64_t rope_period, int64_t q_block,
                                   rpo_stream_t stream) {
-    if (!q || !k || !v || !cu_seqlens || !tiles || !out || !lse || ntiles <= 0 || total_tokens <= 0)
+    if (!q || !k || !v || !cu_seqlens || !tiles || !out || ntiles <= 0 || total_tokens <= 0)      // lse may be NULL (forward only)
         return RPO_ERR_INVALID_ARG;
     // q_block: query rows per work-list entry.  128 (or 0): every kernel.  64: head_dim 128 only -- an entry is 64 queries x the FOUR
     // consecutive q heads that start at the entry's head (format 2: head = 4 x the launch's y index), all of one kv head:
@@ -4265,6 +4279,9 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
 #endif
     if (head_dim == kFa128HD && tile_cols != 3) grid.y = (unsigned)(num_heads / RPO_F128_HEADS);
 #define RPO_F128_KERNEL fa_fwd128_kernel<RPO_F128_WQ, RPO_F128_HEADS, RPO_F128_SUB, RPO_F128_KF>
+#ifndef RPO_ONEWAVE64
+    if (q_block == 64 && head_dim == kFaHD) return RPO_ERR_UNSUPPORTED;       // not in this build (make ONEWAVE64=1; rpo_build_flags())
+#else
     if (q_block == 64 && head_dim == kFaHD) {
         if (tile_cols != 3) grid.y = (unsigned)(num_heads / 4);
         RPO_LAUNCH(fa_fwd64w_kernel, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
@@ -4274,6 +4291,7 @@ extern "C" int rpo_flash_attn_fwd(const void* q, const void* k, const void* v, i
                    (bf16_t*)const_cast<void*>(q));
         return rpo_launch_status();
     }
+#endif
     if (q_block == 64) {
         if (tile_cols != 3) grid.y = (unsigned)(num_heads / 4);
         RPO_LAUNCH(fa_fwd128w_kernel, grid, dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, q_stride,
@@ -4315,6 +4333,9 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
     if (q_block != 128 && !(q_block == 64 && head_dim == kFaHD && num_kv_heads > 0 && num_heads % num_kv_heads == 0 &&
                             (num_heads / num_kv_heads) % 4 == 0 && dq_stride % 8 == 0 && rpo_aligned16(dq)))
         return RPO_ERR_UNSUPPORTED;
+#ifndef RPO_ONEWAVE64
+    if (q_block == 64) return RPO_ERR_UNSUPPORTED;                             // not in this build (make ONEWAVE64=1)
+#endif
     // rope_cos / rope_sin (both or neither): dq / dk leave as gradients w.r.t. the PRE-rotary q / k (inverse rotation in the
     // epilogues); not offered by the 8-wave dK/dV kernel (key_block 64), whose epilogue splits a row's halves over two passes
     if ((rope_cos == nullptr) != (rope_sin == nullptr) || (rope_cos && rope_period <= 0)) return RPO_ERR_INVALID_ARG;
@@ -4366,12 +4387,14 @@ extern "C" int rpo_flash_attn_bwd(const void* q, const void* k, const void* v, c
                        dk_stride, dv_stride, (int)n_k_tiles, gshift128, rope_cos, rope_sin, rope_period);
         return rpo_launch_status();
     }
+#ifdef RPO_ONEWAVE64
     if (q_block == 64)
         RPO_LAUNCH(fa_bwd_dq64w_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)(num_heads / 4)), dim3(256), 0,
                    st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
                    dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse,
                    (const bf16_t*)out, out_stride, nl, nd, total_tokens, (bf16_t*)dq, dq_stride, rope_cos, rope_sin, rope_period);
     else
+#endif
         RPO_LAUNCH(fa_bwd_dq_kernel, dim3((unsigned)n_q_tiles, q_tile_cols == 3 ? 1u : (unsigned)num_heads), dim3(kFaThreads), 0,
                    st, (const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)dout, q_stride, k_stride, v_stride,
                    dout_stride, cu_seqlens, q_tiles, (int)q_tile_cols, (int)num_heads, (int)num_kv_heads, scale * log2e, scale, lse,

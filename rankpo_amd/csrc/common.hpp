@@ -7,6 +7,8 @@
 #define RPO_WAVE 64
 
 typedef unsigned short bf16_t;  // raw bf16 bits
+typedef _Float16 f16_t;         // IEEE half (the reference's fp16 arithmetic: configs/ds_zero1_config_bge.json:2-11, modeling.py:453-454 use_fp16)
+typedef __attribute__((ext_vector_type(8))) _Float16 half8_t; // 8 f16 = one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(8))) short short8_t;   // 8 bf16 = one MFMA A/B fragment (4 VGPRs)
 typedef __attribute__((ext_vector_type(4))) float float4_t;   // 16x16 MFMA accumulator fragment
 typedef __attribute__((ext_vector_type(4))) unsigned int uint4_t;
@@ -35,6 +37,17 @@ template <> struct Elem<bf16_t> {
     __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
     __device__ static __forceinline__ float round(float v) { return round_to_bf16(v); }
 };
+
+template <> struct Elem<f16_t> {
+    static constexpr int kVec = 8;
+    __device__ static __forceinline__ float ld(const f16_t* p) { return (float)*p; }
+    __device__ static __forceinline__ void st(f16_t* p, float v) { *p = (f16_t)v; }          // round to nearest even; overflow -> inf, as torch's .half()
+    __device__ static __forceinline__ float round(float v) { return (float)(f16_t)v; }
+};
+// storage dtype code of a kernel's element type, and element size of a code (host side)
+template <typename T> constexpr int rpo_dtype_of() { return sizeof(T) == 4 ? RPO_DT_F32 : (__is_same(T, bf16_t) ? RPO_DT_BF16 : RPO_DT_F16); }
+static inline int rpo_elem_size(int dtype) { return dtype == RPO_DT_F32 ? 4 : 2; }
+static inline bool rpo_dtype_ok(int dtype) { return dtype == RPO_DT_F32 || dtype == RPO_DT_BF16 || dtype == RPO_DT_F16; }
 
 // 16-byte vector of T held as f32 in registers
 template <typename T> struct Vec16;
@@ -93,6 +106,25 @@ template <> struct Vec16<bf16_t> {
             t[i] = (unsigned)f32_to_bf16(v[2 * i]) | ((unsigned)f32_to_bf16(v[2 * i + 1]) << 16);
         __builtin_nontemporal_store(t, reinterpret_cast<uint4_t*>(p));
     }
+};
+
+template <> struct Vec16<f16_t> {
+    float v[8];
+    __device__ __forceinline__ void unpack(const uint4_t t) {
+        const half8_t h = __builtin_bit_cast(half8_t, t);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)h[i];
+    }
+    __device__ __forceinline__ uint4_t pack() const {
+        half8_t h;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = (f16_t)v[i];
+        return __builtin_bit_cast(uint4_t, h);
+    }
+    __device__ __forceinline__ void load(const f16_t* p) { unpack(*reinterpret_cast<const uint4_t*>(p)); }
+    __device__ __forceinline__ void store(f16_t* p) const { *reinterpret_cast<uint4_t*>(p) = pack(); }
+    __device__ __forceinline__ void load_nt(const f16_t* p) { unpack(__builtin_nontemporal_load(reinterpret_cast<const uint4_t*>(p))); }
+    __device__ __forceinline__ void store_nt(f16_t* p) const { __builtin_nontemporal_store(pack(), reinterpret_cast<uint4_t*>(p)); }
 };
 
 __device__ __forceinline__ bool rpo_aligned16_dev(const void* p) {

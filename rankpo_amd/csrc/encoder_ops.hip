@@ -274,7 +274,8 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in
 extern "C" int rpo_transpose(const void* in, void* out, int64_t rows, int64_t cols, int64_t ld_in, int64_t ld_out, int dtype,
                              rpo_stream_t stream) {
     if (!in || !out || rows <= 0 || cols <= 0 || ld_in < cols || ld_out < rows) return RPO_ERR_INVALID_ARG;
-    if (dtype != RPO_DT_F32 && dtype != RPO_DT_BF16) return RPO_ERR_INVALID_ARG;
+    if (!rpo_dtype_ok(dtype)) return RPO_ERR_INVALID_ARG;
+    if (dtype == RPO_DT_F16) dtype = RPO_DT_BF16;               // a transpose moves bits: any 2-byte element
     const int64_t gx = rpo_cdiv(cols, 64), gy = rpo_cdiv(rows, 64);
     if (gy > 65535) return RPO_ERR_UNSUPPORTED;                 // 4 M rows
     const int es = dtype == RPO_DT_BF16 ? 2 : 4, V = 16 / es;

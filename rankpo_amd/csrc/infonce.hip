@@ -43,6 +43,13 @@ template <> struct Mma<bf16_t> {
     }
     __device__ static __forceinline__ Frag zero() { return Frag{0, 0, 0, 0, 0, 0, 0, 0}; }
 };
+template <> struct Mma<f16_t> {          // f16: the same operand layout, v_mfma_f32_16x16x32_f16
+    typedef half8_t Frag;
+    __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, float4_t& c) {
+        c = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+    }
+    __device__ static __forceinline__ Frag zero() { return Frag{0, 0, 0, 0, 0, 0, 0, 0}; }
+};
 template <> struct Mma<float> {
     typedef float4_t Frag;
     __device__ static __forceinline__ void mma(const Frag& a, const Frag& b, float4_t& c) {
@@ -93,11 +100,15 @@ __device__ __forceinline__ void softmax_merge(float& m, float& l, float om, floa
 template <typename T>
 __device__ __forceinline__ void store_scores4(T* row_ptr, int64_t col, int64_t ncols, const float v[4], bool vec_ok) {
     if (vec_ok && col + 3 < ncols) {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (__is_same(T, bf16_t)) {
             uint2 w;
             w.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
             w.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
             *reinterpret_cast<uint2*>(row_ptr + col) = w;
+        } else if constexpr (__is_same(T, f16_t)) {
+            typedef __attribute__((ext_vector_type(4))) _Float16 half4_;
+            const half4_ h = {(f16_t)v[0], (f16_t)v[1], (f16_t)v[2], (f16_t)v[3]};
+            *reinterpret_cast<half4_*>(row_ptr + col) = h;
         } else {
             *reinterpret_cast<float4*>(row_ptr + col) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -882,9 +893,9 @@ __global__ __launch_bounds__(kSkinnyThreads) void sim_skinny_kernel(
         const T* sp = scores + (int64_t)tid * P + (int64_t)tid * group;
         float tgt;
         if constexpr (sizeof(T) == 2) {
-            const unsigned w = __hip_atomic_load(reinterpret_cast<const unsigned short*>(sp), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-            tgt = __uint_as_float(w << 16);
+            const unsigned short w = __hip_atomic_load(reinterpret_cast<const unsigned short*>(sp), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_AGENT);
+            tgt = Elem<T>::ld(reinterpret_cast<const T*>(&w));
         } else {
             tgt = __uint_as_float(__hip_atomic_load(reinterpret_cast<const unsigned*>(sp), __ATOMIC_RELAXED,
                                                     __HIP_MEMORY_SCOPE_AGENT));
@@ -1296,7 +1307,7 @@ template <typename T> constexpr int row_elems() { return kTileRowBytes / (int)si
 
 static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) {
     Plan pl{};
-    const int es = dtype == RPO_DT_BF16 ? 2 : 4;
+    const int es = rpo_elem_size(dtype);
     const int CE = 16 / es, KE = kTileRowBytes / es;
     const bool chunk_ok = aligned && (d % CE == 0);
     if (!chunk_ok) {
@@ -1346,7 +1357,7 @@ static Plan make_plan(int64_t Q, int64_t P, int64_t d, int dtype, bool aligned) 
 template <typename T>
 int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, float temperature, int target_mode,
              void* scores_out, float* lse_out, float* loss_out, void* ws, size_t ws_bytes, hipStream_t st) {
-    const int dtype = sizeof(T) == 2 ? RPO_DT_BF16 : RPO_DT_F32;
+    const int dtype = rpo_dtype_of<T>();
     const bool do_stats = lse_out != nullptr;
     const int scale = temperature != 1.0f;
     const bool aligned = rpo_aligned16(q) && rpo_aligned16(p);
@@ -1388,7 +1399,7 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
             RPO_LAUNCH((sim_tile_kernel<T, 64, 64, 8>), grid, block, tile_lds_bytes(64, 64, 8), st, (const T*)q, (const T*)p, Q, P, d,
                        temperature, scale, do_stats ? 1 : 0, (T*)scores_out, partial, pl.nPt, pl.nQt);
     } else if (pl.path == PATH_TILE256) {
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (__is_same(T, bf16_t)) {          // make_plan picks this path for bf16 only
             static bool attr_set256 = false;
             if (!attr_set256) {
                 (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1497,7 +1508,7 @@ int bwd_impl(const void* q, const void* p, const void* scores, const float* lse,
 static int check_common(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int dtype, float temperature,
                         int target_mode) {
     if (!q || !p || Q <= 0 || P <= 0 || d <= 0) return RPO_ERR_INVALID_ARG;
-    if (dtype != RPO_DT_F32 && dtype != RPO_DT_BF16) return RPO_ERR_INVALID_ARG;
+    if (!rpo_dtype_ok(dtype)) return RPO_ERR_INVALID_ARG;
     if (target_mode != RPO_TARGET_INBATCH && target_mode != RPO_TARGET_FIRST) return RPO_ERR_INVALID_ARG;
     if (!(temperature > 0.f)) return RPO_ERR_INVALID_ARG;
     if (target_mode == RPO_TARGET_FIRST && P % Q != 0) return RPO_ERR_INVALID_ARG;  // .view(Q, G, -1)
@@ -1540,6 +1551,9 @@ extern "C" int rpo_infonce_fwd(const void* q, const void* p, int64_t Q, int64_t 
     if (dtype == RPO_DT_F32)
         return fwd_impl<float>(q, p, Q, P, d, temperature, target_mode, scores_out, lse_out, loss_out, workspace,
                                workspace_bytes, st);
+    if (dtype == RPO_DT_F16)
+        return fwd_impl<f16_t>(q, p, Q, P, d, temperature, target_mode, scores_out, lse_out, loss_out, workspace,
+                               workspace_bytes, st);
     return fwd_impl<bf16_t>(q, p, Q, P, d, temperature, target_mode, scores_out, lse_out, loss_out, workspace,
                             workspace_bytes, st);
 }
@@ -1564,6 +1578,9 @@ extern "C" int rpo_infonce_bwd(const void* q, const void* p, const void* scores,
     if (dtype == RPO_DT_F32)
         return bwd_impl<float>(q, p, scores, lse, grad_loss, Q, P, d, temperature, target_mode, q_row0, q_rows,
                                p_row0, p_rows, dq_out, dp_out, st);
+    if (dtype == RPO_DT_F16)
+        return bwd_impl<f16_t>(q, p, scores, lse, grad_loss, Q, P, d, temperature, target_mode, q_row0, q_rows,
+                               p_row0, p_rows, dq_out, dp_out, st);
     return bwd_impl<bf16_t>(q, p, scores, lse, grad_loss, Q, P, d, temperature, target_mode, q_row0, q_rows, p_row0,
                             p_rows, dq_out, dp_out, st);
 }
@@ -1572,7 +1589,7 @@ extern "C" int rpo_infonce_ds(const void* scores, const float* lse, const float*
                               int dtype, float temperature, int64_t q_row0, int64_t q_rows, int64_t p_row0,
                               int64_t p_rows, void* ds_out, void* dst_out, rpo_stream_t stream) {
     if (!scores || !lse || !grad_loss || Q <= 0 || P < Q || !(temperature > 0.f)) return RPO_ERR_INVALID_ARG;
-    if (dtype != RPO_DT_F32 && dtype != RPO_DT_BF16) return RPO_ERR_INVALID_ARG;
+    if (!rpo_dtype_ok(dtype)) return RPO_ERR_INVALID_ARG;
     if (q_row0 < 0 || q_rows < 0 || q_row0 + q_rows > Q || p_row0 < 0 || p_rows < 0 || p_row0 + p_rows > P)
         return RPO_ERR_INVALID_ARG;
     if (q_rows == 0) ds_out = nullptr;
@@ -1584,6 +1601,9 @@ extern "C" int rpo_infonce_ds(const void* scores, const float* lse, const float*
     if (dtype == RPO_DT_F32)
         RPO_LAUNCH(infonce_ds_kernel<float>, grid, dim3(256), 0, st, (const float*)scores, lse, grad_loss, Q, P,
                    temperature, P / Q, q_row0, q_rows, p_row0, p_rows, (float*)ds_out, (float*)dst_out);
+    else if (dtype == RPO_DT_F16)
+        RPO_LAUNCH(infonce_ds_kernel<f16_t>, grid, dim3(256), 0, st, (const f16_t*)scores, lse, grad_loss, Q, P,
+                   temperature, P / Q, q_row0, q_rows, p_row0, p_rows, (f16_t*)ds_out, (f16_t*)dst_out);
     else
         RPO_LAUNCH(infonce_ds_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)scores, lse, grad_loss, Q, P,
                    temperature, P / Q, q_row0, q_rows, p_row0, p_rows, (bf16_t*)ds_out, (bf16_t*)dst_out);

@@ -235,6 +235,9 @@ extern "C" int rpo_pool_normalize_fwd(const void* h, int64_t h_stride_n, int64_t
         case RPO_DT_BF16:
             return launch_fwd<bf16_t>(h, h_stride_n, h_stride_l, mask, N, L, d, pool_mode, normalize, eps, out,
                                       idx_out, norm_out, st);
+        case RPO_DT_F16:
+            return launch_fwd<f16_t>(h, h_stride_n, h_stride_l, mask, N, L, d, pool_mode, normalize, eps, out,
+                                     idx_out, norm_out, st);
         default:
             return RPO_ERR_INVALID_ARG;
     }
@@ -252,6 +255,8 @@ extern "C" int rpo_pool_normalize_bwd(const void* grad_out, const void* out, con
             return launch_bwd<float>(grad_out, out, idx, norm, N, L, d, normalize, eps, dh, drow, st);
         case RPO_DT_BF16:
             return launch_bwd<bf16_t>(grad_out, out, idx, norm, N, L, d, normalize, eps, dh, drow, st);
+        case RPO_DT_F16:
+            return launch_bwd<f16_t>(grad_out, out, idx, norm, N, L, d, normalize, eps, dh, drow, st);
         default:
             return RPO_ERR_INVALID_ARG;
     }

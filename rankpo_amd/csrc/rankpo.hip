@@ -172,9 +172,14 @@ int rpo_launch_grouped_dots(const void* q, const void* p, int64_t B, int64_t G, 
     if (dtype == RPO_DT_F32)
         RPO_LAUNCH(grouped_dots_kernel<float>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const float*)q,
                            (const float*)p, G, d, out);
-    else
+    else if (dtype == RPO_DT_BF16)
         RPO_LAUNCH(grouped_dots_kernel<bf16_t>, dim3((unsigned)B), dim3(kDotThreads), 0, st,
                            (const bf16_t*)q, (const bf16_t*)p, G, d, out);
+    else if (dtype == RPO_DT_F16)
+        RPO_LAUNCH(grouped_dots_kernel<f16_t>, dim3((unsigned)B), dim3(kDotThreads), 0, st,
+                           (const f16_t*)q, (const f16_t*)p, G, d, out);
+    else
+        return RPO_ERR_INVALID_ARG;
     return rpo_launch_status();
 }
 
@@ -185,7 +190,7 @@ extern "C" int rpo_rankpo_fwd(const void* q, const void* p, const float* ref_cho
     if (!q || !p || !params || !scores_out || !losses_out || !loss_out || !metrics_out || !dscores_out)
         return RPO_ERR_INVALID_ARG;
     if (B <= 0 || d <= 0 || B > INT32_MAX) return RPO_ERR_INVALID_ARG;
-    if (dtype != RPO_DT_F32 && dtype != RPO_DT_BF16) return RPO_ERR_INVALID_ARG;
+    if (!rpo_dtype_ok(dtype)) return RPO_ERR_INVALID_ARG;
     if (params->loss_type != RPO_LOSS_SIGMOID && params->loss_type != RPO_LOSS_HINGE) return RPO_ERR_INVALID_ARG;
     if (!(params->temperature > 0.f)) return RPO_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
@@ -207,6 +212,9 @@ extern "C" int rpo_rankpo_bwd(const void* q, const void* p, const float* dscores
     else if (dtype == RPO_DT_BF16)
         RPO_LAUNCH(rankpo_bwd_kernel<bf16_t>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const bf16_t*)q,
                            (const bf16_t*)p, dscores, grad_loss, d, (bf16_t*)dq_out, (bf16_t*)dp_out);
+    else if (dtype == RPO_DT_F16)
+        RPO_LAUNCH(rankpo_bwd_kernel<f16_t>, dim3((unsigned)B), dim3(kDotThreads), 0, st, (const f16_t*)q,
+                           (const f16_t*)p, dscores, grad_loss, d, (f16_t*)dq_out, (f16_t*)dp_out);
     else
         return RPO_ERR_INVALID_ARG;
     return rpo_launch_status();

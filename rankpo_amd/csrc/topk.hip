@@ -28,6 +28,8 @@ template <>
 __device__ __forceinline__ float load_score<float>(const float* p) { return *p; }
 template <>
 __device__ __forceinline__ float load_score<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
+template <>
+__device__ __forceinline__ float load_score<f16_t>(const f16_t* p) { return (float)*p; }
 
 // sorts the 4096 (value, index) slots: best first
 template <int NT>
@@ -235,11 +237,15 @@ extern "C" int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int6
         return RPO_ERR_INVALID_ARG;
     if (k > kTopkMaxK || rows > INT32_MAX) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
-    const int V = dtype == RPO_DT_BF16 ? 8 : 4;
-    if ((dtype == RPO_DT_F32 || dtype == RPO_DT_BF16) && ld % V == 0 && rpo_aligned16(scores) && cols >= 4096) {
+    if (!rpo_dtype_ok(dtype)) return RPO_ERR_INVALID_ARG;
+    const int V = 16 / rpo_elem_size(dtype);
+    if (ld % V == 0 && rpo_aligned16(scores) && cols >= 4096) {
         if (dtype == RPO_DT_F32)
             RPO_LAUNCH(topk_merge_fast_kernel<float>, dim3((unsigned)rows), dim3(kFastThreads), 0, st, (const float*)scores,
                        ld, cols, col0, k, best_val, (long long*)best_idx, first);
+        else if (dtype == RPO_DT_F16)
+            RPO_LAUNCH(topk_merge_fast_kernel<f16_t>, dim3((unsigned)rows), dim3(kFastThreads), 0, st,
+                       (const f16_t*)scores, ld, cols, col0, k, best_val, (long long*)best_idx, first);
         else
             RPO_LAUNCH(topk_merge_fast_kernel<bf16_t>, dim3((unsigned)rows), dim3(kFastThreads), 0, st,
                        (const bf16_t*)scores, ld, cols, col0, k, best_val, (long long*)best_idx, first);
@@ -252,6 +258,7 @@ extern "C" int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int6
         RPO_LAUNCH(topk_merge_kernel<bf16_t>, dim3((unsigned)rows), dim3(kTopkThreads), 0, st, (const bf16_t*)scores, ld,
                    cols, col0, k, best_val, (long long*)best_idx, first);
     else
-        return RPO_ERR_INVALID_ARG;
+        RPO_LAUNCH(topk_merge_kernel<f16_t>, dim3((unsigned)rows), dim3(kTopkThreads), 0, st, (const f16_t*)scores, ld,
+                   cols, col0, k, best_val, (long long*)best_idx, first);
     return rpo_launch_status();
 }

@@ -347,7 +347,16 @@ class FlatGradAllReducer:
         zeroed.  Single-rank use only -- with peers, a rank that leaves a step mid-way has already broken the collective sequence."""
         self._armed = False
         self._pending = [0] * len(self.buckets)
+        # bucket reductions the hooks fired before the failure may still be running on the communicator's stream (world == 1 over
+        # RCCL, the --force-dist rehearsal, is allowed to retry): they write the flat buffer, so they finish before it is zeroed
+        for w in self._works:
+            try:
+                w.wait()
+            except Exception:                   # a reduction that failed with the step: nothing of it may be trusted, nor awaited
+                pass
         self._works = []
+        if self.flat.is_cuda:
+            torch.cuda.synchronize(self.flat.device)
         self.zero_()
 
     def zero_(self):

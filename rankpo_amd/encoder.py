@@ -326,6 +326,13 @@ class LlamaAttention(nn.Module):
                                                 attn_mask.tiles, attn_mask.k_tiles, 1.0 / math.sqrt(self.hd), head_dim=self.hd,
                                                 fold_forward=FOLD_ROPE >= 2, fwd_tiles=attn_mask.fwd_tiles)
             return _ops.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
+        if (isinstance(attn_mask, VarlenCtx) and fused and attn_mask.tiles is not None and self.hd in (64, 128)
+                and x.dtype == torch.bfloat16 and FOLD_ROPE and not torch.is_grad_enabled()):
+            # no-grad callers (ModelForInference.encode, the RankPO ref_model under inference_mode, eval-mode scoring): the same
+            # rotary fold and forward kernel, without a key-block table, an autograd node or row statistics
+            o = _ops.rope_flash_attn_varlen_qkv_fwd(qkv, rope.cos32, rope.sin32, self.nh, self.nkv, attn_mask.cu, attn_mask.tiles,
+                                                    1.0 / math.sqrt(self.hd), head_dim=self.hd, fwd_tiles=attn_mask.fwd_tiles)
+            return F.linear(o.reshape(1, L, self.nh * self.hd), self.o_proj.weight, self.o_proj.bias)
         if fused:       # one in-place HIP pass over the q and k heads instead of neg / cat / 2 mul / add per tensor
             qkv = _ops.rope_(qkv, rope.cos32, rope.sin32, self.nh + self.nkv, self.hd, grad_inplace=True)
         q, k, v = qkv.split([nq, nk, nk], dim=-1)
@@ -368,11 +375,12 @@ class LlamaMLP(nn.Module):
         tag_fuse_group(self.gate_proj.weight, self.up_proj.weight)
         self.down_proj = nn.Linear(cfg.intermediate_size, cfg.hidden_size, bias=b)
 
-    def forward(self, x):
+    def forward(self, x, last_in_block: bool = False):
+        """last_in_block: the caller's function ends with this MLP (see ops.swiglu_down)."""
         if self.down_proj.bias is None and self.gate_proj.bias is None and _ops.fused_encoder_ops_ok(x):
             # ONE gate|up projection GEMM; fused HIP silu*mul on its two halves, product not kept alive
             gu = _ops.linear(x, fused_weight([self.gate_proj.weight, self.up_proj.weight]))
-            return _ops.swiglu_down(gu, self.down_proj.weight)
+            return _ops.swiglu_down(gu, self.down_proj.weight, last_in_block)
         return self.down_proj(F.silu(self.gate_proj(x)) * self.up_proj(x))
 
 
@@ -390,7 +398,7 @@ class LlamaLayer(nn.Module):
         into the RMSNorm that follows it."""
         x, h = _add_norm(x, delta, self.input_layernorm)
         x, h = _add_norm(x, self.self_attn(h, rope, attn_mask), self.post_attention_layernorm)
-        return x, self.mlp(h)
+        return x, self.mlp(h, last_in_block=True)       # the block's last computation: `_run_layers` checkpoints ONE block per call
 
     def forward_last_rows(self, x, delta, rope, ctx, last_idx):
         """The LAST block of a last-token-pooled encoder: only the pooled rows are consumed downstream, so K and V
@@ -412,7 +420,8 @@ class LlamaLayer(nn.Module):
                 # hand-written one-query-per-sequence attention on the fused k|v buffer (ctx.tiles: hand_attention is on)
                 o = _ops.last_query_attn(q, kv, ctx.cu, att.nkv, att.hd, 1.0 / math.sqrt(att.hd))
                 xl = x[0].index_select(0, last_idx) + att.o_proj(o.reshape(-1, att.nh * att.hd))
-                return xl + self.mlp(self.post_attention_layernorm(xl))
+                # last_in_block: only the residual add follows, and an add saves nothing for backward
+                return xl + self.mlp(self.post_attention_layernorm(xl), last_in_block=True)
             k, v = kv.split([nk, nk], dim=-1)
             k = k.view(T, att.nkv, att.hd)
         else:
@@ -424,7 +433,7 @@ class LlamaLayer(nn.Module):
             k = k * ck + _rotate_half(k) * sk
         o = _varlen_last_query_attention(q, k, v.view(T, att.nkv, att.hd), ctx)
         xl = x[0].index_select(0, last_idx) + att.o_proj(o.reshape(-1, att.nh * att.hd))
-        return xl + self.mlp(self.post_attention_layernorm(xl))
+        return xl + self.mlp(self.post_attention_layernorm(xl), last_in_block=True)
 
 
 def _resized_embedding(old: nn.Embedding, n: int, std: float) -> nn.Embedding:
@@ -461,7 +470,9 @@ class LlamaEncoder(nn.Module):
         # HF computes inv_freq in float32 whatever the model dtype; so does this: a float32 tensor per device, never cast.
         self._inv_freq = {"cpu": _rope_inv_freq(config)}
         self.gradient_checkpointing = False
-        self.checkpoint_layers = None      # None = all layers when gradient_checkpointing, else the first k
+        self.checkpoint_layers = None      # None = all layers when gradient_checkpointing, "auto" = rankpo_amd.memory's plan, else the first k
+        self.memory_plan = None            # the last EncoderPlan "auto" resolved to (tokens it was made for, blocks, modelled peak)
+        self.memory_plan_hints = {}        # world= / partitioned= for the plan, set by whoever owns the optimizer (train_step)
         self.pack_fill = True              # packed path: round the token count up to a multiple of 256 with a filler sequence
         self.hand_attention = True         # False: PyTorch's own flash-attention ops both ways (the "stock flash" control of
         #                                    bench.step_parity; a Python attribute, not an environment switch)
@@ -476,10 +487,33 @@ class LlamaEncoder(nn.Module):
         elif isinstance(m, nn.Embedding):
             nn.init.normal_(m.weight, 0.0, std)
 
-    def gradient_checkpointing_enable(self, layers: Optional[int] = None, **_):
-        """`layers`: checkpoint only the first `layers` blocks (288 GB of HBM lets the rest keep activations)."""
+    def gradient_checkpointing_enable(self, layers="auto", **_):
+        """The reference's `--gradient_checkpointing` (scripts/train/run_contrastive.sh:39; HF checkpoints every block).
+        `layers`: "auto" (the default, what the HF Trainer's bare call gets): as FEW blocks as the HBM plan allows
+        (rankpo_amd.memory.plan_for_encoder: measured free HBM, world size, the padded token count of the batches that arrive --
+        288 GB lets Llama-3.2-1B keep every block at the BASELINE batch); None or "all": every block (HF's meaning); an int k: the
+        first k blocks."""
         self.gradient_checkpointing = True
-        self.checkpoint_layers = layers
+        self.checkpoint_layers = None if layers == "all" else layers
+        self.memory_plan = None
+
+    def _checkpointed_blocks(self, tokens: int) -> int:
+        """How many of the first blocks run under torch.utils.checkpoint for a step of `tokens` padded tokens.  "auto" plans once
+        per LARGEST token count seen (a longer batch re-plans: only ever towards more checkpointing, so the plan holds for every
+        batch so far) and hands ops the verdict on the transposed d(gate|up) buffer."""
+        if self.checkpoint_layers is None:
+            return len(self.layers)
+        if self.checkpoint_layers != "auto":
+            return int(self.checkpoint_layers)
+        if self.memory_plan is None or tokens > self.memory_plan.tokens:
+            from . import memory
+            plan = memory.plan_for_encoder(self, tokens, block_inputs=1 if CKPT_SINGLE_INPUT else 2, **self.memory_plan_hints)
+            if self.memory_plan is not None:
+                plan.checkpoint_blocks = max(plan.checkpoint_blocks, self.memory_plan.checkpoint_blocks)
+            self.memory_plan = plan
+            if plan.transposed_dgu_limit:
+                _ops.SWIGLU_DGU_T_MAX_BYTES = max(_ops.SWIGLU_DGU_T_DEFAULT_MAX_BYTES, plan.transposed_dgu_limit)
+        return self.memory_plan.checkpoint_blocks
 
     def gradient_checkpointing_disable(self):
         self.gradient_checkpointing = False
@@ -540,16 +574,16 @@ class LlamaEncoder(nn.Module):
         N, L, _ = x.shape
         rope = self._rope(torch.arange(L, device=x.device))
         mask = self._mask(attention_mask, L, x.dtype, right_padded)
-        return self._run_layers(x, rope, mask)
+        return self._run_layers(x, rope, mask, tokens=N * L)
 
     def forward(self, input_ids=None, attention_mask=None, return_dict=True, right_padded=None, **_):
         x, delta = self._stack(input_ids, attention_mask, right_padded)
         h = _add_norm(x, delta, self.norm)[1]
         return EncoderOutput(last_hidden_state=h) if return_dict else (h,)
 
-    def _run_layers(self, x, rope, ctx, upto=None):
+    def _run_layers(self, x, rope, ctx, upto=None, tokens=None):
         ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
-        nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
+        nck = self._checkpointed_blocks(x.shape[0] * x.shape[1] if tokens is None else tokens) if ck else 0
         delta = None
         for i, layer in enumerate(self.layers if upto is None else self.layers[:upto]):
             if ck and i < nck:
@@ -574,13 +608,18 @@ class LlamaEncoder(nn.Module):
         (e.g. the query and the passage batch of a training step: sequences are independent, so every pooled row is what the
         separate calls give, but the small batch no longer runs as its own set of under-filled GEMMs and launches).
         Returns a list of [N_i, d] tensors, or None if any batch is not right-padded 0/1 with at least one token per row."""
+        dev = self.embed_tokens.weight.device
+        # HOST batches for a model on the GPU (ModelForInference.encode hands over the tokenizer's CPU tensors): the checks, the
+        # lengths and the packing are done on the host and ONLY the real tokens are uploaded -- no device sync at all, so the
+        # batches of an encode() loop queue up behind each other on the stream
+        on_host = dev.type == "cuda" and all(m.device.type == "cpu" and i.device.type == "cpu" for i, m in batches)
         stats = []
         for _, m in batches:
             lens_d = m.sum(-1)
             rp = (m[:, 1:].ne(0) <= m[:, :-1].ne(0)).all()                               # what `_mask` asks of a mask
             ok = (m[:, 1:] <= m[:, :-1]).all() & (lens_d > 0).all() & ((m == 0) | (m == 1)).all()
             stats.append(torch.cat([lens_d.to(torch.int64), ok.to(torch.int64)[None], rp.to(torch.int64)[None]]))
-        info = torch.cat(stats).tolist()                                                   # the one sync
+        info = torch.cat(stats).tolist()                                                   # the one sync (none for host batches)
         lens, o, oks = [], 0, []
         self.last_right_padded = []          # per batch; a caller that falls back to the padded path hands it to forward()
         for _, m in batches:
@@ -601,7 +640,7 @@ class LlamaEncoder(nn.Module):
         # 37.9 ms per block at 138 k tokens).  A filler sequence of < 256 pad tokens rounds it up; its pooled row is dropped
         # and, having no gradient, it contributes exact zeros to every weight gradient.
         n_fill = 0
-        if (ids_parts[0].is_cuda and self.embed_tokens.weight.dtype == torch.bfloat16 and sum(lens) >= 4096
+        if (dev.type == "cuda" and self.embed_tokens.weight.dtype == torch.bfloat16 and sum(lens) >= 4096
                 and self.pack_fill):
             n_fill = (-sum(lens)) % 256
         if n_fill:
@@ -611,6 +650,9 @@ class LlamaEncoder(nn.Module):
             lens = lens + [n_fill]
         ids = ids_parts[0] if len(ids_parts) == 1 else torch.cat(ids_parts)
         pos = pos_parts[0] if len(pos_parts) == 1 else torch.cat(pos_parts)
+        if on_host:                                      # one upload: packed ids | positions (int32, pinned, asynchronous)
+            both = torch.stack([ids.to(torch.int32), pos.to(torch.int32)]).pin_memory().to(dev, non_blocking=True)
+            ids, pos = both[0], both[1]
         x = self.embed_tokens(ids)[None]                                                   # [1, T, d]
         rope = self._rope(pos)                                                             # per-token angles [T, hd/2]
         N = len(lens)
@@ -629,10 +671,12 @@ class LlamaEncoder(nn.Module):
                     _ops.ATTN_KEY_BLOCK if self.config.head_dim == 64 else _ops.ATTN_KEY_BLOCK_HD128)
         ctx = VarlenCtx(cu, lens, max(lens), tiles, k_tiles, fwd_tiles)
         last_idx = (cu[1:] - 1).to(torch.int64)
-        x, delta = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1)
+        # the plan's token count is the PADDED one (every row at its batch's full width): what the collator can hand over at worst
+        tok_pad = sum(m.shape[0] * m.shape[1] for _, m in batches)
+        x, delta = self._run_layers(x, rope, ctx, upto=len(self.layers) - 1, tokens=tok_pad)
         li = len(self.layers) - 1
         ck = self.gradient_checkpointing and self.training and torch.is_grad_enabled()
-        nck = len(self.layers) if self.checkpoint_layers is None else self.checkpoint_layers
+        nck = self._checkpointed_blocks(tok_pad) if ck else 0
         if ck and li < nck:
             if CKPT_SINGLE_INPUT and delta is not None:
                 x, delta = x + delta, None
@@ -896,7 +940,10 @@ def load_encoder(path: str, torch_dtype=None) -> nn.Module:
                 for k in keys:
                     put(k, lambda k=k: f.get_tensor(k))
         else:
-            sd = torch.load(full, map_location="cpu", weights_only=True, mmap=True)
+            try:
+                sd = torch.load(full, map_location="cpu", weights_only=True, mmap=True)
+            except RuntimeError:            # a legacy (non-zip) torch.save file cannot be memory-mapped; AutoModel.from_pretrained reads it
+                sd = torch.load(full, map_location="cpu", weights_only=True)
             keys = list(sd)
             for k in keys:
                 put(k, lambda k=k: sd[k])
@@ -943,8 +990,10 @@ def save_encoder(enc: nn.Module, path: str, max_shard_size="5GB"):
         cur_bytes += nb
     if cur:
         shards.append(cur)
-    for fn in os.listdir(path):                                 # a previous save of another shard count must not shine through
-        if fn == SAFE_INDEX or (fn.startswith("model") and fn.endswith(".safetensors")):
+    import re
+    for fn in os.listdir(path):                                 # a previous save of another shard count must not shine through:
+        # ONLY the names save_pretrained itself writes (a user's own `model_notes.safetensors` in the directory stays)
+        if fn in (SAFE_INDEX, SAFE_WEIGHTS) or re.fullmatch(r"model-\d{5}-of-\d{5}\.safetensors", fn):
             os.remove(os.path.join(path, fn))
     names = [SAFE_WEIGHTS] if len(shards) == 1 else [f"model-{i + 1:05d}-of-{len(shards):05d}.safetensors" for i in range(len(shards))]
     weight_map, total = {}, 0

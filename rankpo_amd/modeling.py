@@ -256,6 +256,8 @@ class ModelForInference(nn.Module):
         elif use_bf16:
             torch_dtype = torch.bfloat16
         self.model = _load_or_build(model_name_or_path, encoder, config, torch_dtype)
+        if encoder is not None and (use_fp16 or use_bf16):           # an in-memory encoder follows the flag like a checkpoint does
+            self.model = self.model.to(torch_dtype)
         if tokenizer is None:
             from transformers import AutoTokenizer
             tokenizer = AutoTokenizer.from_pretrained(model_name_or_path)
@@ -276,7 +278,10 @@ class ModelForInference(nn.Module):
         description: str = "Encoding",
     ) -> Union[np.ndarray, torch.Tensor]:
         """modeling.py:473-554.  Differences that do not change results: no per-batch `empty_cache()` (a device
-        sync per batch, modeling.py:543-544); numpy conversion happens once at the end."""
+        sync per batch, modeling.py:543-544); numpy conversion happens once at the end; batch i + 1 is tokenised (a worker
+        thread; the fast tokenizers release the GIL) while batch i runs; right-padded Llama batches are packed on the HOST from
+        the tokenizer's own CPU tensors and only the real tokens are uploaded, so that no batch waits for the one before it
+        (`LlamaEncoder.pooled_last_token_multi`: no device sync)."""
         self.model.eval()
         input_was_string = False
         if isinstance(sentences, str):
@@ -286,29 +291,38 @@ class ModelForInference(nn.Module):
             raise ValueError("Input items should be text.")
         mode = "last" if "Llama" in self.config.architectures[0] else "cls"
         all_embeddings = []
-        for i in range(0, len(sentences), batch_size):
-            batch_sentences = sentences[i:i + batch_size]
-            inputs = self.tokenizer(batch_sentences, padding=True, truncation=True, max_length=max_length,
-                                    return_tensors="pt")
-            inputs = {k: v.to(self.device) for k, v in inputs.items()}
-            pooled = None
-            packed_tried = mode == "last" and hasattr(self.model, "pooled_last_token")
-            if packed_tried:
-                # right-padded batches (the tokenizer's default): packed tokens, no pad token is ever computed, the last block
-                # runs for the pooled rows only; ONE host sync per batch (the lengths); None for any other mask
-                pooled = self.model.pooled_last_token(inputs["input_ids"], inputs["attention_mask"])
-            if pooled is not None:
-                if pooled.dtype == torch.float16:
-                    pooled = pooled.float()
-                emb = ops.pool_normalize(pooled[:, None, :], None, "cls", self.normalize_embeddings)
-            else:
-                hint = {"right_padded": self.model.last_right_padded[0]} if packed_tried else {}
-                h = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
-                               return_dict=True, **hint).last_hidden_state
-                if h.dtype == torch.float16:        # the HIP kernels take f32 / bf16
-                    h = h.float()
-                emb = ops.pool_normalize(h, inputs["attention_mask"], mode, self.normalize_embeddings)
-            all_embeddings.append(emb)
+        starts = list(range(0, len(sentences), batch_size))
+
+        def tokenise(i):
+            return self.tokenizer(sentences[i:i + batch_size], padding=True, truncation=True, max_length=max_length,
+                                  return_tensors="pt")
+
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=1) if len(starts) > 1 else None
+        try:
+            ahead = pool.submit(tokenise, starts[0]) if pool else None
+            for n, i in enumerate(starts):
+                inputs = ahead.result() if pool else tokenise(i)
+                if pool and n + 1 < len(starts):
+                    ahead = pool.submit(tokenise, starts[n + 1])          # runs while this batch is launched and computed
+                pooled = None
+                packed_tried = mode == "last" and hasattr(self.model, "pooled_last_token")
+                if packed_tried:
+                    # right-padded batches (the tokenizer's default): packed tokens, no pad token is ever computed, the last
+                    # block runs for the pooled rows only; None for any other mask.  The tensors are still on the host here.
+                    pooled = self.model.pooled_last_token(inputs["input_ids"], inputs["attention_mask"])
+                if pooled is not None:
+                    emb = ops.pool_normalize(pooled[:, None, :], None, "cls", self.normalize_embeddings)
+                else:
+                    hint = {"right_padded": self.model.last_right_padded[0]} if packed_tried else {}
+                    inputs = {k: v.to(self.device) for k, v in inputs.items()}
+                    h = self.model(input_ids=inputs["input_ids"], attention_mask=inputs["attention_mask"],
+                                   return_dict=True, **hint).last_hidden_state
+                    emb = ops.pool_normalize(h, inputs["attention_mask"], mode, self.normalize_embeddings)
+                all_embeddings.append(emb)
+        finally:
+            if pool:
+                pool.shutdown(wait=True, cancel_futures=True)
         out = torch.cat(all_embeddings, dim=0)
         if convert_to_numpy:
             if out.dtype == torch.bfloat16:      # modeling.py:537-538

@@ -12,7 +12,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import (RPO_DT_BF16, RPO_DT_F32, RPO_LOSS_HINGE, RPO_LOSS_SIGMOID, RPO_NUM_METRICS, RPO_POOL_CLS,
+from ._lib import (RPO_DT_BF16, RPO_DT_F16, RPO_DT_F32, RPO_LOSS_HINGE, RPO_LOSS_SIGMOID, RPO_NUM_METRICS, RPO_POOL_CLS,
                    RPO_POOL_LAST, RPO_TARGET_FIRST, RPO_TARGET_INBATCH, METRIC_KEYS, RankPOParams, check)
 
 F_NORMALIZE_EPS = 1e-12  # torch.nn.functional.normalize default (modeling.py:236)
@@ -23,7 +23,9 @@ def _dt(t: torch.Tensor) -> int:
         return RPO_DT_F32
     if t.dtype == torch.bfloat16:
         return RPO_DT_BF16
-    raise TypeError(f"rankpo_amd HIP kernels take float32 or bfloat16 tensors, got {t.dtype}")
+    if t.dtype == torch.float16:     # scoring kernels only (pool / normalize, similarity + InfoNCE, RankPO, top-k): the reference's
+        return RPO_DT_F16            # fp16 BGE setup (configs/ds_zero1_config_bge.json:2-11, modeling.py:453-454); f32 accumulation
+    raise TypeError(f"rankpo_amd HIP kernels take float32, bfloat16 or float16 tensors, got {t.dtype}")
 
 
 def _need_gpu(*ts):
@@ -184,14 +186,24 @@ def sim_gemm_nt(b, a):
     return c
 
 
+def sim_gemm_nt_takes(rows, K, d, ld_ds, ds_ptr=0, bf16=True) -> bool:
+    """Whether `rpo_sim_gemm_nt` accepts dS [rows, K] (row stride ld_ds) x X^T [d, K] -> [rows, d]: the C entry point's own
+    conditions (csrc/infonce.hip), restated so that the dispatch never hands it a problem it answers with RPO_ERR_UNSUPPORTED --
+    bf16; a reduction that is a multiple of the 64-element K-step; 16-byte pieces (row strides % 8, aligned bases); and operands
+    below 4 GiB each, because the kernel addresses its LDS-DMA pieces by 32-bit byte offsets (a dS of 32768 x 65536 bf16 is 4 GiB:
+    `ds @ x_all` has to take it, as it did before the hand-written arm existed -- advisor, round 5)."""
+    return bool(bf16 and K % 64 == 0 and d % 8 == 0 and ld_ds % 8 == 0 and ld_ds >= K and ds_ptr % 16 == 0
+                and rows * ld_ds * 2 < 2 ** 32 and d * K * 2 < 2 ** 32 and rows > 0 and d > 0)
+
+
 def _bwd_product(ds, x_all):
     """ds [rows, K] @ x_all [K, d]: dq = dS p_all or dp = dS^T q_all.  On the hand-written path the embeddings are transposed
     first (rpo_transpose: 2 K d bytes each way, ~1 % of the product's time at sweep sizes) so that both operands are contiguous
     along the reduction, the layout of the forward kernel's LDS-DMA staging."""
     K, d = x_all.shape
     want_hip = INFONCE_BWD_GEMM == "hip" or (INFONCE_BWD_GEMM == "auto" and K >= INFONCE_BWD_HIP_MIN_K)
-    if (want_hip and ds.dtype == torch.bfloat16 and K % 64 == 0 and d % 8 == 0 and ds.stride(1) == 1
-            and ds.stride(0) % 8 == 0 and ds.data_ptr() % 16 == 0):
+    if (want_hip and ds.stride(1) == 1 and x_all.dtype == ds.dtype
+            and sim_gemm_nt_takes(ds.shape[0], K, d, ds.stride(0), ds.data_ptr(), ds.dtype == torch.bfloat16)):
         return sim_gemm_nt(ds, transpose2d(x_all))
     return ds @ x_all
 
@@ -308,8 +320,10 @@ def _swiglu_fwd(lib, gu, prod, rows, ff):
 LINEAR_TN = True      # input-gradient GEMMs against a transposed copy of the weight (`_LinearTN`); bench.py --no-linear-tn
 WGRAD_MIXED = True    # weight-gradient GEMMs with the smaller operand transposed first (`wgrad`); bench.py --no-wgrad-mixed
 SWIGLU_DGU_T = True   # ... and d(gate|up) transposed as well, for the gate|up weight gradient; bench.py --no-dgu-t
-SWIGLU_DGU_T_MAX_BYTES = 6 * 2 ** 30   # the [2 ff, T] buffer is optional: taken up to this size (cfg 2: 5.1 GB; the Llama-3-8B shape needs 13 GB and
-                                       # runs at 88 % of HBM on one GPU: a caller that has MEASURED its headroom may raise it, as bench.py does)
+SWIGLU_DGU_T_DEFAULT_MAX_BYTES = 6 * 2 ** 30
+SWIGLU_DGU_T_MAX_BYTES = SWIGLU_DGU_T_DEFAULT_MAX_BYTES   # the [2 ff, T] buffer is optional: taken up to this size (cfg 2: 5.1 GB; the Llama-3-8B
+                                       # shape needs 13 GB and runs at 88 % of HBM on one GPU: a caller that KNOWS its headroom may raise it --
+                                       # rankpo_amd.memory's plan (`gradient_checkpointing_enable()`) and bench.py's measured pre-size step do)
 SWIGLU_PROD_T = True  # SwiGLU backward writes the recomputed product transposed for the down projection's weight gradient; bench.py --no-prod-t
 WGRAD_SPLIT_T = 4     # chunks of the token reduction for the small-output weight gradients (0 / 1: one GEMM); bench.py --wgrad-split
 
@@ -381,7 +395,7 @@ def _bmm_f32_out_ok(device) -> bool:
 
 def _wt(w):
     """W^T as a contiguous matrix (operand of the input-gradient GEMM in the forward's layout)."""
-    return transpose2d(w) if w.is_cuda and w.dtype in (torch.bfloat16, torch.float32) and w.stride(1) == 1 else w.t().contiguous()
+    return transpose2d(w) if w.is_cuda and w.dtype in (torch.bfloat16, torch.float16, torch.float32) and w.stride(1) == 1 else w.t().contiguous()
 
 
 class _LinearTN(torch.autograd.Function):
@@ -450,14 +464,19 @@ class _SwiGLUDown(torch.autograd.Function):
     [tokens, ff] product (the largest activation of the block) is recomputed by one fused pass in backward."""
 
     @staticmethod
-    def forward(ctx, gu, weight):
+    def forward(ctx, gu, weight, last_in_block=False):
         lib = _lib.load()
         gu = gu.contiguous()
         ff = gu.shape[-1] // 2
         rows = gu.numel() // (2 * ff)
         ctx.save_for_backward(gu, weight)
-        if SKIP_RECOMPUTED_OUTPUT and recomputing.active():      # the output of a recomputed block is never read
-            return torch.empty(gu.shape[:-1] + (weight.shape[0],), dtype=gu.dtype, device=gu.device)
+        # the output of a recomputed block is never read -- IF this call is what the checkpointed function computes last (the caller
+        # says so: `last_in_block`, advisor round 5; a thread-wide "a recomputation is running" alone would also hit an MLP in the
+        # middle of a longer checkpointed segment).  POISON_SKIPPED_OUTPUT (tests): NaNs instead of uninitialised memory, so that
+        # anything that does read it shows.
+        if SKIP_RECOMPUTED_OUTPUT and last_in_block and recomputing.active():
+            out = torch.empty(gu.shape[:-1] + (weight.shape[0],), dtype=gu.dtype, device=gu.device)
+            return out.fill_(float("nan")) if POISON_SKIPPED_OUTPUT else out
         prod = _swiglu_fwd(lib, gu, torch.empty(gu.shape[:-1] + (ff,), dtype=gu.dtype, device=gu.device), rows, ff)
         return torch.nn.functional.linear(prod, weight)
 
@@ -499,7 +518,7 @@ class _SwiGLUDown(torch.autograd.Function):
             if dgu_t is not None:                             # stamped AFTER the kernel wrote dgu (version and pointer as handed on)
                 dgu._rpo_transposed = (dgu_t, dgu._version, dgu.data_ptr())
             del dprod, dgu_t
-            return dgu, torch.nn.functional.linear(transpose2d(dy2), prod_t)      # [n, T] x [ff, T]^T -> [n, ff]
+            return dgu, torch.nn.functional.linear(transpose2d(dy2), prod_t), None      # [n, T] x [ff, T]^T -> [n, ff]
         with torch.cuda.device(gu.device):
             check(lib.rpo_swiglu_bwd(gu.data_ptr(), gu.data_ptr() + ff * es, dprod.data_ptr(), dgu.data_ptr(),
                                      dgu.data_ptr() + ff * es, dprod.data_ptr() if want_dw else None, rows, ff, 2 * ff,
@@ -508,11 +527,13 @@ class _SwiGLUDown(torch.autograd.Function):
         if want_dw:
             prod = dprod                                      # overwritten in place by the kernel
             dW = wgrad(dy2, prod.reshape(-1, ff))
-        return dgu, dW
+        return dgu, dW, None
 
 
-def swiglu_down(gu, weight):
-    return _SwiGLUDown.apply(gu, weight)
+def swiglu_down(gu, weight, last_in_block: bool = False):
+    """last_in_block: this product is the LAST thing the enclosing (possibly checkpointed) function computes, i.e. nothing that
+    saves tensors for backward consumes it inside that function; only then may a recomputation skip it (`recomputing`)."""
+    return _SwiGLUDown.apply(gu, weight, bool(last_in_block))
 
 
 def fused_encoder_ops_ok(x, head_dim=None) -> bool:
@@ -685,6 +706,7 @@ def attn_tile_table(lens, device, num_heads: int = 0, num_kv_heads: int = 0, blo
 # (profiles/r05_fa_fwd128w_ladder.md).
 FWD_ONE_WAVE_HEAD_DIMS = (128,)
 SKIP_RECOMPUTED_OUTPUT = True   # see `recomputing`; False: the A/B arm of `bench.py --recompute-output`
+POISON_SKIPPED_OUTPUT = False   # tests: a skipped output is filled with NaN instead of left uninitialised
 
 
 def attn_fwd_tile_table(lens, device, num_heads: int, num_kv_heads: int, head_dim: int, force: bool = False):
@@ -705,9 +727,11 @@ def _check_rope_tables(rope, hd, who):
         raise ValueError(f"{who}: rope must be (cos, sin), contiguous f32 [period, head_dim / 2]")
 
 
-def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0, rope=None, q_block: int = 128):
+def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int = 0, num_seqs: int = 0, rope=None, q_block: int = 128,
+                          want_lse: bool = True):
     """q [T, nh, hd], k / v [T, nkv, hd], hd = 64 or 128 (last two dims contiguous, token stride free); returns
-    (out [T, nh, hd] bf16, lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0).  rope = (cos, sin),
+    (out [T, nh, hd] bf16, lse f32: [nh, T], or [num_seqs, nh, padded_lse_len] when padded_lse_len > 0; None with
+    want_lse=False: the forward-only entry, no row statistics are allocated or written).  rope = (cos, sin),
     f32 [period, hd / 2]: q arrives UN-rotated and the kernel rotates it IN PLACE (k must arrive rotated), see the header.
     q_block = the query rows per entry of `tiles`: 128, or 64 for a list from `attn_fwd_tile_table` (entries of 64 queries x 4 q
     heads: the one-wave-per-SIMD forward)."""
@@ -720,14 +744,16 @@ def flash_attn_varlen_fwd(q, k, v, cu_seqlens, tiles, scale, padded_lse_len: int
             or v.stride(1) != hd):
         raise ValueError("flash_attn_varlen_fwd: bf16, head_dim 64 or 128, heads contiguous inside a token row")
     out = torch.empty((T, nh, hd), dtype=q.dtype, device=q.device)
-    if padded_lse_len > 0:
+    if not want_lse:
+        lse = None
+    elif padded_lse_len > 0:
         lse = torch.zeros((num_seqs, nh, padded_lse_len), dtype=torch.float32, device=q.device)
     else:
         lse = torch.empty((nh, T), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
         check(lib.rpo_flash_attn_fwd(q.data_ptr(), k.data_ptr(), v.data_ptr(), q.stride(0), k.stride(0), v.stride(0),
                                      cu_seqlens.data_ptr(), tiles.data_ptr(), tiles.shape[0], tiles.shape[1], T, nh, nkv, hd, scale,
-                                     out.data_ptr(), nh * hd, lse.data_ptr(), padded_lse_len,
+                                     out.data_ptr(), nh * hd, _p(lse), padded_lse_len,
                                      rope[0].data_ptr() if rope is not None else None,
                                      rope[1].data_ptr() if rope is not None else None,
                                      rope[0].shape[0] if rope is not None else 0, q_block, _stream(q)),
@@ -879,6 +905,10 @@ class _FlashAttnVarlen(torch.autograd.Function):
 
 
 def flash_attn_varlen(q, k, v, cu, tiles, max_len, scale, k_tiles=None, key_block: int = ATTN_KEY_BLOCK, fwd_tiles=None):
+    if not (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)):
+        # nothing will differentiate this: the forward kernel alone, no row statistics (no padded zero-filled lse per layer)
+        return flash_attn_varlen_fwd(q, k, v, cu, tiles if fwd_tiles is None else fwd_tiles, scale, want_lse=False,
+                                     q_block=128 if fwd_tiles is None else 64)[0]
     return _FlashAttnVarlen.apply(q, k, v, cu, tiles, k_tiles, max_len, scale, key_block, fwd_tiles)
 
 
@@ -974,6 +1004,33 @@ def rope_flash_attn_varlen_qkv(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles
         raise ValueError("rope_flash_attn_varlen_qkv: the 64-key dK/dV kernel has no rotary epilogue; use rope_ + flash_attn_varlen_qkv")
     return _RopeFlashAttnVarlenQKV.apply(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block,
                                          bool(fold_forward), fwd_tiles)[0]
+
+
+FWD_ONLY_CALLS = 0    # forward-only fused rotary + attention calls so far (tests read it: the inference surface ran the hand-written path)
+
+
+def rope_flash_attn_varlen_qkv_fwd(qkv, cos, sin, num_heads, num_kv_heads, cu, tiles, scale, head_dim: int = 64, fwd_tiles=None):
+    """The FORWARD-ONLY entry of `rope_flash_attn_varlen_qkv` (no autograd node, for `torch.no_grad()` / `inference_mode()`
+    callers: ModelForInference.encode, modeling.py:473-554; the RankPO ref_model, rankpo_trainer.py:468-477; eval-mode scoring):
+    `rpo_rope` in place on the k heads of the fresh projection output, then the attention forward, which rotates the q block it
+    loads anyway; no key-block table, no lse buffer.  Same kernels and same arithmetic as the training forward."""
+    global FWD_ONLY_CALLS
+    if head_dim not in (64, 128):
+        raise ValueError("rope_flash_attn_varlen_qkv_fwd: head_dim must be 64 or 128")
+    if qkv.shape[-1] != (num_heads + 2 * num_kv_heads) * head_dim or not qkv.is_contiguous():
+        raise ValueError("rope_flash_attn_varlen_qkv_fwd: qkv must be a contiguous [..., T, (nh + 2 nkv) * head_dim] tensor")
+    if torch.is_grad_enabled() and qkv.requires_grad:
+        raise RuntimeError("rope_flash_attn_varlen_qkv_fwd is forward-only; use rope_flash_attn_varlen_qkv under autograd")
+    x = qkv.view(-1, qkv.shape[-1])
+    lib = _lib.load()
+    ptr = x.data_ptr() + num_heads * head_dim * x.element_size()
+    with torch.cuda.device(x.device):
+        check(lib.rpo_rope(ptr, ptr, x.shape[1], cos.data_ptr(), sin.data_ptr(), x.shape[0], num_kv_heads, head_dim, cos.shape[0],
+                           _dt(x), 0, _stream(x)), "rpo_rope")
+    q, k, v = _FlashAttnVarlenQKV._views(x, num_heads, num_kv_heads, head_dim)
+    FWD_ONLY_CALLS += 1
+    return flash_attn_varlen_fwd(q, k, v, cu, tiles if fwd_tiles is None else fwd_tiles, scale, rope=(cos, sin),
+                                 q_block=128 if fwd_tiles is None else 64, want_lse=False)[0]
 
 
 def flash_attn_varlen_qkv(qkv, num_heads, num_kv_heads, cu, tiles, k_tiles, scale, key_block=None, head_dim: int = 64, fwd_tiles=None):
@@ -1081,5 +1138,5 @@ def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
 
 __all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
-           "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table", "recomputing",
+           "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "rope_flash_attn_varlen_qkv_fwd", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table", "recomputing",
            "attn_key_tile_table"]

@@ -176,6 +176,7 @@ class TrainStep:
         self.warmup_steps = int(math.ceil(total_steps * warmup_ratio))
         self.global_step = 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self._in_optimizer = False       # True while opt.step runs: an exception there leaves half-updated moments (no retry)
 
     def micro_step(self, batch, last: bool) -> torch.Tensor:
         if last:
@@ -187,7 +188,12 @@ class TrainStep:
     def abort_step(self):
         """After an exception inside `step` (e.g. an out-of-memory error the caller answers by checkpointing more blocks): drop
         the half-accumulated gradients and the reducer's armed state, so that the next `step` starts clean.  The optimizer's
-        moments and step count are untouched (the failed step never reached `opt.step`)."""
+        moments and step count are untouched (the failed step never reached `opt.step`).  An exception that came out of `opt.step`
+        itself (the clip-norm or all-gather temporaries running out of memory) is NOT retryable -- master weights and moments may
+        be half-updated -- and is refused here: the caller's `except` re-raises."""
+        if self._in_optimizer:
+            raise RuntimeError("TrainStep.abort_step: the step failed inside the optimizer update; its state may be half-updated and "
+                               "the step cannot be retried")
         r = self.opt.reducer
         r.reset()
         for p, o in zip(r.order, r.offsets):                   # every .grad is the parameter's view of the flat buffer again
@@ -204,6 +210,8 @@ class TrainStep:
             tot = l if tot is None else tot + l
         inv_world = self.opt.reducer.finish()
         mult = cosine_with_warmup(self.global_step, self.total_steps, self.warmup_steps)   # HF: scheduler steps after the optimizer
+        self._in_optimizer = True
         self.opt.step(grad_scale=inv_world / self.gas, lr_mult=mult)
+        self._in_optimizer = False
         self.global_step += 1
         return tot / self.gas

@@ -165,6 +165,20 @@ def test_load_encoder_in_the_requested_dtype_and_from_bin_files(tmp_path):
     e2 = PE.load_encoder(d2)
     for k, v in enc.state_dict().items():
         assert torch.equal(e1.state_dict()[k], v) and torch.equal(e2.state_dict()[k], v), k
+    # a LEGACY (non-zip) torch.save file cannot be memory-mapped; AutoModel.from_pretrained reads it, so does load_encoder
+    d3 = str(tmp_path / "bin3")
+    os.makedirs(d3)
+    json.dump(json.load(open(os.path.join(d, "config.json"))), open(os.path.join(d3, "config.json"), "w"))
+    torch.save({k: v.clone() for k, v in enc.state_dict().items()}, os.path.join(d3, PE.BIN_WEIGHTS), _use_new_zipfile_serialization=False)
+    e3 = PE.load_encoder(d3)
+    assert all(torch.equal(e3.state_dict()[k], v) for k, v in enc.state_dict().items())
+    # save_encoder clears ITS OWN previous files only (another shard count), never a user's file that happens to match model*.safetensors
+    open(os.path.join(d, "model_notes.safetensors"), "wb").write(b"mine")
+    n_before = len([f for f in os.listdir(d) if f.startswith("model-")])
+    PE.save_encoder(enc, d)                                             # one shard now
+    left = sorted(os.listdir(d))
+    assert n_before > 1 and "model_notes.safetensors" in left and PE.SAFE_WEIGHTS in left
+    assert not [f for f in left if f.startswith("model-")] and PE.SAFE_INDEX not in left
 
 
 def _cpu_optimizer_kernels(FlatAdamW, monkeypatch):

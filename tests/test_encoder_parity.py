@@ -252,7 +252,7 @@ def test_packed_pooled_path_equals_padded_path(ci):
     for ck in (False, True):
         enc.zero_grad()
         if ck:
-            enc.gradient_checkpointing_enable()
+            enc.gradient_checkpointing_enable(layers="all")
         enc.pooled_last_token(ids, m).backward(gr)
         assert (enc.layers[0].self_attn.q_proj.weight.grad - g0).abs().max() < 1e-5 * max(1.0, g0.abs().max().item())
         assert (enc.embed_tokens.weight.grad - e0).abs().max() < 1e-5 * max(1.0, e0.abs().max().item())

@@ -370,6 +370,14 @@ def test_flash_attn_fwd_head_dim_128(lens, nh, nkv, fused):
         ops.flash_attn_varlen_bwd(q, k, v, out, go, lse, cu, tiles, ops.attn_key_tile_table(lens, DEV, nkv), scale, key_block=256)
 
 
+def _need_onewave64(hd=64):
+    """The head_dim-64 one-wave-per-SIMD kernels are an opt-in of the build (`make ONEWAVE64=1`: they lose to the default kernels,
+    profiles/r05_fa_fwd128w_ladder.md); the default library answers RPO_ERR_UNSUPPORTED there, which is checked where it is skipped."""
+    from rankpo_amd import _lib
+    if hd == 64 and not (_lib.load().rpo_build_flags() & _lib.RPO_BUILD_ONEWAVE64):
+        pytest.skip("librankpo_hip.so was built without ONEWAVE64=1")
+
+
 @pytest.mark.parametrize("hd", [128, 64])
 @pytest.mark.parametrize("lens,nh,nkv,fused", [
     ([128], 4, 1, False), ([1], 4, 1, False), ([64, 1, 200, 129, 33, 31, 32, 65, 63], 8, 2, False),
@@ -379,6 +387,7 @@ def test_flash_attn_fwd_one_wave(lens, nh, nkv, fused, hd):
     deferred softmax scale, Q in / O out through LDS as whole rows) against the f32 reference and against the 128-query kernel,
     on both list formats, the padded-lse layout, strided (fused-projection) views, the rotary fold, and through autograd with the
     hand-written backward (which walks the 128-row list)."""
+    _need_onewave64(hd)
     from rankpo_amd import ops
     torch.manual_seed(sum(lens) + 7 + hd)
     T = sum(lens)
@@ -438,6 +447,7 @@ def test_flash_attn_fwd_one_wave_rescales_and_refusals(hd):
     """The deferred scale: logits that keep growing along the sequence (every few tiles some row outgrows 2^8 times its scale: the
     RESCALE statements of both score generations run, many times) and logits far below zero (the scale starts at tile 0's row
     maximum, not at 0) still match the f32 reference; what the kernel is not built for is refused, not mis-run."""
+    _need_onewave64(hd)
     from rankpo_amd import ops
     from rankpo_amd._lib import RankPOHipError
     torch.manual_seed(5)
@@ -475,6 +485,7 @@ def test_flash_attn_dq_one_wave_head_dim_64(lens, nh, nkv, fused):
     """fa_bwd_dq64w_kernel (rpo_flash_attn_bwd's q_block = 64: 64 queries x 4 q heads per block, one wave per SIMD, generated
     statements) against fa_bwd_dq_kernel and the f32 reference: dq, and -- through the row constants it writes for the dK/dV
     kernel -- dk and dv; both list formats; strided views; the rotary epilogue."""
+    _need_onewave64()
     from rankpo_amd import ops
     torch.manual_seed(sum(lens) + 11)
     T, hd = sum(lens), 64
@@ -518,6 +529,7 @@ def test_one_wave_kernels_on_a_long_sequence(hd):
     """16 k tokens in one sequence (512 key tiles: the K / V rings of the one-wave kernels wrap 64-128 times, the eight statement
     variants of the dQ kernel and the four of the forward come round many times) beside a short one, against the 128-query
     kernels -- forward at both head dims, and the head_dim-64 dQ kernel."""
+    _need_onewave64(hd)
     from rankpo_amd import ops
     torch.manual_seed(3 + hd)
     lens, nh, nkv = [16384 + 37, 70], 4, 1
@@ -698,3 +710,25 @@ def test_last_query_attention_lse_and_speed_report():
     nbytes = 2 * T * nkv * hd * 2
     print(f"\nlast-query attention, cfg-2 shape (T = {T}): forward HIP {ours:.0f} us = {nbytes / ours / 1e3:.0f} GB/s of K|V; PyTorch op "
           f"{theirs:.0f} us; backward HIP {ours_b:.0f} us = {2 * nbytes / ours_b / 1e3:.0f} GB/s (K|V read + dK|dV written)")
+
+
+def test_default_build_refuses_the_optional_one_wave_64_kernels():
+    """Without ONEWAVE64=1 the q_block = 64 entries at head_dim 64 are RPO_ERR_UNSUPPORTED (status -2), forward and backward: refused
+    loudly, never mis-run; with it the tests above run them."""
+    from rankpo_amd import ops, _lib
+    from rankpo_amd._lib import RankPOHipError
+    if _lib.load().rpo_build_flags() & _lib.RPO_BUILD_ONEWAVE64:
+        pytest.skip("this library holds the one-wave 64 kernels")
+    lens, nh, nkv, hd = [200, 70], 8, 2, 64
+    T = sum(lens)
+    q = torch.randn(T, nh, hd, device=DEV).to(torch.bfloat16)
+    k = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+    v = torch.randn(T, nkv, hd, device=DEV).to(torch.bfloat16)
+    cu = torch.tensor([0] + list(np.cumsum(lens)), dtype=torch.int32, device=DEV)
+    t64 = ops.attn_fwd_tile_table(lens, DEV, nh, nkv, hd, force=True)
+    with pytest.raises(RankPOHipError, match="status -2"):
+        ops.flash_attn_varlen_fwd(q, k, v, cu, t64, 0.125, q_block=64)
+    out, lse = ops.flash_attn_varlen_fwd(q, k, v, cu, ops.attn_tile_table(lens, DEV, nh, nkv), 0.125)
+    with pytest.raises(RankPOHipError, match="status -2"):
+        ops.flash_attn_varlen_bwd(q, k, v, out, torch.randn_like(out), lse, cu, t64, ops.attn_key_tile_table(lens, DEV, nkv), 0.125,
+                                  q_block=64)

@@ -67,7 +67,7 @@ def test_bench_path_parity_bf16_packed_filler(hd, ckpt):
     bench = importlib.import_module("bench")
     cfg, enc, model = _model(PE, rankpo_amd, hd=hd)
     if ckpt:
-        model.gradient_checkpointing_enable()
+        model.gradient_checkpointing_enable(layers="all")
     batch, tot = _batch()
 
     # spies: the branches under test must be the ones that run
@@ -121,7 +121,7 @@ def test_checkpointed_blocks_skip_their_recomputed_output_and_keep_one_input(hd)
     import rankpo_amd
     from rankpo_amd import encoder as PE, ops, _lib
     cfg, enc, model = _model(PE, rankpo_amd, seed=3, hd=hd)
-    model.gradient_checkpointing_enable()
+    model.gradient_checkpointing_enable(layers="all")
     batch, _ = _batch()
     gb = {k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in batch.items()}
     lib = _lib.load()
@@ -147,9 +147,12 @@ def test_checkpointed_blocks_skip_their_recomputed_output_and_keep_one_input(hd)
         l_skip, g_skip, n_skip = run(True, True)
         l_full, g_full, n_full = run(False, True)
         l_pair, g_pair, _ = run(True, False)
+        ops.POISON_SKIPPED_OUTPUT = True          # the skipped output as NaNs: whoever read it would carry them into a gradient
+        l_nan, g_nan, _ = run(True, True)
     finally:
-        ops.SKIP_RECOMPUTED_OUTPUT, PE.CKPT_SINGLE_INPUT = True, True
+        ops.SKIP_RECOMPUTED_OUTPUT, PE.CKPT_SINGLE_INPUT, ops.POISON_SKIPPED_OUTPUT = True, True, False
     assert l_skip == l_full and all(torch.equal(g_skip[n], g_full[n]) for n in g_skip)
+    assert l_nan == l_full and all(torch.equal(g_nan[n], g_full[n]) for n in g_nan)      # nothing reads the skipped output
     assert n_full - n_skip == cfg.num_hidden_layers, (n_full, n_skip)              # one product pass per checkpointed block less
     assert abs(l_skip - l_pair) < 2e-3 * max(1.0, abs(l_pair))
     num = sum((g_skip[n].float() - g_pair[n].float()).norm() ** 2 for n in g_skip) ** 0.5

@@ -857,14 +857,47 @@ def test_no_valu_reads_a_transcendental_result_in_the_next_slot(tmp_path):
     if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
         pytest.skip("no hipcc")
     root = os.path.join(os.path.dirname(__file__), "..")
-    subprocess.run(["make", "-s", "-C", os.path.join(root, "rankpo_amd", "csrc"), "isa", f"ISA_DIR={tmp_path}"], check=True,
-                   capture_output=True, text=True)
+    # ONEWAVE64=1: the ISA of the optional head_dim-64 one-wave kernels is checked too (the default library leaves them out)
+    subprocess.run(["make", "-s", "-C", os.path.join(root, "rankpo_amd", "csrc"), "isa", f"ISA_DIR={tmp_path}", "ONEWAVE64=1"],
+                   check=True, capture_output=True, text=True)
     files = sorted(str(p) for p in tmp_path.glob("*.s"))
     assert len(files) == 8, files
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "check_trans_hazard.py")] + files, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:]
     _check_dkdv_prefetch_registers(os.path.join(str(tmp_path), "attention.s"), root)
     _check_fwd128w_register_ownership(os.path.join(str(tmp_path), "attention.s"), root)
+    _check_counted_waits(os.path.join(str(tmp_path), "attention.s"), os.path.join(str(tmp_path), "infonce.s"), root)
+
+
+def _check_counted_waits(attention_s, infonce_s, root):
+    """Advisor finding of round 5 (medium): the counted `s_waitcnt vmcnt(N)` waits of the one-wave-per-SIMD attention forwards and of
+    the persistent 256 x 256 similarity kernel assume an exact number and order of vector-memory instructions in flight.
+    tools/check_vmcnt_isa.py (run by `make` after every compile, a failure fails the build): the prologue rule on the code hipcc
+    generated here, the recorded signatures (tools/isa_signatures.json) match that code, and both have teeth."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("check_vmcnt_isa", os.path.join(root, "tools", "check_vmcnt_isa.py"))
+    C = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(C)
+    assert C.main([attention_s, infonce_s]) == 0
+    isa = open(attention_s).read()
+    for kern, qp, waits in (("fa_fwd128w_kernel", 16, [12, 28]), ("fa_fwd64w_kernel", 8, [6, 14])):
+        rep = C.prologue_report(isa, kern, qp)
+        assert rep["ok"] and rep["counted_waits"] == waits, rep
+        name, body = C.kernels(isa, kern)[0]
+        first_dma = re.search(r"^\s*global_load_lds_dwordx4[^\n]*\n", body, flags=re.M)
+        plain = re.search(r"^\s*global_load_dwordx4 v\[[^\n]*\n", body, flags=re.M)
+        assert first_dma and plain and plain.start() > first_dma.start()
+        # teeth (a): a rotary-table load hoisted in front of the Q pieces
+        hoisted = body[:first_dma.start()] + plain.group(0) + body[first_dma.start():plain.start()] + body[plain.end():]
+        bad = C.prologue_report(isa.replace(body, hoisted), kern, qp)
+        assert not bad["ok"] and any("in front of or between" in p_ for p_ in bad["problems"]), bad
+        # teeth (b): one K / V piece gone: no path carries exactly N instructions behind the Q pieces any more, and the signature moves
+        dmas = list(re.finditer(r"^\s*global_load_lds_dwordx4[^\n]*\n", body, flags=re.M))
+        gone = body[:dmas[qp].start()] + body[dmas[qp].end():]
+        bad = C.prologue_report(isa.replace(body, gone), kern, qp)
+        assert not bad["ok"] and any("no longer matches" in p_ for p_ in bad["problems"]), bad
+        assert C.signature(isa.replace(body, gone), kern)["sha256"] != C.signature(isa, kern)["sha256"]
 
 
 def _check_fwd128w_register_ownership(attention_s, root):
@@ -1037,6 +1070,7 @@ _GIB = 2 ** 30
 _TOK_CONTRASTIVE = 8 * 1280 + 48 * 4096          # cfg 2 / cfg 5: every row at full length (the pre-size step's batch)
 _LLAMA_1B = (1_235_828_736 + 7 * 2048, 2, 2048, 8192, 16)      # parameters, bytes per element, d, ff, blocks
 _LLAMA_8B = (7_504_953_344, 2, 4096, 14336, 32)
+from rankpo_amd import memory as M      # noqa: E402  (the plan lives in the package since round 6; bench.py drives it)
 
 
 def test_recomputation_context_is_seen_only_by_the_recomputation():
@@ -1079,48 +1113,49 @@ def test_memory_guard_plans_cfg2_and_cfg5_without_a_gpu():
     cfg 2 runs all 16 blocks un-checkpointed (measured worst-case peak 198 GiB, modelled 187); cfg 5 on one GPU checkpoints all
     32 (measured 253.4 GiB at 287.2 usable, modelled 253.7); with the optimizer state partitioned over 8 ranks 4 blocks run free."""
     import bench
+    assert bench.plan_checkpointing is M.plan_checkpointing and bench.checkpoint_fewer is M.checkpoint_fewer      # ONE plan
     usable = int(287.2 * _GIB)
-    assert bench.plan_free_blocks(usable, *_LLAMA_1B, _TOK_CONTRASTIVE) == 16
-    assert bench.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE) == (0, False)
-    assert abs(bench.modelled_peak_bytes(16, *_LLAMA_1B, _TOK_CONTRASTIVE) / _GIB - 198) < 15
-    assert bench.plan_free_blocks(usable, *_LLAMA_8B, _TOK_CONTRASTIVE) == 0
-    assert bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE) == (32, False)
+    assert M.plan_free_blocks(usable, *_LLAMA_1B, _TOK_CONTRASTIVE) == 16
+    assert M.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE) == (0, False)
+    assert abs(M.modelled_peak_bytes(16, *_LLAMA_1B, _TOK_CONTRASTIVE) / _GIB - 198) < 15
+    assert M.plan_free_blocks(usable, *_LLAMA_8B, _TOK_CONTRASTIVE) == 0
+    assert M.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE) == (32, False)
     # the calibration point: state + two kept input tensors per block + the block in flight (profiles/r05_cfg5_memory_summary.txt)
-    assert abs(bench.modelled_peak_bytes(0, *_LLAMA_8B, _TOK_CONTRASTIVE) / _GIB - 253.4) < 2.0
-    assert abs(bench.optimizer_state_bytes(_LLAMA_8B[0], 2, 1, False) / _GIB - 111.8) < 0.2
+    assert abs(M.modelled_peak_bytes(0, *_LLAMA_8B, _TOK_CONTRASTIVE) / _GIB - 253.4) < 2.0
+    assert abs(M.optimizer_state_bytes(_LLAMA_8B[0], 2, 1, False) / _GIB - 111.8) < 0.2
     # round 5: x + delta is formed in front of a checkpointed block, which then keeps ONE input tensor: 50.5 GiB less at cfg 5,
     # spent on two un-checkpointed blocks (each 17 GiB of activations instead of 1.6 GiB of input)
-    assert abs(bench.modelled_peak_bytes(0, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) / _GIB - (253.7 - 50.5)) < 0.5
-    assert bench.plan_free_blocks(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) == 2
-    assert bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) == (30, False)
-    assert bench.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, block_inputs=1) == (0, False)
+    assert abs(M.modelled_peak_bytes(0, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) / _GIB - (253.7 - 50.5)) < 0.5
+    assert M.plan_free_blocks(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) == 2
+    assert M.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, block_inputs=1) == (30, False)
+    assert M.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, block_inputs=1) == (0, False)
     # ... and what the measured worst-case step leaves under the plan's own budget goes back, once: cfg 5 measured 204.4 GiB with 30
     # blocks checkpointed (modelled 234); with 2 x 11 GiB set aside for the transposed d(gate|up) buffer one more block runs free
     shape8 = _LLAMA_8B + (_TOK_CONTRASTIVE,)
-    assert bench.checkpoint_fewer(int(204.4 * _GIB), usable, 30, *shape8, block_inputs=1, reserve=2 * int(11.0 * _GIB)) == 29
-    assert bench.checkpoint_fewer(int(204.4 * _GIB), usable, 30, *shape8, block_inputs=1) == 28
-    assert bench.checkpoint_fewer(int(243.0 * _GIB), usable, 30, *shape8, block_inputs=1) == 30          # no room: nothing changes
-    assert bench.checkpoint_fewer(int(60.0 * _GIB), usable, 2, *shape8, block_inputs=1) == 0             # never below zero
-    assert bench.checkpoint_fewer(int(60.0 * _GIB), usable, 0, *shape8, block_inputs=1) == 0
+    assert M.checkpoint_fewer(int(204.4 * _GIB), usable, 30, *shape8, block_inputs=1, reserve=2 * int(11.0 * _GIB)) == 29
+    assert M.checkpoint_fewer(int(204.4 * _GIB), usable, 30, *shape8, block_inputs=1) == 28
+    assert M.checkpoint_fewer(int(243.0 * _GIB), usable, 30, *shape8, block_inputs=1) == 30          # no room: nothing changes
+    assert M.checkpoint_fewer(int(60.0 * _GIB), usable, 2, *shape8, block_inputs=1) == 0             # never below zero
+    assert M.checkpoint_fewer(int(60.0 * _GIB), usable, 0, *shape8, block_inputs=1) == 0
     # 8 ranks: `auto` partitions the optimizer state exactly because the replicated state forces checkpointing, and gives the
     # freed 70 GiB back to activations
-    ckpt, part = bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="auto")
+    ckpt, part = M.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="auto")
     assert part is True and ckpt == 28
-    assert bench.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="off") == (32, False)
-    assert bench.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="auto") == (0, False)
+    assert M.plan_checkpointing(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="off") == (32, False)
+    assert M.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, world=8, multi=True, partition_mode="auto") == (0, False)
     # a card with less room (another tenant, RCCL buffers): fewer free blocks, never a negative count; monotone in the room
     last = -1
     for room in (40, 120, 180, 230, 287.2, 400):
-        f = bench.plan_free_blocks(int(room * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE)
+        f = M.plan_free_blocks(int(room * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE)
         assert 0 <= f <= 16 and f >= last
         last = f
-    assert bench.plan_free_blocks(int(40 * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE) == 0
+    assert M.plan_free_blocks(int(40 * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE) == 0
     # encoders without per-block control: all or nothing
-    assert bench.plan_checkpointing(int(100 * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE, per_block_control=False) == (-1, False)
-    assert bench.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, per_block_control=False) == (0, False)
+    assert M.plan_checkpointing(int(100 * _GIB), *_LLAMA_1B, _TOK_CONTRASTIVE, per_block_control=False) == (-1, False)
+    assert M.plan_checkpointing(usable, *_LLAMA_1B, _TOK_CONTRASTIVE, per_block_control=False) == (0, False)
     # a --share-gpu rehearsal splits the card between its ranks
-    assert bench.usable_hbm(200 * _GIB, 10 * _GIB, 288 * _GIB, 4) == (210 * _GIB) // 4
-    assert bench.usable_hbm(280 * _GIB, 20 * _GIB, 288 * _GIB) == 288 * _GIB
+    assert M.usable_hbm(200 * _GIB, 10 * _GIB, 288 * _GIB, 4) == (210 * _GIB) // 4
+    assert M.usable_hbm(280 * _GIB, 20 * _GIB, 288 * _GIB) == 288 * _GIB
 
 
 def test_memory_guard_retry_and_transposed_buffer_decisions():
@@ -1130,24 +1165,24 @@ def test_memory_guard_retry_and_transposed_buffer_decisions():
     out-of-memory error may be answered by a retry only when the process is alone."""
     import bench
     usable = int(287.2 * _GIB)
-    assert bench.presize_is_tight(int(253.4 * _GIB), usable) is False          # cfg 5, N = 1: 88 %
-    assert bench.presize_is_tight(int(271 * _GIB), usable) is True
-    assert bench.presize_is_tight(0, usable, oom=True) is True
-    assert [bench.checkpoint_more(c, 32) for c in (0, 8, 22, 28, 31, 32)] == [8, 16, 30, 32, 32, None]
-    assert bench.checkpoint_more(0, 2) == 1 and bench.checkpoint_more(16, 16) is None
-    need8 = bench.transposed_dgu_bytes(14336, _TOK_CONTRASTIVE, 2)
-    need1 = bench.transposed_dgu_bytes(8192, _TOK_CONTRASTIVE, 2)
+    assert M.presize_is_tight(int(253.4 * _GIB), usable) is False          # cfg 5, N = 1: 88 %
+    assert M.presize_is_tight(int(271 * _GIB), usable) is True
+    assert M.presize_is_tight(0, usable, oom=True) is True
+    assert [M.checkpoint_more(c, 32) for c in (0, 8, 22, 28, 31, 32)] == [8, 16, 30, 32, 32, None]
+    assert M.checkpoint_more(0, 2) == 1 and M.checkpoint_more(16, 16) is None
+    need8 = M.transposed_dgu_bytes(14336, _TOK_CONTRASTIVE, 2)
+    need1 = M.transposed_dgu_bytes(8192, _TOK_CONTRASTIVE, 2)
     lim = 6 * _GIB
     assert abs(need8 / _GIB - 11.05) < 0.05 and abs(need1 / _GIB - 6.31) < 0.05
-    assert bench.admit_transposed_dgu(int(253.4 * _GIB), need8, usable, lim) is False      # cfg 5 on one GPU
-    assert bench.admit_transposed_dgu(int(198 * _GIB), need1, usable, lim) is True         # cfg 2's full-length batch
-    assert bench.admit_transposed_dgu(int(100 * _GIB), 5 * _GIB, usable, lim) is None      # within ops' static default: no decision
+    assert M.admit_transposed_dgu(int(253.4 * _GIB), need8, usable, lim) is False      # cfg 5 on one GPU
+    assert M.admit_transposed_dgu(int(198 * _GIB), need1, usable, lim) is True         # cfg 2's full-length batch
+    assert M.admit_transposed_dgu(int(100 * _GIB), 5 * _GIB, usable, lim) is None      # within ops' static default: no decision
     # 8 ranks, state partitioned: what the plan's own peak model says for the free-block count it chose, and for one block fewer
     # (the measured peak decides at run time; on every rank the same way: the verdict is all-reduced)
     for free, expect in ((4, False), (3, True)):
-        peak = bench.modelled_peak_bytes(free, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, partitioned=True)
-        assert bench.admit_transposed_dgu(int(peak), need8, usable, lim) is expect
-    assert bench.may_retry_after_oom(1) is True and bench.may_retry_after_oom(2) is False
+        peak = M.modelled_peak_bytes(free, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, partitioned=True)
+        assert M.admit_transposed_dgu(int(peak), need8, usable, lim) is expect
+    assert M.may_retry_after_oom(1) is True and M.may_retry_after_oom(2) is False
 
 
 def test_train_step_abort_leaves_a_clean_reducer(monkeypatch):
@@ -1187,3 +1222,63 @@ def test_train_step_abort_leaves_a_clean_reducer(monkeypatch):
     ts2.step([x])
     for a, b in zip(net.parameters(), ref.parameters()):
         assert torch.equal(a, b)                           # the retried step = a first step: nothing of the failed one leaked
+    # an exception out of the OPTIMIZER update is not retryable (moments may be half-updated): abort_step refuses (advisor, round 5)
+    real_step = ts.opt.step
+
+    def failing_step(*a, **kw):
+        raise torch.OutOfMemoryError("synthetic, inside opt.step")
+    ts.opt.step = failing_step
+    with pytest.raises(torch.OutOfMemoryError):
+        ts.step([x])
+    with pytest.raises(RuntimeError, match="inside the optimizer update"):
+        ts.abort_step()
+    ts.opt.step = real_step
+
+
+def test_infonce_backward_dispatch_never_hands_the_hip_product_what_it_refuses():
+    """Advisor finding of round 5 (medium): `rpo_sim_gemm_nt` returns RPO_ERR_UNSUPPORTED for operands of 4 GiB or more (32-bit
+    piece offsets) and `check()` raises; the dispatch in `_bwd_product` now restates the entry point's conditions
+    (`ops.sim_gemm_nt_takes`) so that such a dS goes to `ds @ x_all` as it did before the hand-written arm existed."""
+    from rankpo_amd import ops
+    ok = ops.sim_gemm_nt_takes
+    assert ok(16384, 16384, 2048, 16384)                            # the sweep's top shape
+    assert not ok(32768, 65536, 2048, 65536)                        # dS = 4 GiB
+    assert ok(32768, 65536 - 64, 2048, 65536 - 64)                  # just below
+    assert not ok(1024, 2 ** 21, 1024, 2 ** 21)                     # the transposed embeddings [d, K] = 4 GiB
+    assert not ok(4096, 16400, 2048, 16400)                         # reduction not a multiple of the 64-element K-step
+    assert not ok(4096, 16384, 2044, 16384)                         # output rows not 16-byte pieces
+    assert not ok(4096, 16384, 2048, 16388)                         # a dS view whose row stride is not a multiple of 8
+    assert not ok(4096, 16384, 2048, 16384, ds_ptr=8)               # unaligned base
+    assert not ok(4096, 16384, 2048, 16384, bf16=False)             # f32 / fp16 storage: the library GEMM
+
+
+def test_gradient_checkpointing_enable_resolves_to_the_memory_plan():
+    """The reference's `--gradient_checkpointing` (scripts/train/run_contrastive.sh:39) checkpoints every block.  Here the bare call
+    resolves to rankpo_amd.memory's plan (as few blocks as fit); "all" / None / an int keep their explicit meaning; on a CPU encoder
+    there is no HBM to measure and every block is checkpointed, as HF does."""
+    import torch
+    from rankpo_amd import encoder as PE, memory as M
+    cfg = PE.llama_config(vocab_size=64, hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+                          num_key_value_heads=1, pad_token_id=0)
+    enc = PE.LlamaEncoder(cfg).train()
+    enc.gradient_checkpointing_enable()
+    assert enc.checkpoint_layers == "auto" and enc._checkpointed_blocks(1000) == 3 and enc.memory_plan.tokens == 1024
+    enc.gradient_checkpointing_enable(layers="all")
+    assert enc.checkpoint_layers is None and enc._checkpointed_blocks(10) == 3
+    enc.gradient_checkpointing_enable(layers=1)
+    assert enc._checkpointed_blocks(10) == 1
+    # the plan itself, from byte counts (what a GPU encoder measures): Llama-3.2-1B keeps every block at the BASELINE batch,
+    # Llama-3-8B on one GPU checkpoints 30 of 32, on 8 GPUs with the optimizer state partitioned far fewer; a longer batch only
+    # ever moves towards more checkpointing
+    usable = int(287.5 * _GIB)
+    p1 = M.plan_for_shape(usable, *_LLAMA_1B, _TOK_CONTRASTIVE)
+    assert p1.checkpoint_blocks == 0 and p1.tokens == _TOK_CONTRASTIVE and p1.modelled_peak < 0.85 * usable
+    p8 = M.plan_for_shape(usable, *_LLAMA_8B, _TOK_CONTRASTIVE)
+    need8 = M.transposed_dgu_bytes(14336, _TOK_CONTRASTIVE, 2)
+    assert p8.checkpoint_blocks == 30 and p8.transposed_dgu_limit == need8      # 11 GiB buffer: modelled peak 234 GiB + 2 x 11 < 90 %
+    assert M.plan_for_shape(int(250 * _GIB), *_LLAMA_8B, _TOK_CONTRASTIVE).transposed_dgu_limit == 6 * 2 ** 30    # less HBM: refused
+    p8w = M.plan_for_shape(usable, *_LLAMA_8B, _TOK_CONTRASTIVE, world=8, partitioned=True)
+    assert p8w.checkpoint_blocks == 25 and p8w.transposed_dgu_limit == 6 * 2 ** 30    # the room goes to 5 more free blocks, not to the buffer
+    #   (a recomputed block costs ~56 ms per step, the buffer saves ~1.2 ms per block: bench.py makes the same choice from measurements)
+    assert M.plan_for_shape(usable, *_LLAMA_1B, 2 * _TOK_CONTRASTIVE).checkpoint_blocks > 0
+    assert M.pad_tokens(1) == 256 and M.pad_tokens(256) == 256 and M.pad_tokens(257) == 512

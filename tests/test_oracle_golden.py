@@ -169,3 +169,57 @@ def test_round_bf16_matches_torch():
     x = np.random.RandomState(0).randn(4096).astype(np.float32) * np.float32(37.0)
     t = torch.from_numpy(x).to(torch.bfloat16).float().numpy()
     np.testing.assert_array_equal(R.round_bf16(x), t)
+
+
+# ---- the reference's own 16-bit runs (tests/golden/lowp.npz, tools/make_golden_lowp.py) ----------------------------------
+def _rankpo_oracle_on(tag, c, g0):
+    import lowp_util as LU
+    with_ref = not c["reference_free"]
+    q, p = LU.round_to(g0["q"], tag), LU.round_to(g0["p"], tag)
+    rc = LU.round_to(g0["ref_chosen"], tag) if with_ref else None
+    rr = LU.round_to(g0["ref_rejected"], tag) if with_ref else None
+    o = R.rankpo_batch_loss_metrics(q, p, rc, rr, beta=c["beta"], temperature=c["temperature"], gamma_beta_ratio=c["gamma_beta_ratio"],
+                                    label_smoothing=c["label_smoothing"], loss_type=c["loss_type"], reference_free=c["reference_free"],
+                                    rankpo_weight=c["rankpo_weight"], sft_weight=c["sft_weight"])
+    return o, rc, rr
+
+
+@pytest.mark.parametrize("tag", ["bf16", "fp16"])
+def test_rankpo_reference_in_16_bit_storage_within_the_stated_bound(golden, tag):
+    """The oracle (float64 on the 16-bit-rounded inputs) against what the REFERENCE produced in bf16 / fp16 on the same 48 knob
+    cases: scores within one unit roundoff, loss within tests/lowp_util.py's derived bound -- the tolerance the GPU test
+    (tests/test_gpu_f16.py) then holds the kernel to."""
+    import lowp_util as LU
+    g, meta = LU.load()
+    g0 = golden("rankpo")
+    u = LU.UNIT_ROUNDOFF[tag]
+    assert len(meta["rankpo_cases"][tag]) == 48
+    for c in meta["rankpo_cases"][tag]:
+        o, rc, rr = _rankpo_oracle_on(tag, c, g0)
+        s = g[c["name"] + "_scores"]
+        assert np.all(np.abs(s - o["scores"]) <= u * np.abs(o["scores"]) + 1e-12), c["name"]
+        bound = LU.rankpo_loss_bound(c, o["scores"], rc, rr, o["loss"], tag)
+        assert abs(c["loss"] - o["loss"]) <= bound, (c, o["loss"], bound)
+        assert c["metrics"]["rewards/accuracies"] == o["metrics"]["rewards/accuracies"]
+
+
+@pytest.mark.parametrize("d", [64, 384, 2048])
+def test_contrastive_reference_in_fp16_storage(golden, d):
+    """The oracle with the reference's two rounding points (dot -> storage dtype, / T -> storage dtype; modeling.py:294-295 on
+    fp16 tensors) against the reference's own fp16 run: scores within 2 fp16 ulps (a float32-vs-float64 accumulation flip of the
+    first rounding, doubled by the division's binade change), loss within 2^-10 relative (it is itself an fp16 number)."""
+    import lowp_util as LU
+    g, _ = LU.load()
+    from conftest import contrastive_inputs
+    qn, pn = contrastive_inputs(d)
+    q, p = LU.round_to(qn, "fp16"), LU.round_to(pn, "fp16")
+    raw = R.similarity(q, p)
+    exp = LU.round_to(LU.round_to(raw, "fp16") / 0.02, "fp16")
+    ref = g[f"contrastive_inbatch_d{d}_fp16_scores"]
+    assert np.all(np.abs(ref - exp) <= 2 * 2.0 ** -10 * np.maximum(np.abs(exp), 1e-2))
+    ev = g[f"contrastive_eval_d{d}_fp16_scores"]
+    assert np.all(np.abs(ev - LU.round_to(raw, "fp16")) <= 2.0 ** -10 * np.maximum(np.abs(raw), 1e-3))
+    m = ref.astype(np.float64)
+    lse = np.log(np.exp(m - m.max(-1, keepdims=True)).sum(-1)) + m.max(-1)
+    loss = (lse - m[np.arange(8), np.arange(8) * 6]).mean()
+    assert abs(float(g[f"contrastive_inbatch_d{d}_fp16_loss"]) - loss) <= 2.0 ** -9 * max(1.0, abs(loss))
