@@ -59,6 +59,9 @@ WORKLOADS = {
     "cfg5": ("llama-3-8b", 8, 5, 1280, 4096, 0.02, "bf16"),       # 8B contrastive (per-GPU part of configs[4])
     "cfg5r": ("llama-3-8b", 8, 1, 1280, 4096, 0.1, "bf16"),       # 8B RankPO + 0.5 x SFT (InfoNCE) loss: the other half of configs[4]
     "tiny": ("llama-tiny", 8, 5, 160, 512, 0.02, "bf16"),
+    # not a training step: ModelForInference.encode + exact top-k search, measured by bench_inference.py (SURVEY §8 a13 + f3)
+    "encode": ("llama-3.2-1b", 64, 0, 1280, 4096, 1.0, "bf16"),
+    "encode-tiny": ("llama-tiny", 64, 0, 1280, 4096, 1.0, "bf16"),     # the same code path on a small model (rehearsals)
 }
 
 
@@ -66,7 +69,7 @@ WORKLOADS = {
 # live HIP-event timing of the C entry points (events are recorded on the stream the kernels are launched on)
 # ----------------------------------------------------------------------------------------------------------
 def _es(dt):
-    return 2 if dt == 1 else 4
+    return 4 if dt == 0 else 2          # RPO_DT_F32 = 0; bf16 = 1 and fp16 = 2 are two bytes
 
 
 _LAST_T = [0]
@@ -1047,6 +1050,43 @@ from rankpo_amd.memory import (PLAN_HBM_FRACTION, PRESIZE_TIGHT_FRACTION, DGU_T_
                                admit_transposed_dgu, may_retry_after_oom)
 
 
+def inference_main(args, device, wd, rank, arch):
+    """--workload encode: ModelForInference.encode and the exact top-k search, ONE JSON line (bench_inference.py)."""
+    import bench_inference as BI
+    from rankpo_amd import _lib
+    from rankpo_amd.encoder import build_encoder
+    cfg = build_config(arch)
+    torch.manual_seed(0)
+    with torch.device(device):
+        enc = build_encoder(cfg)
+    enc = enc.to(torch.bfloat16)
+    timed = TimedLib(_lib.load())
+    _lib._lib = timed
+    hook_attn_tables()
+    note = lambda m: print(f"[bench r{rank} {time.strftime('%H:%M:%S')}] {m}", file=sys.stderr, flush=True)
+    small = arch != "llama-3.2-1b"
+    wd.phase("encode()", 1500)
+    enc_block = BI.encode_block(cfg, enc, device, note, reps=max(1, args.steps // 2), n_query=128 if small else 256,
+                                n_passage=128 if small else 256, oracle=not args.no_cpu_baseline)
+    wd.phase("search", 600)
+    search = BI.search_block(device, timed, note, ntotal=100_000 if small else 1_000_000)
+    wd.done()
+    pas = enc_block["passages"]
+    line = {"metric": "sentences/sec of ModelForInference.encode (passages <= 4096 tokens, batch 64), tokeniser included",
+            "value": pas["end_to_end"]["sentences_per_s"], "unit": "sentences/s", "n_gpus": 1, "steps": max(1, args.steps // 2),
+            "warmup": 1, "ms_per_step": round(1e3 * pas["end_to_end"]["seconds"] / (pas["sentences"] / pas["batch_size"]), 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"encode: {arch} architecture, bf16, 256 queries <= 1280 tokens + 256 passages <= 4096 tokens in batches "
+                                   "of 64 (scripts/evaluate/run_evaluate.sh); search: 10^6 x 2048 bf16 corpus, k = 100",
+                       "note": "NOT the headline metric of BASELINE.json (that is the default --workload cfg2); a step = one batch of 64"},
+            "roofline": {"bound": "mfma", "achieved": pas["pre_tokenised"]["achieved_TFLOPs"], "peak": MFMA_BF16_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": pas["pre_tokenised"]["frac_mfma"], "traffic": None,
+                         "of": "the whole forward (library GEMMs + hand-written attention + fused elementwise) on pre-tokenised passages, "
+                               "algorithmic FLOP on real tokens"},
+            "cpu_baseline": enc_block.get("cpu_baseline"), "encode": enc_block, "search": search}
+    print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1170,6 +1210,10 @@ def main():
     from rankpo_amd.train_step import TrainStep
 
     arch, B, K, Lq, Lp, temperature, dtn = WORKLOADS[args.workload]
+    if args.workload.startswith("encode"):
+        if world != 1:
+            raise SystemExit("--workload encode measures one GPU (encode() shards trivially: run N processes on N slices of the corpus)")
+        return inference_main(args, device, wd, rank, arch)
     dtype = torch.bfloat16 if dtn == "bf16" else torch.float32
     cfg = build_config(arch)
     torch.manual_seed(0)                      # identical weights on every rank (data parallel replicas)

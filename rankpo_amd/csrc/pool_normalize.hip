@@ -137,6 +137,107 @@ __global__ __launch_bounds__(kPoolThreads) void pool_normalize_fwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Forward, ONE WAVE PER SAMPLE (round 6).  The block-per-sample kernel above is a chain of dependent round trips with two
+// block-wide barriers in it: at an encode()-scale batch (N = 4096 samples x L = 512 x d = 2048 bf16: 50 MB of algorithmic traffic)
+// it moved 2.0 TB/s, a quarter of the HBM peak (profiles/r05_pmc_traffic.md).  Here a wave owns a sample: the whole mask row is
+// requested in ONE round of 16-byte loads per lane (up to four in flight per lane: L <= 512; longer rows go round again), the
+// argmin is a register scan + six wave shuffles (no LDS, no barrier), the pooled row is requested straight behind it (NV 16-byte
+// loads per lane in flight, the row stays in registers through the norm), and four samples share a block so that a CU holds up to
+// 32 samples in flight.  Rows of up to 8 vectors per lane (d <= 4096 bf16 / fp16, 2048 f32); anything else -- and rows that are not
+// 16-byte friendly -- takes the block kernel.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kPoolSamplesPerBlock = kPoolThreads / RPO_WAVE;
+
+__device__ __forceinline__ void argmin_take(int64_t v, int i, int64_t& best, int& bidx) {
+    if (v < best) { best = v; bidx = i; }              // strict '<': the earliest index of a lane's ascending scan wins ties
+}
+
+// First index of the minimum of m[0..L) by one wave (torch.argmin: ties -> smallest index).
+__device__ __forceinline__ int wave_argmin_first(const int64_t* __restrict__ m, int64_t L, int lane) {
+    int64_t best = INT64_MAX;
+    int bidx = INT32_MAX;
+    if ((L & 1) == 0 && rpo_aligned16_dev(m)) {
+        const longlong2* m2 = reinterpret_cast<const longlong2*>(m);
+        const int64_t np = L >> 1;                      // 16-byte pieces
+        for (int64_t p0 = 0; p0 < np; p0 += 4 * RPO_WAVE) {
+            longlong2 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {               // four independent loads in flight
+                const int64_t p = p0 + j * RPO_WAVE + lane;
+                v[j] = p < np ? m2[p] : longlong2{INT64_MAX, INT64_MAX};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = (int)(2 * (p0 + j * RPO_WAVE + lane));
+                argmin_take(v[j].x, i, best, bidx);
+                argmin_take(v[j].y, i + 1, best, bidx);
+            }
+        }
+    } else {
+        for (int64_t i = lane; i < L; i += RPO_WAVE) argmin_take(m[i], (int)i, best, bidx);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int64_t ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ov < best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    return bidx;
+}
+
+template <typename T, int NV>
+__global__ __launch_bounds__(kPoolThreads) void pool_normalize_fwd_wave_kernel(
+    const T* __restrict__ h, int64_t sn, int64_t sl, const int64_t* __restrict__ mask, int64_t N, int64_t L, int64_t d,
+    int pool_mode, int normalize, float eps, T* __restrict__ out, int32_t* __restrict__ idx_out, float* __restrict__ norm_out) {
+    const int lane = threadIdx.x & (RPO_WAVE - 1);
+    const int64_t n = (int64_t)blockIdx.x * kPoolSamplesPerBlock + (threadIdx.x >> 6);
+    if (n >= N) return;                                 // (whole waves: no barrier anywhere in this kernel)
+    int idx = 0;
+    if (pool_mode == RPO_POOL_LAST) {
+        const int am = wave_argmin_first(mask + n * L, L, lane);
+        idx = (int)(((int64_t)am - 1 + L) % L);         // (argmin - 1) mod L, python semantics
+    }
+    constexpr int V = Elem<T>::kVec;
+    const T* row = h + n * sn + (int64_t)idx * sl;
+    T* o = out + n * d;
+    Vec16<T> x[NV];
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {                      // NV loads in flight; vector j of lane l = elements (j * 64 + l) * V ...
+        const int64_t c = ((int64_t)j * RPO_WAVE + lane) * V;
+        if (c < d) x[j].load_nt(row + c);               // (read once: streaming)
+        else {
+#pragma unroll
+            for (int k = 0; k < V; ++k) x[j].v[k] = 0.f;
+        }
+    }
+    if (normalize) {
+#pragma unroll
+        for (int j = 0; j < NV; ++j)
+#pragma unroll
+            for (int k = 0; k < V; ++k) ss += x[j].v[k] * x[j].v[k];
+        ss = wave_sum(ss);
+    }
+    const float nrm = sqrtf(ss);
+    const float den = fmaxf(nrm, eps);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int64_t c = ((int64_t)j * RPO_WAVE + lane) * V;
+        if (c < d) {
+            if (normalize) {
+#pragma unroll
+                for (int k = 0; k < V; ++k) x[j].v[k] = x[j].v[k] / den;
+            }
+            x[j].store(o + c);
+        }
+    }
+    if (lane == 0) {
+        idx_out[n] = idx;
+        norm_out[n] = nrm;
+    }
+}
+
 // Backward.  grid = (bx, N): sample n = blockIdx.y.  Block x == 0 of every sample first produces dx_n
 // (written into dh / drow); then all blocks of the sample zero-fill the rest of dh[n] with 16-byte
 // non-temporal stores, skipping the pooled row (no 64-bit index arithmetic in the fill loop).
@@ -195,6 +296,23 @@ template <typename T>
 int launch_fwd(const void* h, int64_t sn, int64_t sl, const int64_t* mask, int64_t N, int64_t L, int64_t d,
                int pool_mode, int normalize, float eps, void* out, int32_t* idx_out, float* norm_out,
                hipStream_t st) {
+    constexpr int V = Elem<T>::kVec;
+    const int64_t vecs = rpo_cdiv(d, (int64_t)V * RPO_WAVE);           // 16-byte vectors per lane of a wave that owns a row
+    // every row 16-byte friendly: base pointers aligned and all strides multiples of the vector (the pooled row of sample n sits at
+    // h + n sn + idx sl for an idx only the kernel knows)
+    const bool wave_ok = d % V == 0 && vecs <= 8 && rpo_aligned16(h) && rpo_aligned16(out) && sn % V == 0 && sl % V == 0;
+    if (wave_ok) {
+        const dim3 grid((unsigned)rpo_cdiv(N, kPoolSamplesPerBlock)), block(kPoolThreads);
+#define RPO_POOL_WAVE(NV)                                                                                          \
+        RPO_LAUNCH((pool_normalize_fwd_wave_kernel<T, NV>), grid, block, 0, st, (const T*)h, sn, sl, mask, N, L, d, pool_mode, \
+                   normalize, eps, (T*)out, idx_out, norm_out)
+        if (vecs <= 1) RPO_POOL_WAVE(1);
+        else if (vecs <= 2) RPO_POOL_WAVE(2);
+        else if (vecs <= 4) RPO_POOL_WAVE(4);
+        else RPO_POOL_WAVE(8);
+#undef RPO_POOL_WAVE
+        return rpo_launch_status();
+    }
     RPO_LAUNCH(pool_normalize_fwd_kernel<T>, dim3((unsigned)N), dim3(kPoolThreads), 0, st,
                        (const T*)h, sn, sl, mask, L, d, pool_mode, normalize, eps, (T*)out, idx_out, norm_out);
     return rpo_launch_status();
@@ -226,7 +344,7 @@ extern "C" int rpo_pool_normalize_fwd(const void* h, int64_t h_stride_n, int64_t
     if (!h || !out || !idx_out || !norm_out || N <= 0 || L <= 0 || d <= 0) return RPO_ERR_INVALID_ARG;
     if (pool_mode != RPO_POOL_LAST && pool_mode != RPO_POOL_CLS) return RPO_ERR_INVALID_ARG;
     if (pool_mode == RPO_POOL_LAST && !mask) return RPO_ERR_INVALID_ARG;
-    if (L > INT32_MAX || N > 65535) return RPO_ERR_UNSUPPORTED;
+    if (L > INT32_MAX || N > INT32_MAX) return RPO_ERR_UNSUPPORTED;          // (the backward's grid holds N in its y dimension: 65535 there)
     hipStream_t st = (hipStream_t)stream;
     switch (dtype) {
         case RPO_DT_F32:
