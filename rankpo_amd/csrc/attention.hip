@@ -38,6 +38,42 @@ __device__ unsigned long long g_fa_stamp[8 * 8];
 #define RPO_STAMP(VAR)
 #define RPO_STAMP_ADD(I, A, B)
 #endif
+#ifdef RPO_FA_LADDER  // diagnostic build only (tools/exp/build_variant.sh ladder -DRPO_FA_LADDER; tools/fa_ladder64.py reads it): ONE record per
+                      // block of the three head_dim-64 kernels -- s_memrealtime (100 MHz, the same clock on every CU) at the block's entry,
+                      // at the start and the end of its key-tile / slice loop, after its last store was ISSUED and after it has LANDED,
+                      // + where it ran (XCC id, HW id) and how many iterations its loop had.  Region K of the buffer = kernel K
+                      // (0 forward, 1 dQ, 2 dK/dV); nothing of this exists in the shipped library.
+constexpr int kLadMax = 1 << 17;
+__device__ unsigned long long g_fa_ladder[3 * kLadMax * 8];
+#define RPO_LAD_DECL unsigned long long lad_[5] = {0, 0, 0, 0, 0}
+#define RPO_LAD(I)                                                                                      \
+    do {                                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(lad_[I])::"memory");             \
+        __builtin_amdgcn_sched_barrier(0);                                                              \
+    } while (0)
+#define RPO_LAD_END(K, ITERS)                                                                           \
+    do {                                                                                                \
+        RPO_LAD(3);                                                                                     \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                \
+        RPO_LAD(4);                                                                                     \
+        const unsigned bid_ = blockIdx.x + gridDim.x * blockIdx.y;                                      \
+        if (threadIdx.x == 0 && bid_ < (unsigned)kLadMax) {                                             \
+            unsigned xcc_, hw_;                                                                         \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                         \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                           \
+            unsigned long long* r_ = g_fa_ladder + ((size_t)(K) * kLadMax + bid_) * 8;                  \
+            r_[0] = lad_[0]; r_[1] = lad_[1]; r_[2] = lad_[2]; r_[3] = lad_[3]; r_[4] = lad_[4];        \
+            r_[5] = ((unsigned long long)xcc_ << 32) | hw_;                                             \
+            r_[6] = (unsigned long long)(ITERS);                                                        \
+            r_[7] = 1;                                                                                  \
+        }                                                                                               \
+    } while (0)
+#else
+#define RPO_LAD_DECL
+#define RPO_LAD(I)
+#define RPO_LAD_END(K, ITERS)
+#endif
 #if defined(RPO_FA_STAMP) && defined(RPO_FA_STAMP_FWD)
 #define RPO_FSTAMP(VAR) RPO_STAMP(VAR)
 #define RPO_FSTAMP_ADD(I, A, B) RPO_STAMP_ADD(I, A, B)
@@ -167,6 +203,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     int64_t lse_head_stride, int lse_packed, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod,
     bf16_t* q_rw) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kKvTile];       // ring of (K tile | V tile), 128-byte rows
+    RPO_LAD_DECL;
+    RPO_LAD(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, fr = lane & 15;
@@ -275,6 +313,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ta, tb_, tc, td, te, tf, tg;
 #endif
     int cur = 0;
+    RPO_LAD(1);
     for (int kt = 0; kt < nkt; ++kt) {
         RPO_FSTAMP(ta);
         if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile kt landed; tile kt + 1 may fly
@@ -448,6 +487,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
     if (lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_fa_stamp[wave * 8 + i], st_acc[i]);
 #endif
+    RPO_LAD(2);
     // ---- epilogue: O[q][16c + 4g + r] = O^T / l ;  lse = scale m + ln l
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -467,6 +507,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_fwd_kernel(
             lse[(int64_t)seq * lse_seq_stride + (int64_t)h * lse_head_stride + (lse_packed ? t0 : 0) + qi] =
                 mrun[n] * scale + logf(l);
     }
+    RPO_LAD_END(0, nkt);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -874,6 +915,8 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
     float* __restrict__ nd_out, int64_t T, bf16_t* __restrict__ dq, int64_t sdq, const float* __restrict__ rcos,
     const float* __restrict__ rsin, int64_t rperiod) {
     __shared__ __attribute__((aligned(16))) char smem[3 * kDqTile];      // ring of (K tile | V tile), chunk ^= row & 7
+    RPO_LAD_DECL;
+    RPO_LAD(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, fr = lane & 15;
@@ -968,6 +1011,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
     const unsigned smem_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
 
     int cur = 0;
+    RPO_LAD(1);
     for (int kt = 0; kt < nkt; ++kt) {
         if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // tile kt landed; tile kt + 1 may fly
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1063,6 +1107,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
         }
         cur = cur == 2 ? 0 : cur + 1;
     }
+    RPO_LAD(2);
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
         const int qi = qw + 16 * n + fr;
@@ -1085,6 +1130,7 @@ __global__ __launch_bounds__(kFaThreads, 2) void fa_bwd_dq_kernel(
             *reinterpret_cast<uint2*>(row + 16 * c + 4 * g) = w;
         }
     }
+    RPO_LAD_END(1, nkt);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -2827,6 +2873,8 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
     const float* __restrict__ nd, int64_t T, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int64_t sdk,
     int64_t sdv, int n_ktiles, int gshift, const float* __restrict__ rcos, const float* __restrict__ rsin, int64_t rperiod) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    RPO_LAD_DECL;
+    RPO_LAD(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, fr = lane & 15;
@@ -3192,6 +3240,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
 #ifdef RPO_D4_EXP_DQ_ATOMICS
     int exp_hq = hk * group;
 #endif
+    RPO_LAD(1);
     for (int it = 0; it < niter; ++it) {
         if constexpr (DOWN) sl = nsl - 1 - (it >> gshift);
         // slices <= it + 1 have landed (the body prefetches from the next image).  Steady state (slices still being staged):
@@ -3349,6 +3398,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
 #endif
         }
     }
+    RPO_LAD(2);
     // epilogue: dK[key][16 c + 4 g + r] = scale * dka, dV likewise (unscaled); the wave owns its keys: no reduction
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");       // the last MFMAs' results are readable
     float4_t dka[4][4], dva[4][4];
@@ -3602,6 +3652,7 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv4_kernel(
             *reinterpret_cast<uint2*>(vrow + 16 * c) = w;
         }
     }
+    RPO_LAD_END(2, niter);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -4215,6 +4266,22 @@ __global__ __launch_bounds__(256, 1) void fa_bwd_dkdv128_kernel(
 }
 
 }  // namespace
+
+#ifdef RPO_FA_LADDER
+// host copy of region `kernel` (0 forward, 1 dQ, 2 dK/dV) of the per-block records: out = nblocks x 8 uint64; reset: zero the region
+extern "C" int rpo_debug_fa_ladder(unsigned long long* out, int kernel, int nblocks, int reset) {
+    if (kernel < 0 || kernel > 2 || nblocks <= 0 || nblocks > kLadMax) return -1;
+    const size_t off = (size_t)kernel * kLadMax * 8 * sizeof(unsigned long long), n = (size_t)nblocks * 8 * sizeof(unsigned long long);
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fa_ladder), n, off) != hipSuccess) return -1;
+    if (reset) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_fa_ladder)) != hipSuccess) return -1;
+        if (hipMemset((char*)p + off, 0, n) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 #ifdef RPO_FA_STAMP
 extern "C" int rpo_debug_fa_stamps(unsigned long long* out64, int reset) {

@@ -300,7 +300,12 @@ int launch_fwd(const void* h, int64_t sn, int64_t sl, const int64_t* mask, int64
     const int64_t vecs = rpo_cdiv(d, (int64_t)V * RPO_WAVE);           // 16-byte vectors per lane of a wave that owns a row
     // every row 16-byte friendly: base pointers aligned and all strides multiples of the vector (the pooled row of sample n sits at
     // h + n sn + idx sl for an idx only the kernel knows)
-    const bool wave_ok = d % V == 0 && vecs <= 8 && rpo_aligned16(h) && rpo_aligned16(out) && sn % V == 0 && sl % V == 0;
+    // ... and only where it measured faster (profiles/r06_pool_normalize.md, kernel durations from rocprofv3's trace on cold data):
+    // last-token pooling of MANY samples with mask rows a wave reads in one or two rounds -- 4096 x 512 x 2048: 15.2 vs 15.7 us,
+    // 16384 x 128 x 4096: 61.5 vs 70.6.  One long mask row per wave loses to 256 threads on it (64 x 4096: 10.9 vs 7.1 us), and
+    // without a mask (CLS / packed rows) the two forms are the same two round trips (4096 rows: 11.1 vs 10.2).
+    const bool wave_ok = d % V == 0 && vecs <= 8 && rpo_aligned16(h) && rpo_aligned16(out) && sn % V == 0 && sl % V == 0 &&
+                         pool_mode == RPO_POOL_LAST && N >= 512 && L <= 1024;
     if (wave_ok) {
         const dim3 grid((unsigned)rpo_cdiv(N, kPoolSamplesPerBlock)), block(kPoolThreads);
 #define RPO_POOL_WAVE(NV)                                                                                          \

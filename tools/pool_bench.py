@@ -33,30 +33,52 @@ def bind(path):
 
 def main():
     new = _lib.load()
-    old_path = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "tools", "exp", "librankpo_hip_r5pool.so")
+    # --shape I: that shape only (under `rocprofv3 --kernel-trace --stats` the per-kernel averages are then this shape's own kernel
+    # durations: the Python loop issues a launch every ~10 us, so for kernels shorter than that the event brackets below measure the
+    # launch rate, not the kernel)
+    only = None
+    argv = sys.argv[1:]
+    if "--shape" in argv:
+        only = int(argv[argv.index("--shape") + 1])
+        del argv[argv.index("--shape"):argv.index("--shape") + 2]
+    old_path = argv[0] if argv else os.path.join(ROOT, "tools", "exp", "librankpo_hip_r5pool.so")
     old = bind(old_path) if os.path.exists(old_path) else None
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream(dev).cuda_stream
-    print("| N | L | d | dtype | mode | bytes | old us | old TB/s | new us | new TB/s | of 8 TB/s | same result | what |")
+    print("| N | L | d | dtype | mode | bytes (cold) | old us | old TB/s | new us | new TB/s | of 8 TB/s | same result | what |")
     print("|---:|---:|---:|---|---|---:|---:|---:|---:|---:|---:|---|---|")
-    for N, L, d, dt, mode, what in SHAPES:
+    for N, L, d, dt, mode, what in (SHAPES if only is None else [SHAPES[only]]):
         g = torch.Generator(device=dev).manual_seed(N + L)
-        h = torch.randn((N, L, d), generator=g, device=dev).to(dt)
-        lens = torch.randint(1, L + 1, (N,), generator=g, device=dev)
-        mask = (torch.arange(L, device=dev)[None, :] < lens[:, None]).to(torch.int64)
+        es = torch.empty((), dtype=dt).element_size()
+        nbytes = (N * L * 8 if mode == "last" else 0) + 2 * N * d * es
+        # COLD data for every launch: the kernel's lines (mask rows + pooled rows + outputs) of consecutive launches come from NB
+        # different buffer sets that together exceed the 256 MB Infinity Cache, so the rate is HBM's, not the cache's
+        NB = max(2, min(16, -(-600 * 2 ** 20 // nbytes)))
+        hs, masks = [], []
+        for b in range(NB):
+            if mode == "last":
+                hs.append(torch.randn((N, L, d), generator=g, device=dev).to(dt) if b < 2 or N * L * d * es < 2 ** 31 else hs[b % 2])
+                lens = torch.randint(1, L + 1, (N,), generator=g, device=dev)
+                masks.append((torch.arange(L, device=dev)[None, :] < lens[:, None]).to(torch.int64))
+            else:                               # CLS: only row 0 of every sample is touched -> [N, 1, d] buffers, all distinct
+                hs.append(torch.randn((N, 1, d), generator=g, device=dev).to(dt))
+                masks.append(None)
         code = {torch.float32: 0, torch.bfloat16: 1, torch.float16: 2}[dt]
-        outs = {}
+        outs, turn = {}, {"new": 0, "old": 0}
 
         def call(lib, tag):
-            out = outs.setdefault(tag, (torch.empty((N, d), dtype=dt, device=dev), torch.empty((N,), dtype=torch.int32, device=dev),
-                                        torch.empty((N,), dtype=torch.float32, device=dev)))
-            rc = lib.rpo_pool_normalize_fwd(h.data_ptr(), h.stride(0), h.stride(1), mask.data_ptr() if mode == "last" else None, N, L, d,
-                                            code, 0 if mode == "last" else 1, 1, 1e-12, out[0].data_ptr(), out[1].data_ptr(),
-                                            out[2].data_ptr(), st)
+            b = turn[tag] % NB
+            turn[tag] += 1
+            h, mask = hs[b], masks[b]
+            out = outs.setdefault((tag, b), (torch.empty((N, d), dtype=dt, device=dev), torch.empty((N,), dtype=torch.int32, device=dev),
+                                             torch.empty((N,), dtype=torch.float32, device=dev)))
+            rc = lib.rpo_pool_normalize_fwd(h.data_ptr(), h.stride(0), h.stride(1), mask.data_ptr() if mode == "last" else None, N,
+                                            h.shape[1], d, code, 0 if mode == "last" else 1, 1, 1e-12, out[0].data_ptr(),
+                                            out[1].data_ptr(), out[2].data_ptr(), st)
             assert rc == 0, rc
         libs = [("new", new)] + ([("old", old)] if old else [])
         times = {t: [] for t, _ in libs}
-        for _ in range(5):
+        for _ in range(NB):
             for t, lib in libs:
                 call(lib, t)
         torch.cuda.synchronize()
@@ -73,12 +95,11 @@ def main():
                 times[t].append((e0, e1))
         torch.cuda.synchronize()
         med = {t: sorted(a.elapsed_time(b) for a, b in v)[len(v) // 2] * 1e3 / REPS for t, v in times.items()}
-        es = h.element_size()
-        nbytes = (N * L * 8 if mode == "last" else 0) + 2 * N * d * es
         same = "-"
         if old:
-            same = str(bool(torch.equal(outs["new"][1], outs["old"][1])
-                            and (outs["new"][0].float() - outs["old"][0].float()).abs().max().item() <= 2.0 ** -7))
+            same = str(all(bool(torch.equal(outs[("new", b)][1], outs[("old", b)][1])
+                                and (outs[("new", b)][0].float() - outs[("old", b)][0].float()).abs().max().item() <= 2.0 ** -7)
+                           for b in range(NB)))
         o_us = med.get("old")
         print(f"| {N} | {L} | {d} | {str(dt).split('.')[-1]} | {mode} | {nbytes} | {o_us and round(o_us, 2)} | "
               f"{o_us and round(nbytes / o_us / 1e6, 2)} | {med['new']:.2f} | {nbytes / med['new'] / 1e6:.2f} | "
