@@ -164,7 +164,7 @@ def _algo(name, a):
     if name == "rpo_transpose":
         rows, cols, dt = a[2], a[3], a[6]
         return 2 * rows * cols * _es(dt), 0
-    if name == "rpo_topk_merge":
+    if name in ("rpo_topk_merge", "rpo_topk_merge_split"):
         rows, cols, k, dt = a[2], a[3], a[5], a[6]
         return rows * cols * _es(dt) + 2 * rows * k * 12, rows * cols
     if name == "rpo_rankpo_fwd":

@@ -331,6 +331,13 @@ int rpo_lastq_attn_bwd(const void* q, int64_t q_stride, const void* k, const voi
  * --------------------------------------------------------------------------------------------- */
 int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype,
                    float* best_val, int64_t* best_idx, int first, rpo_stream_t stream);
+/* The same with `split` winner lists per score row: list r * split + s collects columns [s seg, (s + 1) seg) of row r, seg =
+ * ceil(cols / split) rounded up to whole 16-byte vectors; best_val / best_idx: [rows * split, k].  A search of a FEW query rows
+ * (256, the reference's faiss_search batch: utils.py:58-80) is one block per list: split = 4 fills the 256 CUs four times over
+ * where one list per row leaves each CU one block.  The caller merges the `split` lists of a row once, at the end of the search
+ * (value descending, ties by the smaller index: the same order).  split == 1 is rpo_topk_merge. */
+int rpo_topk_merge_split(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype, int split,
+                         float* best_val, int64_t* best_idx, int first, rpo_stream_t stream);
 
 #ifdef __cplusplus
 }

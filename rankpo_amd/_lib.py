@@ -59,6 +59,7 @@ SIGNATURES = {
     "rpo_sumsq_partial": (C.c_int, [_vp, _i64, _i32, _vp, _i32, _vp]),
     "rpo_swiglu_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),
     "rpo_topk_merge": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "rpo_topk_merge_split": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "rpo_swiglu_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "rpo_swiglu_bwd_t": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "rpo_transpose": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp]),

@@ -31,13 +31,13 @@ __device__ __forceinline__ float load_score<bf16_t>(const bf16_t* p) { return bf
 template <>
 __device__ __forceinline__ float load_score<f16_t>(const f16_t* p) { return (float)*p; }
 
-// sorts the 4096 (value, index) slots: best first
+// sorts the first n (a power of two, <= kTopkSlots) (value, index) slots: best first
 template <int NT>
-__device__ void bitonic_sort_desc(float* val, long long* idx, int tid) {
-    for (int size = 2; size <= kTopkSlots; size <<= 1) {
+__device__ void bitonic_sort_desc(float* val, long long* idx, int tid, int n = kTopkSlots) {
+    for (int size = 2; size <= n; size <<= 1) {
         for (int stride = size >> 1; stride > 0; stride >>= 1) {
             __syncthreads();
-            for (int t = tid; t < kTopkSlots / 2; t += NT) {
+            for (int t = tid; t < n / 2; t += NT) {
                 const int lo = 2 * t - (t & (stride - 1));       // index with bit `stride` clear
                 const int hi = lo + stride;
                 const bool up = (lo & size) == 0;                 // this run sorts best-first, the next one worst-first
@@ -57,13 +57,18 @@ __device__ void bitonic_sort_desc(float* val, long long* idx, int tid) {
 template <typename T>
 __global__ __launch_bounds__(kTopkThreads) void topk_merge_kernel(const T* __restrict__ scores, int64_t ld, int64_t cols,
                                                                   int64_t col0, int k, float* __restrict__ best_val,
-                                                                  long long* __restrict__ best_idx, int first) {
+                                                                  long long* __restrict__ best_idx, int first, int split, int64_t seg) {
     __shared__ float s_val[kTopkSlots];
     __shared__ long long s_idx[kTopkSlots];
     __shared__ int s_count;
     const int tid = threadIdx.x;
+    // split > 1: block = (score row, column segment): LIST blockIdx.x = row * split + s holds the winners of columns
+    // [s seg, (s + 1) seg) of row blockIdx.x / split (rpo_topk_merge_split); split == 1: one list per row
     const int64_t row = blockIdx.x;
-    const T* srow = scores + row * ld;
+    const int sgm = (int)(row % split);
+    const T* srow = scores + (row / split) * ld + sgm * seg;
+    col0 += sgm * seg;
+    cols = cols - sgm * seg < 0 ? 0 : (cols - sgm * seg < seg ? cols - sgm * seg : seg);
     // slots [0, k): winners so far; [kTopkMaxK, kTopkMaxK + count): candidates; everything else: (-inf, max index)
     for (int i = tid; i < kTopkSlots; i += kTopkThreads) {
         float v = -INFINITY;
@@ -111,26 +116,35 @@ __global__ __launch_bounds__(kTopkThreads) void topk_merge_kernel(const T* __res
     }
 }
 
-// ---- streaming path: 1024 threads per row, one 16-byte vector per thread and segment, kFastDepth segments in flight --
+// ---- streaming path: 1024 threads per list, one 16-byte vector per thread and segment, kFastDepth segments in flight --------
 // Requires 16-byte aligned rows (ld and the chunk base multiples of the vector length).  A segment is 1024 vectors
-// (4096 f32 / 8192 bf16 columns); candidates are appended under the same filter, a re-selection runs whenever the list is
-// more than half full, and a segment that overflows the list (only possible while the k-th winner is still weak: the first
-// columns of the first chunk) is replayed from its registers in quarters with a re-selection after each.
+// (4096 f32 / 8192 bf16 columns).  Round 6 (the search of bench.py --workload encode spent 2.9 of its 6.7 ms here at 0.7 TB/s):
+// the kernel was bound by its BARRIERS, not by memory -- two per segment plus a 78-stage bitonic sort of all 4096 slots per
+// re-selection, at least one per call.  Now: the candidates sit right behind the k winners (slots [k, k + count)), a re-selection
+// sorts only the next power of two of k + count slots (k = 100 with a few dozen candidates: 128 slots, 28 stages), and a GROUP of
+// kFastDepth segments is filtered under one threshold between ONE pair of barriers.  A group that overflows the list (only while
+// the k-th winner is still weak: the first columns of the first chunk) is replayed from its registers, segment by segment in
+// quarters, with a re-selection after each.
 constexpr int kFastThreads = 1024;
 constexpr int kFastDepth = 4;
 
 template <typename T>
 __global__ __launch_bounds__(kFastThreads) void topk_merge_fast_kernel(const T* __restrict__ scores, int64_t ld, int64_t cols,
                                                                        int64_t col0, int k, float* __restrict__ best_val,
-                                                                       long long* __restrict__ best_idx, int first) {
+                                                                       long long* __restrict__ best_idx, int first, int split,
+                                                                       int64_t seg) {
     constexpr int V = Elem<T>::kVec;
     constexpr int SEG = kFastThreads * V;
     __shared__ float s_val[kTopkSlots];
     __shared__ long long s_idx[kTopkSlots];
     __shared__ int s_count;
     const int tid = threadIdx.x;
-    const int64_t row = blockIdx.x;
-    const T* srow = scores + row * ld;
+    const int64_t row = blockIdx.x;                        // the LIST: (score row, column segment), see topk_merge_kernel
+    const int sgm = (int)(row % split);
+    const T* srow = scores + (row / split) * ld + sgm * seg;
+    col0 += sgm * seg;
+    cols = cols - sgm * seg < 0 ? 0 : (cols - sgm * seg < seg ? cols - sgm * seg : seg);
+    // slots [0, k): winners so far; [k, k + count): candidates; everything behind: (-inf, max index) -- an invariant of every step
     for (int i = tid; i < kTopkSlots; i += kFastThreads) {
         float v = -INFINITY;
         long long ix = 0x7fffffffffffffffLL;
@@ -145,9 +159,13 @@ __global__ __launch_bounds__(kFastThreads) void topk_merge_fast_kernel(const T* 
     __syncthreads();
     float tv = s_val[k - 1];
     long long ti = s_idx[k - 1];
-    auto reselect = [&]() {                                   // winners + candidates -> k winners, list emptied
-        bitonic_sort_desc<kFastThreads>(s_val, s_idx, tid);
-        for (int i = k + tid; i < kTopkSlots; i += kFastThreads) {
+    const int cap = kTopkSlots - k < kTopkCap ? kTopkSlots - k : kTopkCap;      // candidates the list takes
+    auto reselect = [&]() {                                   // winners + candidates -> k winners, list emptied (block-uniform call)
+        const int count = s_count < cap ? s_count : cap;
+        int n = 64;
+        while (n < k + count) n <<= 1;
+        bitonic_sort_desc<kFastThreads>(s_val, s_idx, tid, n);
+        for (int i = k + tid; i < n; i += kFastThreads) {      // drop everything past the k-th
             s_val[i] = -INFINITY;
             s_idx[i] = 0x7fffffffffffffffLL;
         }
@@ -155,6 +173,15 @@ __global__ __launch_bounds__(kFastThreads) void topk_merge_fast_kernel(const T* 
         __syncthreads();
         tv = s_val[k - 1];
         ti = s_idx[k - 1];
+    };
+    auto offer = [&](float v, long long ix) {                  // append (v, ix) if it beats the k-th winner; false: the list is full
+        if (before(v, ix, tv, ti)) {
+            const int pos = atomicAdd(&s_count, 1);
+            if (pos < cap) {
+                s_val[k + pos] = v;
+                s_idx[k + pos] = ix;
+            }
+        }
     };
     const int64_t nseg = (cols + SEG - 1) / SEG;
     Vec16<T> reg[kFastDepth];
@@ -171,54 +198,62 @@ __global__ __launch_bounds__(kFastThreads) void topk_merge_fast_kernel(const T* 
 #pragma unroll
         for (int u = 0; u < kFastDepth; ++u)
             if (s0 + u < nseg) fetch(s0 + u, reg[u]);
+        // Bootstrap: while the list holds fewer than k winners (k-th = -inf: the first columns of the first chunk) EVERYTHING passes
+        // the filter and a whole group would overflow the list 16 times over.  The first quarter of the group's first segment
+        // (<= 256 V <= cap elements) goes in alone and is settled; the k-th winner of those already turns away ~95 % of what
+        // follows (k = 100), so the rest of the group takes the common path.  (Before: the group overflowed and was replayed in 16
+        // quarters with a full 4096-slot sort each: 0.5 ms for the first chunk of a search against 0.09 for the others.)
+        const bool boot = tv == -INFINITY && ti == 0x7fffffffffffffffLL;      // block-uniform
+        if (boot) {
+            if (tid < 256) {
+                const int64_t c = s0 * SEG + (int64_t)tid * V;
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    if (c + j < cols) offer(reg[0].v[j], col0 + c + j);
+            }
+            __syncthreads();
+            reselect();
+        }
+        const int before_count = s_count;                     // uniform: read after the barrier that ended the last step
+        __syncthreads();
 #pragma unroll
         for (int u = 0; u < kFastDepth; ++u) {
             if (s0 + u >= nseg) break;
+            if (boot && u == 0 && tid < 256) continue;        // already in
             const int64_t c = (s0 + u) * SEG + (int64_t)tid * V;
-            const int before_count = s_count;                 // uniform: read after the barrier that ended the last step
-            __syncthreads();
 #pragma unroll
-            for (int j = 0; j < V; ++j) {
-                const long long ix = col0 + c + j;
-                if (c + j < cols && before(reg[u].v[j], ix, tv, ti)) {
-                    const int pos = atomicAdd(&s_count, 1);
-                    if (pos < kTopkCap) {
-                        s_val[kTopkMaxK + pos] = reg[u].v[j];
-                        s_idx[kTopkMaxK + pos] = ix;
-                    }
-                }
+            for (int j = 0; j < V; ++j)
+                if (c + j < cols) offer(reg[u].v[j], col0 + c + j);
+        }
+        __syncthreads();
+        const int count = s_count;
+        if (count > cap) {
+            // overflow: drop this group's appends, settle what was there, replay the group segment by segment in quarters
+            __syncthreads();
+            if (tid == 0) s_count = before_count;
+            __syncthreads();
+            for (int i = k + before_count + tid; i < k + cap; i += kFastThreads) {
+                s_val[i] = -INFINITY;
+                s_idx[i] = 0x7fffffffffffffffLL;
             }
             __syncthreads();
-            int count = s_count;
-            if (count > kTopkCap) {
-                // overflow: drop this segment's appends, settle what was there, replay the segment in quarters
-                __syncthreads();
-                if (tid == 0) s_count = before_count;
-                __syncthreads();
-                for (int i = kTopkMaxK + before_count + tid; i < kTopkMaxK + kTopkCap; i += kFastThreads) {
-                    s_val[i] = -INFINITY;
-                    s_idx[i] = 0x7fffffffffffffffLL;
-                }
-                __syncthreads();
-                reselect();
-                for (int part = 0; part < 4; ++part) {
-                    if ((tid >> 8) == part) {
+            reselect();
 #pragma unroll
-                        for (int j = 0; j < V; ++j) {
-                            const long long ix = col0 + c + j;
-                            if (c + j < cols && before(reg[u].v[j], ix, tv, ti)) {
-                                const int pos = atomicAdd(&s_count, 1);       // <= 256 V <= kTopkCap
-                                s_val[kTopkMaxK + pos] = reg[u].v[j];
-                                s_idx[kTopkMaxK + pos] = ix;
-                            }
-                        }
+            for (int u = 0; u < kFastDepth; ++u) {
+                if (s0 + u >= nseg) break;
+                const int64_t c = (s0 + u) * SEG + (int64_t)tid * V;
+                for (int part = 0; part < 4; ++part) {
+                    if ((tid >> 8) == part && !(boot && u == 0 && part == 0)) {     // (the bootstrap quarter is in already)
+#pragma unroll
+                        for (int j = 0; j < V; ++j)
+                            if (c + j < cols) offer(reg[u].v[j], col0 + c + j);      // <= 256 V <= cap appends
                     }
                     __syncthreads();
                     if (s_count > 0) reselect();
                 }
-            } else if (count > kTopkCap / 2) {
-                reselect();
             }
+        } else if (count > cap / 2) {
+            reselect();
         }
     }
     __syncthreads();
@@ -231,34 +266,47 @@ __global__ __launch_bounds__(kFastThreads) void topk_merge_fast_kernel(const T* 
 
 }  // namespace
 
-extern "C" int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype,
-                              float* best_val, int64_t* best_idx, int first, rpo_stream_t stream) {
-    if (!scores || !best_val || !best_idx || rows <= 0 || cols <= 0 || ld < cols || k <= 0 || col0 < 0)
+static int topk_launch(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype, int split,
+                       float* best_val, int64_t* best_idx, int first, rpo_stream_t stream) {
+    if (!scores || !best_val || !best_idx || rows <= 0 || cols <= 0 || ld < cols || k <= 0 || col0 < 0 || split <= 0)
         return RPO_ERR_INVALID_ARG;
-    if (k > kTopkMaxK || rows > INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    if (k > kTopkMaxK || rows * split > INT32_MAX) return RPO_ERR_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     if (!rpo_dtype_ok(dtype)) return RPO_ERR_INVALID_ARG;
     const int V = 16 / rpo_elem_size(dtype);
-    if (ld % V == 0 && rpo_aligned16(scores) && cols >= 4096) {
+    // a list's columns: ceil(cols / split) rounded up to whole 16-byte vectors, so that every segment starts vector-aligned
+    const int64_t seg = split == 1 ? cols : rpo_cdiv(rpo_cdiv(cols, split), V) * V;
+    const dim3 grid((unsigned)(rows * split));
+    if (ld % V == 0 && rpo_aligned16(scores) && seg >= 4096) {
         if (dtype == RPO_DT_F32)
-            RPO_LAUNCH(topk_merge_fast_kernel<float>, dim3((unsigned)rows), dim3(kFastThreads), 0, st, (const float*)scores,
-                       ld, cols, col0, k, best_val, (long long*)best_idx, first);
+            RPO_LAUNCH(topk_merge_fast_kernel<float>, grid, dim3(kFastThreads), 0, st, (const float*)scores,
+                       ld, cols, col0, k, best_val, (long long*)best_idx, first, split, seg);
         else if (dtype == RPO_DT_F16)
-            RPO_LAUNCH(topk_merge_fast_kernel<f16_t>, dim3((unsigned)rows), dim3(kFastThreads), 0, st,
-                       (const f16_t*)scores, ld, cols, col0, k, best_val, (long long*)best_idx, first);
+            RPO_LAUNCH(topk_merge_fast_kernel<f16_t>, grid, dim3(kFastThreads), 0, st,
+                       (const f16_t*)scores, ld, cols, col0, k, best_val, (long long*)best_idx, first, split, seg);
         else
-            RPO_LAUNCH(topk_merge_fast_kernel<bf16_t>, dim3((unsigned)rows), dim3(kFastThreads), 0, st,
-                       (const bf16_t*)scores, ld, cols, col0, k, best_val, (long long*)best_idx, first);
+            RPO_LAUNCH(topk_merge_fast_kernel<bf16_t>, grid, dim3(kFastThreads), 0, st,
+                       (const bf16_t*)scores, ld, cols, col0, k, best_val, (long long*)best_idx, first, split, seg);
         return rpo_launch_status();
     }
     if (dtype == RPO_DT_F32)
-        RPO_LAUNCH(topk_merge_kernel<float>, dim3((unsigned)rows), dim3(kTopkThreads), 0, st, (const float*)scores, ld, cols,
-                   col0, k, best_val, (long long*)best_idx, first);
+        RPO_LAUNCH(topk_merge_kernel<float>, grid, dim3(kTopkThreads), 0, st, (const float*)scores, ld, cols,
+                   col0, k, best_val, (long long*)best_idx, first, split, seg);
     else if (dtype == RPO_DT_BF16)
-        RPO_LAUNCH(topk_merge_kernel<bf16_t>, dim3((unsigned)rows), dim3(kTopkThreads), 0, st, (const bf16_t*)scores, ld,
-                   cols, col0, k, best_val, (long long*)best_idx, first);
+        RPO_LAUNCH(topk_merge_kernel<bf16_t>, grid, dim3(kTopkThreads), 0, st, (const bf16_t*)scores, ld,
+                   cols, col0, k, best_val, (long long*)best_idx, first, split, seg);
     else
-        RPO_LAUNCH(topk_merge_kernel<f16_t>, dim3((unsigned)rows), dim3(kTopkThreads), 0, st, (const f16_t*)scores, ld,
-                   cols, col0, k, best_val, (long long*)best_idx, first);
+        RPO_LAUNCH(topk_merge_kernel<f16_t>, grid, dim3(kTopkThreads), 0, st, (const f16_t*)scores, ld,
+                   cols, col0, k, best_val, (long long*)best_idx, first, split, seg);
     return rpo_launch_status();
+}
+
+extern "C" int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype,
+                              float* best_val, int64_t* best_idx, int first, rpo_stream_t stream) {
+    return topk_launch(scores, ld, rows, cols, col0, k, dtype, 1, best_val, best_idx, first, stream);
+}
+
+extern "C" int rpo_topk_merge_split(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype,
+                                    int split, float* best_val, int64_t* best_idx, int first, rpo_stream_t stream) {
+    return topk_launch(scores, ld, rows, cols, col0, k, dtype, split, best_val, best_idx, first, stream);
 }

@@ -1112,31 +1112,50 @@ def last_query_attn(q, kv, cu, num_kv_heads: int, head_dim: int, scale: float):
 TOPK_MAX_K = 1024
 
 
-def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100):
-    """Merges the top-k of `scores` ([rows, cols] f32 / bf16, the chunk of corpus rows [col0, col0 + cols)) into the winners so
-    far (`best_val` f32 [rows, k], `best_idx` int64 [rows, k]; None: start).  Order: value descending, ties by the smaller
-    corpus index.  Returns (best_val, best_idx), updated in place when given."""
+def topk_merge(scores, col0: int, best_val=None, best_idx=None, k: int = 100, split: int = 1):
+    """Merges the top-k of `scores` ([rows, cols] f32 / bf16 / fp16, the chunk of corpus rows [col0, col0 + cols)) into the winners
+    so far (`best_val` f32 [rows * split, k], `best_idx` int64 [rows * split, k]; None: start).  Order: value descending, ties by
+    the smaller corpus index.  split > 1: `split` winner lists per score row, list r * split + s over a column segment of the
+    chunk (rpo_topk_merge_split: more blocks than query rows); `topk_finish` merges them at the end of the search.  Returns
+    (best_val, best_idx), updated in place when given."""
     _need_gpu(scores)
     lib = _lib.load()
     if scores.dim() != 2 or scores.stride(1) != 1:
         raise ValueError("topk_merge: scores must be [rows, cols] with contiguous columns")
     if not 0 < k <= TOPK_MAX_K:
         raise ValueError(f"topk_merge: k must be in 1..{TOPK_MAX_K}")
+    if split < 1:
+        raise ValueError("topk_merge: split >= 1")
     rows, cols = scores.shape
     first = best_val is None
     if first:
-        best_val = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
-        best_idx = torch.empty((rows, k), dtype=torch.int64, device=scores.device)
-    elif best_val.shape != (rows, k) or best_idx.shape != (rows, k) or not best_val.is_contiguous() \
+        best_val = torch.empty((rows * split, k), dtype=torch.float32, device=scores.device)
+        best_idx = torch.empty((rows * split, k), dtype=torch.int64, device=scores.device)
+    elif best_val.shape != (rows * split, k) or best_idx.shape != (rows * split, k) or not best_val.is_contiguous() \
             or not best_idx.is_contiguous() or best_val.dtype != torch.float32 or best_idx.dtype != torch.int64:
-        raise ValueError("topk_merge: best_val / best_idx must be contiguous f32 / int64 [rows, k]")
+        raise ValueError("topk_merge: best_val / best_idx must be contiguous f32 / int64 [rows * split, k]")
     with torch.cuda.device(scores.device):
-        check(lib.rpo_topk_merge(scores.data_ptr(), scores.stride(0), rows, cols, int(col0), k, _dt(scores),
-                                 best_val.data_ptr(), best_idx.data_ptr(), int(first), _stream(scores)), "rpo_topk_merge")
+        check(lib.rpo_topk_merge_split(scores.data_ptr(), scores.stride(0), rows, cols, int(col0), k, _dt(scores), int(split),
+                                       best_val.data_ptr(), best_idx.data_ptr(), int(first), _stream(scores)),
+              "rpo_topk_merge_split")
     return best_val, best_idx
 
 
-__all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
+def topk_finish(best_val, best_idx, split: int):
+    """[rows * split, k] winner lists -> [rows, k]: the k best of a row's `split` lists, value descending, ties by the smaller
+    corpus index (the lists are disjoint column ranges, so this IS the row's top-k).  rows x split x k elements: two stable sorts."""
+    if split == 1:
+        return best_val, best_idx
+    k = best_val.shape[1]
+    v = best_val.view(-1, split * k)
+    i = best_idx.view(-1, split * k)
+    o = torch.sort(i, dim=1, stable=True).indices                    # index ascending ...
+    v, i = v.gather(1, o), i.gather(1, o)
+    o = torch.sort(v, dim=1, descending=True, stable=True).indices   # ... then value descending, stable: ties keep the smaller index first
+    return v.gather(1, o)[:, :k].contiguous(), i.gather(1, o)[:, :k].contiguous()
+
+
+__all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "topk_finish", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
            "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "rope_flash_attn_varlen_qkv_fwd", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table", "recomputing",
            "attn_key_tile_table"]

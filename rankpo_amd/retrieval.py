@@ -20,11 +20,12 @@ from . import ops
 class FlatIPIndex:
     """Stands where the reference builds `faiss.IndexFlatIP` (utils.py:38-51): keeps the corpus embeddings on the GPU."""
 
-    def __init__(self, embeddings, device="cuda:0", dtype=torch.float32, chunk_rows: int = 262144):
+    def __init__(self, embeddings, device="cuda:0", dtype=torch.float32, chunk_rows: int = 262144, split=None):
         e = torch.as_tensor(np.asarray(embeddings, dtype=np.float32) if not torch.is_tensor(embeddings) else embeddings)
         self.emb = e.to(device=device, dtype=dtype).contiguous()
         self.ntotal = self.emb.shape[0]
         self.chunk_rows = chunk_rows
+        self.split = split                  # winner lists per query row in the selection kernel; None: by the batch size (search)
 
     def search(self, queries, k: int):
         """(scores f32 [nq, k], corpus indices int64 [nq, k]), best first; k is clamped to the corpus size."""
@@ -33,11 +34,16 @@ class FlatIPIndex:
         k = min(k, self.ntotal)
         if k > ops.TOPK_MAX_K:
             raise ValueError(f"FlatIPIndex.search: k <= {ops.TOPK_MAX_K}")
+        # `split` winner lists per query row (rpo_topk_merge_split) would put more selection blocks on the chip than the few hundred
+        # queries of a batch (the reference searches 256 at a time, utils.py:58-80) -- measured, it LOSES: every list pays its own
+        # bootstrap and its own re-selections (10^6 x 2048 corpus, 4 x 256 queries, k = 100: 8.6 ms with 4 lists per row against
+        # 5.65 with one, gpurun_out/r6_D).  One list per row unless the caller says otherwise.
+        split = 1 if self.split is None else int(self.split)
         top = idx = None
         for c0 in range(0, self.ntotal, self.chunk_rows):
             scores = ops.similarity(q, self.emb[c0:c0 + self.chunk_rows])      # [nq, chunk]  (HIP MFMA kernel)
-            top, idx = ops.topk_merge(scores, c0, top, idx, k)                  # HIP selection kernel
-        return top, idx
+            top, idx = ops.topk_merge(scores, c0, top, idx, k, split=split)     # HIP selection kernel
+        return ops.topk_finish(top, idx, split)
 
 
 def create_faiss_index(embeddings, device="cuda:0"):

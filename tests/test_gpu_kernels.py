@@ -638,3 +638,37 @@ def test_flat_index_search_chunked_equals_unchunked():
     mask = np.ones_like(full, dtype=bool)
     np.put_along_axis(mask, ri, False, 1)
     assert (full[mask].reshape(33, -1).max(1) <= rv[:, -1]).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,cols,k,chunk,split", [(5, 70000, 100, 32768, 4), (3, 70000, 1024, 70000, 2), (7, 6000, 300, 1500, 4),
+                                                     (2, 40001, 64, 20000, 8), (4, 9, 4, 9, 2), (256, 65536, 100, 65536, 4)])
+def test_topk_merge_split_lists_equal_one_list(rows, cols, k, chunk, split, dtype):
+    """rpo_topk_merge_split + ops.topk_finish: `split` winner lists per score row over column segments of every chunk (ragged last
+    segments and last chunks, segments shorter than k, quantised scores with ~hundreds of ties per value) merge to EXACTLY the
+    stable-argsort winners of the oracle -- values and corpus indices."""
+    from oracle.scoring_ref import topk_ref
+    from rankpo_amd import ops
+    rs = np.random.RandomState(rows + cols + split)
+    s = rs.randn(rows, cols).astype(np.float32) if rows % 2 else rs.randint(0, 40, size=(rows, cols)).astype(np.float32)
+    st = torch.tensor(s, device=DEV).to(dtype)
+    bv = bi = None
+    for c0 in range(0, cols, chunk):
+        bv, bi = ops.topk_merge(st[:, c0:c0 + chunk], c0, bv, bi, k, split=split)
+    assert bv.shape == (rows * split, k)
+    fv, fi = ops.topk_finish(bv, bi, split)
+    kk = min(k, cols)
+    rv, ri = topk_ref(st.float().cpu().numpy(), kk)
+    assert np.array_equal(fi.cpu().numpy()[:, :kk], ri)
+    assert np.array_equal(fv.cpu().numpy()[:, :kk], rv)
+
+
+def test_flat_index_search_with_split_lists_returns_the_same():
+    """FlatIPIndex(split=4) == FlatIPIndex() (one list per query row, the default: the split form measured slower), bf16 corpus."""
+    from rankpo_amd.retrieval import FlatIPIndex
+    g = torch.Generator(device=DEV).manual_seed(3)
+    corpus = torch.nn.functional.normalize(torch.randn(300_000, 128, generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    q = corpus[torch.randint(0, 300_000, (64,), generator=g, device=DEV)]
+    sv, si = FlatIPIndex(corpus, device=DEV, dtype=torch.bfloat16, chunk_rows=131072, split=4).search(q, 100)
+    bv, bi = FlatIPIndex(corpus, device=DEV, dtype=torch.bfloat16, chunk_rows=131072).search(q, 100)
+    assert torch.equal(si, bi) and torch.equal(sv, bv)
