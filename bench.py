@@ -1527,6 +1527,10 @@ def main():
                        "tokens_per_step_per_gpu": {"padded": tok_pad, "real_mean": int(sum(tok_real) / len(tok_real))},
                        "weights": "random init (seed 0)",
                        "library": os.path.relpath(_lib.LIB_PATH, ROOT),
+                       "timed_region": ("every call of a hand-written entry point is bracketed by two HIP events on its launch stream INSIDE "
+                                        "the timed steps (that is where `roofline` and `kernels` come from): `value` includes their cost "
+                                        "(--no-kernel-timing: without them)") if not args.no_kernel_timing else
+                                       "no per-call HIP events (--no-kernel-timing)",
                        "memory_guard": mem_guard,
                        "dropout": {"hidden": float(getattr(cfg, "hidden_dropout_prob", 0.0) or 0.0),
                                    "attention": float(getattr(cfg, "attention_probs_dropout_prob", getattr(cfg, "attention_dropout", 0.0)) or 0.0)}},
