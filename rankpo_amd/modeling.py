@@ -276,12 +276,17 @@ class ModelForInference(nn.Module):
         max_length: int = 512,
         convert_to_numpy: bool = True,
         description: str = "Encoding",
+        bucket_by_length: bool = False,
     ) -> Union[np.ndarray, torch.Tensor]:
         """modeling.py:473-554.  Differences that do not change results: no per-batch `empty_cache()` (a device
         sync per batch, modeling.py:543-544); numpy conversion happens once at the end; batch i + 1 is tokenised (a worker
         thread; the fast tokenizers release the GIL) while batch i runs; right-padded Llama batches are packed on the HOST from
         the tokenizer's own CPU tensors and only the real tokens are uploaded, so that no batch waits for the one before it
-        (`LlamaEncoder.pooled_last_token_multi`: no device sync)."""
+        (`LlamaEncoder.pooled_last_token_multi`: no device sync).
+        `bucket_by_length` (an addition, default off = the reference's batching): batches are formed over the sentences sorted by
+        text length, longest first, and the rows are put back in input order at the end -- padded encoders (BERT / XLM-R, CLS
+        pooling) then pad every batch to ITS longest row instead of the corpus' (the packed Llama path computes no pad token
+        either way).  Same rows up to the round-off of other GEMM shapes."""
         self.model.eval()
         input_was_string = False
         if isinstance(sentences, str):
@@ -291,6 +296,10 @@ class ModelForInference(nn.Module):
             raise ValueError("Input items should be text.")
         mode = "last" if "Llama" in self.config.architectures[0] else "cls"
         all_embeddings = []
+        order = None
+        if bucket_by_length and len(sentences) > batch_size:
+            order = sorted(range(len(sentences)), key=lambda i: -len(sentences[i]))
+            sentences = [sentences[i] for i in order]
         starts = list(range(0, len(sentences), batch_size))
 
         def tokenise(i):
@@ -324,6 +333,10 @@ class ModelForInference(nn.Module):
             if pool:
                 pool.shutdown(wait=True, cancel_futures=True)
         out = torch.cat(all_embeddings, dim=0)
+        if order is not None:                       # back to the caller's order
+            inv = torch.empty(len(order), dtype=torch.int64)
+            inv[torch.tensor(order)] = torch.arange(len(order))
+            out = out.index_select(0, inv.to(out.device))
         if convert_to_numpy:
             if out.dtype == torch.bfloat16:      # modeling.py:537-538
                 out = out.float()

@@ -308,3 +308,16 @@ def test_model_for_inference_fp16_returns_float16():
     ref = torch.cat([E.embed(w32, cfg.to_dict(), CharTok()(texts[i:i + 4], max_length=96)).detach() for i in (0, 4, 8)]).numpy()
     assert np.abs(out.astype(np.float64) - ref).max() < 3e-3          # two fp16 BERT blocks + one rounding of the unit row
     assert np.abs(np.linalg.norm(out.astype(np.float64), axis=1) - 1).max() < 2 * ULP16
+    # bucket_by_length: batches over the length-sorted sentences, rows back in input order: the same rows (other padded widths)
+    seen = []
+    real = inf.tokenizer.__call__
+
+    class Spy(CharTok):
+        def __call__(self, texts, **kw):
+            o = CharTok.__call__(self, texts, **kw)
+            seen.append(o["input_ids"].shape[1])
+            return o
+    inf.tokenizer = Spy()
+    out_b = inf.encode(texts, batch_size=4, max_length=96, bucket_by_length=True)
+    assert seen == sorted(seen, reverse=True) and len(seen) == 3          # longest batch first, padded to its own longest row
+    assert np.abs(out_b.astype(np.float64) - out.astype(np.float64)).max() < 4 * ULP16
