@@ -322,3 +322,42 @@ def test_real_width_and_length_parity(arch):
     assert seen["qkv_T"] == [(tot + 255) // 256 * 256] and seen["last_rows"] == 1, (seen, tot)
     assert rep["pass"], rep
     assert rep["fast_path"]["cos_max_err"] < 2e-2
+
+
+def test_gradient_checkpointing_enable_plans_from_the_measured_hbm(monkeypatch):
+    """`ModelForTraining.gradient_checkpointing_enable()` with no argument (the reference's --gradient_checkpointing flag,
+    scripts/train/run_contrastive.sh:39) resolves to rankpo_amd.memory's plan at the first training forward: a small model on a
+    288 GB card keeps every block (the plan is recorded with the padded token count and the measured usable HBM), results equal
+    the un-checkpointed run bit for bit; with the usable HBM pretended small the same call checkpoints blocks, and a longer batch
+    re-plans only towards more checkpointing."""
+    import rankpo_amd
+    from rankpo_amd import encoder as PE, memory as M
+    cfg, enc, model = _model(PE, rankpo_amd, seed=5, hd=64)
+    batch, _ = _batch()
+    gb = {k: {kk: vv.to(DEV) for kk, vv in v.items()} for k, v in batch.items()}
+
+    def step():
+        enc.zero_grad()
+        out = model(**gb)
+        out.loss.backward()
+        return out.loss.item(), {n: p.grad.detach().clone() for n, p in enc.named_parameters()}
+    l0, g0 = step()
+    model.gradient_checkpointing_enable()
+    assert enc.checkpoint_layers == "auto" and enc.memory_plan is None
+    l1, g1 = step()
+    plan = enc.memory_plan
+    tok_pad = sum(v["input_ids"].numel() for v in batch.values())
+    assert plan is not None and plan.checkpoint_blocks == 0 and plan.tokens == M.pad_tokens(tok_pad)
+    assert plan.hbm_usable > 200 * 2 ** 30 and 0 < plan.modelled_peak < 0.85 * plan.hbm_usable
+    assert l1 == l0 and all(torch.equal(g1[n], g0[n]) for n in g0)
+    # the same call where HBM is scarce: pretend 1/700 of the card (~0.44 GB: states 0.18 + block in flight 0.14: no room for kept blocks)
+    real = M.usable_hbm
+    monkeypatch.setattr(M, "usable_hbm", lambda *a, **kw: real(*a, **kw) // 700)
+    model.gradient_checkpointing_enable()
+    l2, g2 = step()
+    k_small = enc.memory_plan.checkpoint_blocks
+    assert 0 < k_small <= cfg.num_hidden_layers
+    assert abs(l2 - l0) < 2e-3 * max(1.0, abs(l0))                         # checkpointed blocks keep x + delta rounded to bf16
+    # a longer batch: re-planned, never fewer checkpointed blocks than before
+    enc._checkpointed_blocks(8 * enc.memory_plan.tokens)
+    assert enc.memory_plan.checkpoint_blocks >= k_small and enc.memory_plan.tokens == 8 * M.pad_tokens(tok_pad)
