@@ -902,7 +902,7 @@ constexpr float kFwDefer = RPO_FW_DEFER;
 // computes them in its prologue and writes them for the dK/dV kernel (round 1: a separate fa_delta_kernel, 0.32 ms per call).
 // (Tried and dropped: block-resident Q fragments pre-multiplied by scale log2(e) and re-rounded to bf16, so that the chain's
 // result is the exponent itself -- one multiplication per score less, backward 7.45 -> 7.34 ms, but the extra rounding of Q
-// doubles the error of dQ at a logit spread of 3: 0.0066 instead of 0.0033 relative L2, `tools/fa_accuracy.py`.)
+// doubles the error of dQ at a logit spread of 3: 0.0066 instead of 0.0033 relative L2, `tools/fa_accuracy.py` (round 2; git history).)
 
 // K / V tiles: the same LDS-DMA ring as the forward kernel.
 constexpr int kDqTile = kKvTile;

@@ -224,7 +224,7 @@ inline unsigned ew_grid(int64_t nvec) { return (unsigned)rpo_cdiv(nvec, kEwThrea
 // is HBM-bound.  64 x 64 tile through LDS: 16-byte global loads along the input rows, 2-byte (bf16) / 4-byte (f32) LDS reads
 // down the tile columns, 16-byte global stores along the output rows: whole 128-byte lines on both sides.
 // (Round 3, measured and dropped: a 128 x 128 tile -- 256-byte pieces on both sides -- moved 5.03 TB/s on [151552, 2048] against
-// 5.83 for this one, 5.49 against 5.79 on [151552, 4096]: tools/transpose_ab.py.)
+// 5.83 for this one, 5.49 against 5.79 on [151552, 4096]: tools/transpose_ab.py (round 3; git history).)
 // ------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ in, T* __restrict__ out, int64_t R, int64_t C,
@@ -638,7 +638,7 @@ extern "C" int rpo_add_rmsnorm_fwd(const void* x, const void* delta, const void*
     hipStream_t st = (hipStream_t)stream;
     // (round 3, measured and dropped: ONE row per wave, as many waves as rows -- the forward has no per-wave output that would
     // bound its wave count -- moved 5.71 TB/s at d = 2048 against 5.98 for this capped loop, 5.06 against 4.96 at d = 4096:
-    // tools/norm_ab.py)
+    // tools/norm_ab.py (round 4; git history))
     const int nw = norm_waves(rows, RPO_NORM_FWD_CAP);       // (the forward writes no per-wave partials: its count is its own)
     if (dtype == RPO_DT_BF16) return launch_norm_fwd<bf16_t>(x, delta, weight, eps, x_out, y_out, rstd_out, rows, d, nw, st);
     if (dtype == RPO_DT_F32) return launch_norm_fwd<float>(x, delta, weight, eps, x_out, y_out, rstd_out, rows, d, nw, st);

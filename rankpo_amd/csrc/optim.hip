@@ -22,7 +22,7 @@ __global__ __launch_bounds__(kOptThreads) void adamw_kernel(T* __restrict__ para
     const float decay = 1.0f - lr * wd;
     // ONE group of 4 elements per thread (16-byte f32 accesses, 8-byte bf16 accesses), block b owns the contiguous
     // groups [256 b, 256 b + 256), streaming loads / stores: 5.4 ms = 6.4 TB/s for 1.236 G parameters in
-    // tools/exp/exp_adamw.hip, vs 6.1 ms for a 2048-block grid-stride loop and 14.9 ms (!) for 8 elements per thread
+    // tools/exp/exp_adamw.hip (round 1; git history), vs 6.1 ms for a 2048-block grid-stride loop and 14.9 ms (!) for 8 elements per thread
     // (two 16-byte f32 accesses per lane at a 32-byte lane stride touch every 128-byte line twice).
     const int64_t i = (int64_t)blockIdx.x * kOptThreads + threadIdx.x;
     if (i >= (n >> 2)) return;
