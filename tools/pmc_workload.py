@@ -112,7 +112,8 @@ pmask = (torch.arange(Lp)[None] < plen[:, None]).to(torch.int64).to(DEV)
 pout = torch.empty(Np, d, device=DEV, dtype=bf)
 pidx = torch.empty(Np, device=DEV, dtype=torch.int32)
 pnorm = torch.empty(Np, device=DEV)
-run("rpo_pool_normalize_fwd", ["pool_normalize_fwd_kernel"], f"N = {Np}, L = {Lp}, d = {d} bf16, int64 mask, last-token + normalize",
+run("rpo_pool_normalize_fwd", ["pool_normalize_fwd_wave_kernel"],        # (round 6: one wave per sample at this shape)
+    f"N = {Np}, L = {Lp}, d = {d} bf16, int64 mask, last-token + normalize",
     Np * Lp * 8 + 2 * Np * d * 2 + 8 * Np,
     lambda: lib.rpo_pool_normalize_fwd(hp.data_ptr(), hp.stride(0), hp.stride(1), pmask.data_ptr(), Np, Lp, d, 1, 0, 1, 1e-12,
                                        pout.data_ptr(), pidx.data_ptr(), pnorm.data_ptr(), st()))
