@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA peak
 MFMA_F32_PEAK_TFLOPS = 157.3
 INFINITY_CACHE_BYTES = 256 * 2 ** 20   # MI355X_MICROARCH.md: 256 MB memory-side cache in front of HBM
-PMC_FILE = "profiles/r05_pmc_traffic.json"
+PMC_FILE = "profiles/r06_pmc_traffic.json"
 
 # MFMA products an entry point EXECUTES per algorithmic product (recomputation it does by design), so that the line shows both
 # rates: what the matrix pipe does and what the caller gets.
