@@ -1067,7 +1067,7 @@ def inference_main(args, device, wd, rank, arch):
     small = arch != "llama-3.2-1b"
     wd.phase("encode()", 1500)
     enc_block = BI.encode_block(cfg, enc, device, note, reps=max(1, args.steps // 2), n_query=128 if small else 256,
-                                n_passage=128 if small else 256, oracle=not args.no_cpu_baseline)
+                                n_passage=128 if small else 256, oracle=not args.no_cpu_baseline, cores=usable_cores()[0])
     wd.phase("search", 600)
     search = BI.search_block(device, timed, note, ntotal=100_000 if small else 1_000_000)
     wd.done()

@@ -75,7 +75,7 @@ class _Replay:
         return b
 
 
-def encode_block(cfg, enc, device, note, reps=2, batch_size=64, n_query=256, n_passage=256, oracle=True):
+def encode_block(cfg, enc, device, note, reps=2, batch_size=64, n_query=256, n_passage=256, oracle=True, cores=None):
     import rankpo_amd
     tok = load_bench_tokenizer()
     inf = rankpo_amd.ModelForInference(encoder=enc, tokenizer=tok, use_bf16=True, device=device.index or 0)
@@ -131,17 +131,20 @@ def encode_block(cfg, enc, device, note, reps=2, batch_size=64, n_query=256, n_p
              "driver": "ModelForInference.encode(sentences, batch_size=64, max_length=1280 | 4096) as scripts/evaluate/run_evaluate.sh",
              "host_threads": os.cpu_count()}
     if oracle:
-        block["cpu_baseline"] = oracle_sample(cfg, enc, tok, sides["queries"]["_texts"], sides["queries"]["_out"], note)
+        block["cpu_baseline"] = oracle_sample(cfg, enc, tok, sides["queries"]["_texts"], sides["queries"]["_out"], note, cores=cores)
     for s in sides.values():
         s.pop("_texts"), s.pop("_out")
     block.update(sides)
     return block
 
 
-def oracle_sample(cfg, enc, tok, texts, got, note, rows=2, max_length=1280):
-    """The oracle (float32, host cores) on the first `rows` queries: timed (the CPU baseline of encode()) and compared."""
+def oracle_sample(cfg, enc, tok, texts, got, note, rows=2, max_length=1280, cores=None):
+    """The oracle (float32, host cores) on the first `rows` queries: timed (the CPU baseline of encode()) and compared.
+    cores: the threads this job may really use (bench.usable_cores: the cgroup quota, not the 128 cores the box lists)."""
     from oracle import encoder_ref as E
     w32 = E.state_dict_to_f32(enc)
+    if cores:
+        torch.set_num_threads(int(cores))
     inp = tok(texts[:rows], padding=True, truncation=True, max_length=max_length, return_tensors="pt")
     ntok = int(inp["attention_mask"].sum())
     note(f"encode: oracle on the host cores, {rows} queries, {ntok} tokens ...")
