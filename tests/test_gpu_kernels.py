@@ -672,3 +672,38 @@ def test_flat_index_search_with_split_lists_returns_the_same():
     sv, si = FlatIPIndex(corpus, device=DEV, dtype=torch.bfloat16, chunk_rows=131072, split=4).search(q, 100)
     bv, bi = FlatIPIndex(corpus, device=DEV, dtype=torch.bfloat16, chunk_rows=131072).search(q, 100)
     assert torch.equal(si, bi) and torch.equal(sv, bv)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,L,d", [(600, 512, 2048), (1024, 33, 384), (513, 1000, 4096), (2000, 7, 64), (700, 128, 1024)])
+def test_pool_normalize_one_wave_per_sample_kernel(dtype, N, L, d):
+    """`pool_normalize_fwd_wave_kernel` (round 6: last-token pooling of >= 512 samples with mask rows <= 1024; one wave per sample,
+    NV = 1 / 2 / 4 / 8 vectors per lane) against the oracle: index bit-exact with torch.argmin's first-minimum rule on right-padded,
+    left-padded, all-ones, all-zero and holed mask rows (odd L: the scalar scan; even L: 16-byte pieces), rows at f32 accuracy /
+    correctly rounded in 16-bit storage, the backward through the same indices."""
+    if dtype == torch.float32 and d > 2048:
+        pytest.skip("more than 8 vectors per lane: the block kernel's shape")
+    rs = np.random.RandomState(N + L + d)
+    lens = rs.randint(1, L + 1, size=N)
+    mk = (np.arange(L)[None, :] < lens[:, None]).astype(np.int64)
+    mk[1] = 1                                                   # all ones -> L - 1
+    mk[2] = 0                                                   # all zeros -> argmin 0 -> L - 1
+    mk[3] = (np.arange(L) >= L // 2).astype(np.int64)           # left-padded -> argmin 0 -> L - 1
+    mk[4] = rs.randint(0, 2, size=L)                            # holes: the FIRST zero decides
+    mk[5, :] = 1
+    mk[5, L - 1] = 0                                            # the only zero is the last element
+    torch.manual_seed(N + L)
+    h = torch.randn(N, L, d, device=DEV).to(dtype).requires_grad_(True)          # (on the device: up to 4 GB; the oracle sees the pooled rows)
+    sel = R.last_token_index(mk)
+    e, idx = ops().pool_normalize(h, torch.tensor(mk).to(DEV), "last", True, return_index=True)
+    np.testing.assert_array_equal(idx.cpu().numpy(), sel)
+    rows = npf(h.detach()[torch.arange(N, device=DEV), torch.tensor(sel, device=DEV)])[:, None, :]      # [N, 1, d]
+    ones = np.ones((N, 1), dtype=np.int64)
+    tol = {torch.float32: 2e-6, torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11 * 1.01}[dtype]
+    np.testing.assert_allclose(npf(e), R.pool_normalize(rows, ones, "cls"), rtol=tol, atol=tol * 1e-2)
+    g = t(rs.randn(N, d), dtype)
+    e.backward(g)
+    got = npf(h.grad[torch.arange(N, device=DEV), torch.tensor(sel, device=DEV)])
+    ref = R.pool_normalize_bwd(rows, ones, npf(g), "cls")[:, 0]
+    assert relmax(got, ref) < {torch.float32: 1e-5, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
+    assert float(h.grad.float().abs().sum()) == pytest.approx(float(np.abs(got).sum()), rel=1e-3)      # nothing off the pooled rows
