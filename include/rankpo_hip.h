@@ -132,12 +132,6 @@ int rpo_infonce_ds(const void* scores, const float* lse, const float* grad_loss,
  * strides % 8 == 0 and 16-byte aligned pointers (RPO_ERR_UNSUPPORTED otherwise: the caller keeps the library GEMM). */
 int rpo_sim_gemm_nt(const void* a, int64_t rows_a, int64_t lda, const void* b, int64_t rows_b, int64_t ldb, int64_t K,
                     void* c, int64_t ldc, rpo_stream_t stream);
-/* The same product with the reduction operand as the scoring backward HOLDS it: c [rows_b, N] = b [rows_b, K] x [K, N] (x row-major with
- * N contiguous, row stride ldx) -- dq = dS p_all, dp = dS^T q_all on p_all / q_all themselves.  The kernel stages x as [64 k][128 n]
- * LDS images and reads its MFMA fragments transposed (`ds_read_b64_tr_b16`): no `rpo_transpose` pass in front.  K % 64 == 0,
- * N % 8 == 0, row strides % 8 == 0, 16-byte aligned bases, operands below 4 GiB; anything else RPO_ERR_UNSUPPORTED. */
-int rpo_sim_gemm_nn(const void* x, int64_t K, int64_t N, int64_t ldx, const void* b, int64_t rows_b, int64_t ldb, void* c, int64_t ldc,
-                    rpo_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * (3) RankPO paired scoring + loss + metrics.

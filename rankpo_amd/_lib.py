@@ -53,7 +53,6 @@ SIGNATURES = {
                                   _vp, _vp, _vp, _sz, _vp]),
     "rpo_infonce_ds": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _f32, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "rpo_sim_gemm_nt": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
-    "rpo_sim_gemm_nn": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp]),
     "rpo_rankpo_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, C.POINTER(RankPOParams), _vp, _vp, _vp, _vp, _vp, _vp]),
     "rpo_rankpo_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp]),
     "rpo_adamw_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _vp]),

@@ -346,13 +346,7 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
 // scoring BACKWARD at sweep sizes, dq = dS p_all and dp = dS^T q_all, with the reduction operand transposed beforehand so that
 // both operands are contiguous along the reduction like the forward's (rpo_sim_gemm_nt).  lda / ldb / ldc: row strides (elements)
 // of p, q and the output (EPI 0: d, d, P).
-// TRA (round 6, EPI = 1 only; `rpo_sim_gemm_nn`): the p-side operand is given TRANSPOSED -- X [K, P] with P contiguous (row stride lda)
-// instead of [P, K] -- which is how the scoring backward holds it (dq = dS p_all: p_all is [K = P_total, d]).  Its units are staged as
-// [64 k][128 p] images (256-byte LDS rows, 1 KiB DMA piece = 4 k rows; the 32-byte column units XOR-swizzled by bits {3, 1, 0} of the k
-// row, applied on the per-lane SOURCE address) and its MFMA fragments come out of LDS by `ds_read_b64_tr_b16` (two per fragment: k
-// 8 g + 0..3 and + 4..7 of column frow; a half-wave touches 8 k rows x 32 bytes = every bank once), so that no transposed copy of the
-// embeddings has to be made first (rounds 5's `rpo_transpose` + `rpo_sim_gemm_nt`).
-template <int EPI, bool TRA = false>
+template <int EPI>
 __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, int64_t lda, int64_t ldb,
     int64_t ldc, float temperature, int scale, int do_stats_arg, bf16_t* __restrict__ scores, float2* __restrict__ partial,
@@ -396,20 +390,9 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const bool isA = (u == 0 || u == 3);
-                if (TRA && isA) {
-                    // piece 8 j + wave = k rows 4 (8 j + wave) .. + 3 of the unit's [64 k][128 p] image; lane l sits at k row
-                    // l >> 4, 16-byte position l & 15 and carries the 8 p columns that position holds under the swizzle
-                    const int krow = 4 * (8 * j + wave) + (lane >> 4);
-                    const int cpos = lane & 15;
-                    const int fsw_ = (((krow >> 3) & 1) << 2) | (krow & 3);
-                    const int nl = (((cpos >> 1) ^ fsw_) << 4) + ((cpos & 1) << 3);      // unit-local p row of the lane's first column
-                    const int64_t gc = min(p0_ + big_unit_row(u, nl), P - 8);            // (P % 8 == 0: whole 16-byte groups)
-                    soff[u][j] = (unsigned)(((int64_t)krow * lda + gc) * 2);
-                    continue;
-                }
                 const int ur = (8 * j + wave) * 8 + srow;           // unit-local row
                 const int tr = big_unit_row(u, ur);                 // tile row
+                const bool isA = (u == 0 || u == 3);
                 const int64_t gr = isA ? min(p0_ + tr, P - 1) : min(q0_ + tr, Q - 1);
                 soff[u][j] = (unsigned)((gr * (isA ? lda : ldb) + lchunk * 8) * 2);
             }
@@ -420,29 +403,12 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         _Pragma("unroll") for (int j_ = 0; j_ < 2; ++j_) {                                                         \
             char* dst_ = smem + (BUF) * kBigBufBytes + (U) * kBigUnitBytes + (8 * j_ + wave) * 1024;               \
             const char* base_ = reinterpret_cast<const char*>(((U) == 0 || (U) == 3) ? p : q);                     \
-            const unsigned kadv_ = (TRA && ((U) == 0 || (U) == 3)) ? kstep_tra : (unsigned)(KE * 2);               \
             __builtin_amdgcn_global_load_lds(                                                                      \
-                (const __attribute__((address_space(1))) void*)(base_ + (soff[U][j_] + (unsigned)(T) * kadv_)),    \
+                (const __attribute__((address_space(1))) void*)(base_ + (soff[U][j_] + (unsigned)(T) * (KE * 2))), \
                 (__attribute__((address_space(3))) void*)dst_, 16, 0, 0);                                          \
         }                                                                                                          \
     } while (0)
 
-    const unsigned kstep_tra = (unsigned)(KE * lda * 2);       // TRA: a K-step of the transposed operand is 64 ROWS further on
-    // TRA fragment reads: lane (g, qq, pp) addresses k row 8 g + qq (+ 32 h + 4 part), columns 4 pp .. + 3 of the 16-column unit
-    // (wp * 4 + m) ^ fsw; the transposed read hands lane frow column frow of the group's four rows
-    const int tra_fsw = ((g & 1) << 2) | (frow >> 2);
-    const int tra_row = (8 * g + (frow >> 2)) * 256 + (frow & 3) * 8;
-    auto tra_frag = [&](const char* ub, int m, int h) -> Frag {
-        typedef __attribute__((ext_vector_type(4))) short short4_;
-        typedef __attribute__((address_space(3))) short4_* lds4_;
-        const char* a0 = ub + tra_row + (32 * h) * 256 + (((wp * 4 + m) ^ tra_fsw) << 5);
-        const short4_ lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_)(a0));
-        const short4_ hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds4_)(a0 + 4 * 256));
-        // joined as 32-bit words (register pairs side by side), not element by element: that would be a pack per bf16
-        const uint2_t l2 = __builtin_bit_cast(uint2_t, lo), h2 = __builtin_bit_cast(uint2_t, hi);
-        const uint4_t w = {l2[0], l2[1], h2[0], h2[1]};
-        return __builtin_bit_cast(Frag, w);
-    };
     const int nk = (int)(d / KE);
     // per-lane read offsets inside a unit (row part); the chunk part depends on the k-step
     const int a_off = (wp * 64 + frow) * kTileRowBytes;         // + m*16 rows, units 0 / 3
@@ -490,13 +456,8 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            if constexpr (TRA) {
-                a[m][0] = tra_frag(base + 0 * kBigUnitBytes, m, 0);
-                a[m][1] = tra_frag(base + 0 * kBigUnitBytes, m, 1);
-            } else {
-                a[m][0] = *reinterpret_cast<const Frag*>(base + 0 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c0);
-                a[m][1] = *reinterpret_cast<const Frag*>(base + 0 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c1);
-            }
+            a[m][0] = *reinterpret_cast<const Frag*>(base + 0 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c0);
+            a[m][1] = *reinterpret_cast<const Frag*>(base + 0 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c1);
         }
         if (more) {
             RPO_BIG_STAGE(0, t + 1, nxt);
@@ -541,13 +502,8 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         // ---------------- phase 2
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-            if constexpr (TRA) {
-                a[m][0] = tra_frag(base + 3 * kBigUnitBytes, m, 0);
-                a[m][1] = tra_frag(base + 3 * kBigUnitBytes, m, 1);
-            } else {
-                a[m][0] = *reinterpret_cast<const Frag*>(base + 3 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c0);
-                a[m][1] = *reinterpret_cast<const Frag*>(base + 3 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c1);
-            }
+            a[m][0] = *reinterpret_cast<const Frag*>(base + 3 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c0);
+            a[m][1] = *reinterpret_cast<const Frag*>(base + 3 * kBigUnitBytes + a_off + m * 16 * kTileRowBytes + c1);
         }
         if (more) RPO_BIG_STAGE(2, t + 1, nxt);                 // nothing to retire here: units 0', 1' are due in phase 3
         __builtin_amdgcn_s_barrier();
@@ -1674,28 +1630,6 @@ extern "C" int rpo_sim_gemm_nt(const void* a, int64_t rows_a, int64_t lda, const
     }
     RPO_LAUNCH(sim_tile256_kernel<1>, dim3((unsigned)(RPO_SIM_PERSIST ? std::min<int64_t>(nPt * nQt, kBigPersistBlocks) : nPt * nQt)),
                dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)b, (const bf16_t*)a, rows_b, rows_a, K, lda, ldb, ldc,
-               1.0f, 0, 0, (bf16_t*)c, (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0);
-    return rpo_launch_status();
-}
-
-// C [rows_b, N] = B [rows_b, K] X [K, N] (bf16 in, f32 accumulate, one rounding to bf16): sim_tile256_kernel<1, true>, the p-side operand
-// read TRANSPOSED out of LDS -- the scoring backward's dq = dS p_all and dp = dS^T q_all with the embeddings as they are.
-extern "C" int rpo_sim_gemm_nn(const void* x, int64_t K, int64_t N, int64_t ldx, const void* b, int64_t rows_b, int64_t ldb, void* c,
-                               int64_t ldc, rpo_stream_t stream) {
-    if (!x || !b || !c || K <= 0 || N <= 0 || rows_b <= 0) return RPO_ERR_INVALID_ARG;
-    if (K % 64 != 0 || N % 8 != 0 || ldx % 8 != 0 || ldb % 8 != 0 || ldc % 8 != 0 || ldx < N || ldb < K || ldc < N || !rpo_aligned16(x) ||
-        !rpo_aligned16(b) || !rpo_aligned16(c))
-        return RPO_ERR_UNSUPPORTED;
-    const int64_t nPt = rpo_cdiv(N, kBigTile), nQt = rpo_cdiv(rows_b, kBigTile);
-    if (nPt * nQt > 0x7fffffff) return RPO_ERR_UNSUPPORTED;
-    if (K * ldx * 2 >= ((int64_t)1 << 32) || rows_b * ldb * 2 >= ((int64_t)1 << 32)) return RPO_ERR_UNSUPPORTED;   // 32-bit piece offsets
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
-        attr_set = true;
-    }
-    RPO_LAUNCH((sim_tile256_kernel<1, true>), dim3((unsigned)(RPO_SIM_PERSIST ? std::min<int64_t>(nPt * nQt, kBigPersistBlocks) : nPt * nQt)),
-               dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)b, (const bf16_t*)x, rows_b, N, K, ldx, ldb, ldc,
                1.0f, 0, 0, (bf16_t*)c, (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0);
     return rpo_launch_status();
 }

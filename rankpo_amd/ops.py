@@ -166,10 +166,10 @@ class _InfoNCE(torch.autograd.Function):
         return dq, dp, None, None, None, None, None, None
 
 
-# The two products of the large backward: "hip" = the forward's own MFMA frame with the embeddings read TRANSPOSED out of LDS
-# (rpo_sim_gemm_nn, round 6: no transposed copies), "hip_nt" = the same frame on transposed copies (round 5: rpo_transpose +
-# rpo_sim_gemm_nt), "blaslt" = torch.matmul -> hipBLASLt (rounds 1-4), "auto" = the hand-written arm from the reduction length at
-# which the sweep measured it at least as fast as the library (`INFONCE_BWD_HIP_MIN_K`), the library below.
+# The two products of the large backward: "hip" = the forward's own MFMA frame (rpo_sim_gemm_nt), "blaslt" = torch.matmul ->
+# hipBLASLt (rounds 1-4), "auto" = whichever the sweep measured at least as fast (profiles/r05_sweep_fwd_bwd.md: the two meet at
+# reductions of 16384 -- 2.106 vs 2.096 ms at 16384^2 x 2048, 3.657 vs 3.640 at x 4096 -- and the library wins below, where the
+# hand-written path's five launches (dS, two transposes, two products) show: 0.252 vs 0.229 ms at 4096^2 x 4096).
 INFONCE_BWD_GEMM = "auto"
 INFONCE_BWD_HIP_MIN_K = 16384
 
@@ -184,26 +184,6 @@ def sim_gemm_nt(b, a):
         check(lib.rpo_sim_gemm_nt(a.data_ptr(), N, a.stride(0), b.data_ptr(), M, b.stride(0), K, c.data_ptr(), c.stride(0),
                                   _stream(b)), "rpo_sim_gemm_nt")
     return c
-
-
-def sim_gemm_nn(b, x):
-    """b [M, K] x [K, N] -> [M, N] (bf16; x as it is, N contiguous): sim_tile256_kernel's frame with the x operand read transposed
-    out of LDS (rpo_sim_gemm_nn)."""
-    lib = _lib.load()
-    M, K = b.shape
-    N = x.shape[1]
-    c = torch.empty((M, N), dtype=b.dtype, device=b.device)
-    with torch.cuda.device(b.device):
-        check(lib.rpo_sim_gemm_nn(x.data_ptr(), K, N, x.stride(0), b.data_ptr(), M, b.stride(0), c.data_ptr(), c.stride(0), _stream(b)),
-              "rpo_sim_gemm_nn")
-    return c
-
-
-def sim_gemm_nn_takes(rows, K, d, ld_ds, ld_x, ds_ptr=0, x_ptr=0, bf16=True) -> bool:
-    """`rpo_sim_gemm_nn`'s own conditions for dS [rows, K] (row stride ld_ds) x X [K, d] (row stride ld_x), restated for the dispatch
-    (see `sim_gemm_nt_takes`)."""
-    return bool(bf16 and K % 64 == 0 and d % 8 == 0 and ld_ds % 8 == 0 and ld_ds >= K and ld_x % 8 == 0 and ld_x >= d
-                and ds_ptr % 16 == 0 and x_ptr % 16 == 0 and rows * ld_ds * 2 < 2 ** 32 and K * ld_x * 2 < 2 ** 32 and rows > 0 and d > 0)
 
 
 def sim_gemm_nt_takes(rows, K, d, ld_ds, ds_ptr=0, bf16=True) -> bool:
@@ -221,14 +201,10 @@ def _bwd_product(ds, x_all):
     first (rpo_transpose: 2 K d bytes each way, ~1 % of the product's time at sweep sizes) so that both operands are contiguous
     along the reduction, the layout of the forward kernel's LDS-DMA staging."""
     K, d = x_all.shape
-    want_hip = INFONCE_BWD_GEMM in ("hip", "hip_nt") or (INFONCE_BWD_GEMM == "auto" and K >= INFONCE_BWD_HIP_MIN_K)
-    if want_hip and ds.stride(1) == 1 and x_all.dtype == ds.dtype and x_all.stride(1) == 1:
-        bf = ds.dtype == torch.bfloat16
-        if INFONCE_BWD_GEMM != "hip_nt" and sim_gemm_nn_takes(ds.shape[0], K, d, ds.stride(0), x_all.stride(0), ds.data_ptr(),
-                                                              x_all.data_ptr(), bf):
-            return sim_gemm_nn(ds, x_all)
-        if sim_gemm_nt_takes(ds.shape[0], K, d, ds.stride(0), ds.data_ptr(), bf):
-            return sim_gemm_nt(ds, transpose2d(x_all))
+    want_hip = INFONCE_BWD_GEMM == "hip" or (INFONCE_BWD_GEMM == "auto" and K >= INFONCE_BWD_HIP_MIN_K)
+    if (want_hip and ds.stride(1) == 1 and x_all.dtype == ds.dtype
+            and sim_gemm_nt_takes(ds.shape[0], K, d, ds.stride(0), ds.data_ptr(), ds.dtype == torch.bfloat16)):
+        return sim_gemm_nt(ds, transpose2d(x_all))
     return ds @ x_all
 
 
@@ -1179,7 +1155,7 @@ def topk_finish(best_val, best_idx, split: int):
     return v.gather(1, o)[:, :k].contiguous(), i.gather(1, o)[:, :k].contiguous()
 
 
-__all__ = ["sim_gemm_nt", "sim_gemm_nn", "pool_normalize", "topk_merge", "topk_finish", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
+__all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "topk_finish", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
            "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "rope_flash_attn_varlen_qkv_fwd", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table", "recomputing",
            "attn_key_tile_table"]

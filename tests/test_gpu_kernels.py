@@ -488,7 +488,7 @@ def test_c_abi_argument_errors():
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("arm", ["hip", "hip_nt", "blaslt"])
+@pytest.mark.parametrize("arm", ["hip", "blaslt"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("Q,P,d,win", [(512, 1536, 128, None), (520, 1560, 192, None), (512, 2048, 64, (128, 200, 640, 600)),
                                        (1024, 3072, 512, (256, 300, 1024, 1000))])
@@ -496,14 +496,12 @@ def test_infonce_backward_gemm_form(dtype, Q, P, d, win, arm, monkeypatch):
     """Large problems take the dS-kernel + two-GEMM backward (ops._GEMM_BWD_MIN_PAIRS); same maths, same own-row
     window semantics as the fused small-shape kernel.  Both arms of the two products: the forward's own MFMA frame
     (rpo_sim_gemm_nt; bf16 with a reduction length that is a multiple of 64, else it hands over to the library by itself)
-    (rpo_sim_gemm_nn on the embeddings as they are -- "hip" --, or rpo_sim_gemm_nt on transposed copies -- "hip_nt"),
     and hipBLASLt through torch.matmul."""
     from rankpo_amd import ops as o
     monkeypatch.setattr(o, "INFONCE_BWD_GEMM", arm)
     calls = []
-    real, real_nn = o.sim_gemm_nt, o.sim_gemm_nn
-    monkeypatch.setattr(o, "sim_gemm_nt", lambda b, a: (calls.append(("nt",) + tuple(b.shape)), real(b, a))[1])
-    monkeypatch.setattr(o, "sim_gemm_nn", lambda b, x: (calls.append(("nn",) + tuple(b.shape)), real_nn(b, x))[1])
+    real = o.sim_gemm_nt
+    monkeypatch.setattr(o, "sim_gemm_nt", lambda b, a: (calls.append(tuple(b.shape)), real(b, a))[1])
     rs = np.random.RandomState(Q + P)
     qn, pn = unit(rs.randn(Q, d)), unit(rs.randn(P, d))
     qa, pa = t(qn, dtype), t(pn, dtype)
@@ -524,9 +522,8 @@ def test_infonce_backward_gemm_form(dtype, Q, P, d, win, arm, monkeypatch):
     assert relmax(npf(ql.grad), dq_ref) < tol
     assert relmax(npf(pl.grad), dp_ref) < tol
     # the hand-written frame really ran where it applies (bf16, K = P and K = Q multiples of 64), and only there
-    hip_ok = arm in ("hip", "hip_nt") and dtype == torch.bfloat16
+    hip_ok = arm == "hip" and dtype == torch.bfloat16
     assert len(calls) == (int(P % 64 == 0) + int(Q % 64 == 0) if hip_ok else 0), calls
-    assert all(c[0] == ("nn" if arm == "hip" else "nt") for c in calls), calls       # "hip": the embeddings as they are (round 6)
 
 
 @pytest.mark.parametrize("M,N,K,lds", [(256, 256, 64, None), (1000, 384, 4096, None), (300, 2048, 1024, (1096, 1032, 2056)),
@@ -710,39 +707,3 @@ def test_pool_normalize_one_wave_per_sample_kernel(dtype, N, L, d):
     ref = R.pool_normalize_bwd(rows, ones, npf(g), "cls")[:, 0]
     assert relmax(got, ref) < {torch.float32: 1e-5, torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10}[dtype]
     assert float(h.grad.float().abs().sum()) == pytest.approx(float(np.abs(got).sum()), rel=1e-3)      # nothing off the pooled rows
-
-
-@pytest.mark.parametrize("M,N,K,lds", [(256, 256, 64, None), (1000, 384, 4096, None), (300, 2048, 1024, (1096, 2056, 2064)),
-                                       (513, 520, 128, None), (4096, 2048, 8192, None), (64, 8, 64, None), (2000, 1000, 192, (200, 1008, 1000))])
-def test_sim_gemm_nn_matches_float32_matmul(M, N, K, lds):
-    """rpo_sim_gemm_nn (round 6: sim_tile256_kernel<1, TRA>: the x operand [K, N] staged as [64 k][128 n] LDS images and read
-    TRANSPOSED by ds_read_b64_tr_b16): C = B X in bf16 with f32 accumulation and ONE rounding, against a float32 matmul -- ragged
-    edges in both output dimensions (N not a multiple of 256 / 128 / 16: clamped column groups), row strides wider than the rows,
-    1 to 128 K-steps, and against rpo_sim_gemm_nt on the transposed copy (same frame: bit-identical); refusals."""
-    from rankpo_amd import _lib
-    from rankpo_amd import ops as o
-    torch.manual_seed(M + N + K)
-    ldb, ldx, ldc = lds if lds else (K, N, N)
-    bb = torch.randn(M, ldb, device=DEV).to(torch.bfloat16)
-    xx = torch.randn(K, ldx, device=DEV).to(torch.bfloat16)
-    b, x = bb[:, :K], xx[:, :N]
-    lib = _lib.load()
-    st = torch.cuda.current_stream().cuda_stream
-    if lds is None:
-        c = o.sim_gemm_nn(b, x)
-    else:
-        cc = torch.full((M, ldc), 7.0, device=DEV, dtype=torch.bfloat16)
-        assert lib.rpo_sim_gemm_nn(x.data_ptr(), K, N, ldx, b.data_ptr(), M, ldb, cc.data_ptr(), ldc, st) == 0
-        c = cc[:, :N]
-        assert (cc[:, N:] == 7.0).all()                   # nothing written past the rows' ends
-    ref = b.float() @ x.float()
-    err = ((c.float() - ref).abs() / ref.abs().clamp_min(1.0)).max().item()
-    assert err <= 2.0 ** -8 * 1.03, err
-    c_nt = o.sim_gemm_nt(b.contiguous(), o.transpose2d(x))
-    assert torch.equal(c_nt, c.contiguous())              # the same MFMA chains on the same values in the same order
-    z = torch.zeros(256, 256, device=DEV, dtype=torch.bfloat16)
-    assert lib.rpo_sim_gemm_nn(z.data_ptr(), 96, 256, 256, z.data_ptr(), 256, 256, z.data_ptr(), 256, st) == -2     # K % 64
-    assert lib.rpo_sim_gemm_nn(z.data_ptr(), 64, 100, 256, z.data_ptr(), 256, 256, z.data_ptr(), 256, st) == -2     # N % 8
-    assert lib.rpo_sim_gemm_nn(z.data_ptr() + 2, 64, 64, 256, z.data_ptr(), 64, 256, z.data_ptr(), 256, st) == -2   # alignment
-    assert lib.rpo_sim_gemm_nn(None, 64, 64, 256, z.data_ptr(), 64, 256, z.data_ptr(), 256, st) == -1
-    torch.cuda.synchronize()
