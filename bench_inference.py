@@ -175,8 +175,9 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
     scores, ids = faiss_search(index, q, topk=k, batch_size=batch)                     # warm-up + the result that is checked
     torch.cuda.synchronize(device)
     arms = {}
-    for name, sp in (("4 lists per query row", 4), ("auto", None)):                    # same process, same corpus: the split knob
-        index.split = sp
+    # same process, same corpus: the two knobs of the search (winner lists per row; query rows per pass over the corpus)
+    for name, sp, rows in (("4 lists per query row", 4, 1024), ("256 query rows per corpus pass", None, 256), ("auto", None, 1024)):
+        index.split, index.query_rows_per_pass = sp, rows
         s2, i2 = faiss_search(index, q, topk=k, batch_size=batch)
         assert np.array_equal(i2, ids) and np.array_equal(s2, scores), name
         ws = []
@@ -185,7 +186,7 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
             faiss_search(index, q, topk=k, batch_size=batch)
             ws.append(time.perf_counter() - t0)
         arms[name] = round(min(ws) * 1e3, 3)
-    index.split = None
+    index.split, index.query_rows_per_pass = None, 1024
     wall = arms["auto"] * 1e-3
     # kernel split (HIP events on the launch stream), one more pass
     timed.records.clear()
@@ -207,9 +208,9 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
     del full
     flops = 2.0 * nq * ntotal * d
     cbytes = ntotal * d * 2
-    nb = -(-nq // batch)
+    nb = -(-nq // max(batch, index.query_rows_per_pass))          # passes over the corpus
     out = dict(corpus_rows=ntotal, d=d, dtype="bf16", queries=nq, k=k, query_batch=batch,
-               driver="retrieval.faiss_search(index, q, topk=100, batch_size=256) (reference utils.py:58-80), results on the host",
+               driver="retrieval.faiss_search(index, q, topk=100, batch_size=256) (reference utils.py:58-80; the index regroups the caller's batches to 1024 query rows per pass over the corpus), results on the host",
                seconds=round(wall, 4), queries_per_s=round(nq / wall, 1), scored_pairs_per_s=round(nq * ntotal / wall, 1),
                corpus_GBs=round(nb * cbytes / wall / 1e9, 1), frac_hbm_corpus_stream=round(nb * cbytes / wall / 1e9 / HBM_PEAK_GBS, 4),
                similarity=dict(total_ms=round(sim_ms, 2), achieved_TFLOPs=round(flops / (sim_ms * 1e-3) / 1e12, 1) if sim_ms else None,

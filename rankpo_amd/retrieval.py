@@ -26,6 +26,10 @@ class FlatIPIndex:
         self.ntotal = self.emb.shape[0]
         self.chunk_rows = chunk_rows
         self.split = split                  # winner lists per query row in the selection kernel; None: by the batch size (search)
+        # queries scored per pass over the corpus: every pass streams the whole corpus out of HBM, so a batch of 256 (the reference's
+        # faiss_search default) sits at the machine balance (256 FLOP per corpus byte) while 1024 reads the corpus a quarter as
+        # often and is MFMA-bound; `faiss_search` regroups the caller's batches up to this many rows (rows are independent: same result)
+        self.query_rows_per_pass = 1024
 
     def search(self, queries, k: int):
         """(scores f32 [nq, k], corpus indices int64 [nq, k]), best first; k is clamped to the corpus size."""
@@ -54,6 +58,7 @@ def create_faiss_index(embeddings, device="cuda:0"):
 def faiss_search(index: FlatIPIndex, query_embedding, topk: int = 100, batch_size: int = 256):
     """utils.py:58-80: batched search, returns (scores float32 [N, k], indices int64 [N, k]) as numpy arrays."""
     all_scores, all_indices = [], []
+    batch_size = max(int(batch_size), int(getattr(index, "query_rows_per_pass", batch_size)))
     for i in range(0, len(query_embedding), batch_size):
         s, ix = index.search(query_embedding[i:i + batch_size], topk)
         all_scores.append(s)
