@@ -150,7 +150,10 @@ def plan_for_shape(hbm_usable, nparam, es, hidden, inter, nl, tokens, world=1, p
 def plan_for_encoder(encoder, tokens: int, world: int = None, partitioned: bool = False, block_inputs: int = 1) -> EncoderPlan:
     """Measures what the plan needs -- free HBM of the encoder's device + what this process already holds, the parameter count
     and element size, the world size of torch.distributed -- and returns the plan for `tokens` padded tokens per micro-step
-    (both towers).  On a CPU encoder there is nothing to measure: every block is checkpointed, as HF does."""
+    (both towers).  On a CPU encoder there is nothing to measure: every block is checkpointed, as HF does.
+    The measurement is LOCAL: with several ranks each plans from its own free HBM (no collective is issued from inside a forward;
+    checkpointing changes no result and no collective, so ranks may differ by a block); a launcher that wants one plan for all ranks
+    takes the minimum of the ranks' usable HBM first and passes explicit counts, as bench.py does."""
     import torch
     cfg = encoder.config
     nl = len(encoder.layers)
