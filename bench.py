@@ -1358,10 +1358,10 @@ def main():
             nq_s, np_s = sample_batch["query"]["input_ids"].shape, sample_batch["passage"]["input_ids"].shape
             out["cpu_baseline"] = {"value": round(toks / dt / toks_per_pair, 5), "unit": "pairs/s", "cores": cores,
                                    "kind": "port", "cpu_model": _cpu_model(), "cores_from": cores_how,
-                                   "step_seconds": [round(t, 3) for t in times], "median_seconds": round(dt, 3),
+                                   "step_seconds": [round(t, 3) for t in times], "best_seconds": round(dt, 3),
                                    "sample": f"oracle (eager torch f32, {cores} threads) fwd+bwd of {nq_s[0]} queries x {nq_s[1]} "
                                              f"tok + {np_s[0]} passages x {np_s[1]} tok (padded, as the reference runs them) "
-                                             f"through the same {arch} weights: {toks} tokens, median of {len(times)} timed "
+                                             f"through the same {arch} weights: {toks} tokens, fastest of {len(times)} timed "
                                              f"steps after 1 untimed; pairs/s extrapolated linearly in tokens to "
                                              f"{toks_per_pair:.0f} tokens per full-length pair"}
             if fit is not None:
