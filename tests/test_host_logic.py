@@ -1282,3 +1282,17 @@ def test_gradient_checkpointing_enable_resolves_to_the_memory_plan():
     #   (a recomputed block costs ~56 ms per step, the buffer saves ~1.2 ms per block: bench.py makes the same choice from measurements)
     assert M.plan_for_shape(usable, *_LLAMA_1B, 2 * _TOK_CONTRASTIVE).checkpoint_blocks > 0
     assert M.pad_tokens(1) == 256 and M.pad_tokens(256) == 256 and M.pad_tokens(257) == 512
+
+
+def test_encode_bench_counts_the_same_forward_flops_as_the_training_bench():
+    """bench_inference.forward_flops (the `encode` block's frac of the MFMA peak) is the forward third of bench.llama_step_flops's
+    `required` count: GEMMs 2 of 6 FLOP per weight and token, causal attention 4 of 14 hd nh per (query, key) pair."""
+    import bench
+    import bench_inference as BI
+    from rankpo_amd import encoder as PE
+    lens = [4096, 2048, 3001, 17, 1]
+    for cfg in (PE.llama_3_2_1b_config(), PE.llama_3_8b_config()):
+        f = bench.llama_step_flops(cfg, [lens])
+        assert BI.forward_flops(cfg, lens) == f["gemm_required"] // 3 + round(f["attn_required"] / 3.5)
+    texts = BI.synthetic_texts(BI.load_bench_tokenizer(), 5, 20, 40, seed=1)
+    assert len(texts) == 5 and len(texts[0].split()) == 40 and all(20 <= len(t.split()) <= 40 for t in texts)
