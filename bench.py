@@ -167,6 +167,12 @@ def _algo(name, a):
     if name in ("rpo_topk_merge", "rpo_topk_merge_split"):
         rows, cols, k, dt = a[2], a[3], a[5], a[6]
         return rows * cols * _es(dt) + 2 * rows * k * 12, rows * cols
+    if name == "rpo_sim_topk_filter":           # the fused search step: both operands once, a threshold per row; survivors are a few dozen per row
+        Q, P, d = a[2], a[3], a[4]
+        return (Q + P) * d * 2 + 12 * Q, 2 * Q * P * d
+    if name == "rpo_topk_merge_candidates":     # counters + the winners in and out (+ the few candidates)
+        rows, k = a[3], a[5]
+        return rows * (4 + 2 * k * 12), 0
     if name == "rpo_rankpo_fwd":
         B, d, dt = a[4], a[5], a[6]
         return 3 * B * d * _es(dt), 4 * B * d
@@ -186,7 +192,8 @@ class TimedLib:
 
     def __getattr__(self, name):
         fn = getattr(self._real, name)
-        if not name.startswith("rpo_") or name in ("rpo_version", "rpo_status_string", "rpo_last_hip_error", "rpo_infonce_workspace_bytes", "rpo_add_rmsnorm_waves"):
+        if not name.startswith("rpo_") or name in ("rpo_version", "rpo_status_string", "rpo_last_hip_error", "rpo_infonce_workspace_bytes", "rpo_add_rmsnorm_waves",
+                                               "rpo_sim_topk_filter_ok", "rpo_build_flags"):
             return fn
 
         def wrapped(*a):

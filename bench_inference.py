@@ -176,8 +176,11 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
     torch.cuda.synchronize(device)
     arms = {}
     # same process, same corpus: the two knobs of the search (winner lists per row; query rows per pass over the corpus)
-    for name, sp, rows in (("4 lists per query row", 4, 1024), ("256 query rows per corpus pass", None, 256), ("auto", None, 1024)):
-        index.split, index.query_rows_per_pass = sp, rows
+    # ... and (round 6) the fused step: chunks after the first filtered inside the scoring kernel, no score matrix
+    for name, sp, rows, fused, fill in (("4 lists per query row", 4, 1024, False, 0.25), ("256 query rows per corpus pass", None, 256, False, 0.25),
+                                        ("through the score matrix", None, 1024, False, 0.25), ("fused, candidate lists 1/8 full", None, 1024, True, 0.125),
+                                        ("fused, candidate lists 1/2 full", None, 1024, True, 0.5), ("auto", None, 1024, True, 0.25)):
+        index.split, index.query_rows_per_pass, index.fused, index.candidate_fill = sp, rows, fused, fill
         s2, i2 = faiss_search(index, q, topk=k, batch_size=batch)
         assert np.array_equal(i2, ids) and np.array_equal(s2, scores), name
         ws = []
@@ -186,7 +189,8 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
             faiss_search(index, q, topk=k, batch_size=batch)
             ws.append(time.perf_counter() - t0)
         arms[name] = round(min(ws) * 1e3, 3)
-    index.split, index.query_rows_per_pass = None, 1024
+    index.split, index.query_rows_per_pass, index.fused = None, 1024, True
+    assert index.fused_overflows == 0
     wall = arms["auto"] * 1e-3
     # kernel split (HIP events on the launch stream), one more pass
     timed.records.clear()
@@ -196,8 +200,10 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
     timed.enabled = False
     kern = {r["entry"]: r for r in timed.summary()}
     timed.records.clear()
-    sim_ms = kern.get("rpo_infonce_fwd", {}).get("total_ms", 0.0)
-    top_ms = kern.get("rpo_topk_merge_split", kern.get("rpo_topk_merge", {})).get("total_ms", 0.0)
+    fil_ms = kern.get("rpo_sim_topk_filter", {}).get("total_ms", 0.0)              # scoring + filter of the chunks after the first
+    sim_ms = kern.get("rpo_infonce_fwd", {}).get("total_ms", 0.0) + fil_ms
+    top_ms = kern.get("rpo_topk_merge_split", kern.get("rpo_topk_merge", {})).get("total_ms", 0.0)      # the first chunk's selection
+    cand_ms = kern.get("rpo_topk_merge_candidates", {}).get("total_ms", 0.0)
     # exactness: the planted neighbour wins, and the k winners' VALUES equal a full sort of the kernel's own scores (sample)
     hit = float((torch.as_tensor(ids[:, 0]) == idx_true.cpu()).float().mean())
     sample = list(range(0, nq, max(1, nq // 8)))[:8]
@@ -215,11 +221,15 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
                corpus_GBs=round(nb * cbytes / wall / 1e9, 1), frac_hbm_corpus_stream=round(nb * cbytes / wall / 1e9 / HBM_PEAK_GBS, 4),
                similarity=dict(total_ms=round(sim_ms, 2), achieved_TFLOPs=round(flops / (sim_ms * 1e-3) / 1e12, 1) if sim_ms else None,
                                frac_mfma=round(flops / (sim_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if sim_ms else None),
-               topk_merge=dict(total_ms=round(top_ms, 2),
-                               score_GBs=round(nq * ntotal * 2 / (top_ms * 1e-3) / 1e9, 1) if top_ms else None,
-                               frac_hbm=round(nq * ntotal * 2 / (top_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if top_ms else None),
+               fused_filter=dict(total_ms=round(fil_ms, 2), calls=kern.get("rpo_sim_topk_filter", {}).get("calls", 0),
+                                 frac_mfma=kern.get("rpo_sim_topk_filter", {}).get("frac_mfma"),
+                                 note="chunks after the first: scored and filtered against the rows' k-th winners in one kernel, no score matrix"),
+               topk_merge=dict(total_ms=round(top_ms, 2), calls=kern.get("rpo_topk_merge_split", {}).get("calls", 0),
+                               frac_hbm=kern.get("rpo_topk_merge_split", {}).get("frac_hbm"),
+                               note="the first chunk of every query batch (the winners must be full before the filter can run)"),
+               candidate_merge=dict(total_ms=round(cand_ms, 2), calls=kern.get("rpo_topk_merge_candidates", {}).get("calls", 0)),
                selection_lists_ab_ms=arms, planted_neighbour_is_top1=hit, top_k_values_equal_full_sort=exact, indices_point_at_their_values=rows_ok)
-    note(f"search: {nq * ntotal / wall / 1e9:.1f} G scored pairs/s, similarity {sim_ms:.1f} ms, top-k merge {top_ms:.1f} ms of {wall * 1e3:.1f} ms; "
+    note(f"search: {nq * ntotal / wall / 1e9:.1f} G scored pairs/s, scoring {sim_ms:.1f} ms ({fil_ms:.1f} fused), top-k merge {top_ms:.1f} + {cand_ms:.2f} ms of {wall * 1e3:.1f} ms; "
          f"exact {exact and rows_ok}, planted top-1 {hit:.3f}")
     del corpus, index
     torch.cuda.empty_cache()

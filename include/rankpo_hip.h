@@ -339,6 +339,26 @@ int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int64_t cols, i
 int rpo_topk_merge_split(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype, int split,
                          float* best_val, int64_t* best_idx, int first, rpo_stream_t stream);
 
+/* The search step with the k-selection FUSED into the scoring kernel (round 6; bf16 operands, d a multiple of 64, both operands below
+ * 4 GB): the [Q, P] score matrix of the query block against one corpus chunk (p: rows [col0, col0 + P) of the corpus) is never written.
+ * A score -- <q_r, p_c> accumulated in f32, rounded to bf16 once: bit for bit what the eval similarity (rpo_infonce_fwd without
+ * temperature) stores -- that beats row r's current k-th winner, (best_val, best_idx)[r k + k - 1] in the order of rpo_topk_merge,
+ * is appended to row r's candidate list: slot = atomic increment of cand_cnt[r]; cand_val f32 / cand_idx int64 [Q, cap]; a slot
+ * >= cap is dropped (the counter still counts it).  cand_cnt must be zero on entry (rpo_topk_merge_candidates leaves it so).
+ * The caller's winners must be FULL (k real entries per row: e.g. the first chunk went through rpo_topk_merge), otherwise every
+ * column passes.
+ * rpo_topk_merge_candidates: row r's min(cand_cnt[r], cap) candidates + its k winners -> its k winners (same order); resets
+ * cand_cnt[r]; sets *overflow = 1 if any list had dropped entries (the caller then redoes the search through the score matrix:
+ * retrieval.FlatIPIndex.search).  k + cap <= 4096.
+ * rpo_sim_topk_filter_ok(Q, P, d): 1 for the shapes the filter takes -- those rpo_infonce_fwd scores with the same 256 x 256 kernel
+ * frame (more than 64 query rows, d % 64 == 0, >= 192 tiles, operands below 4 GB), so that the fused step and the score-matrix path
+ * agree bit for bit; everything else returns RPO_ERR_UNSUPPORTED and stays on the score-matrix path. */
+int rpo_sim_topk_filter_ok(int64_t Q, int64_t P, int64_t d);
+int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int64_t col0, int k, const float* best_val,
+                        const int64_t* best_idx, float* cand_val, int64_t* cand_idx, int32_t* cand_cnt, int cap, rpo_stream_t stream);
+int rpo_topk_merge_candidates(const float* cand_val, const int64_t* cand_idx, int32_t* cand_cnt, int64_t rows, int cap, int k,
+                              float* best_val, int64_t* best_idx, int32_t* overflow, rpo_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

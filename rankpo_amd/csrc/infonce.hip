@@ -346,11 +346,27 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
 // scoring BACKWARD at sweep sizes, dq = dS p_all and dp = dS^T q_all, with the reduction operand transposed beforehand so that
 // both operands are contiguous along the reduction like the forward's (rpo_sim_gemm_nt).  lda / ldb / ldc: row strides (elements)
 // of p, q and the output (EPI 0: d, d, P).
+// EPI = 2 (round 6): the exact SEARCH step (rpo_sim_topk_filter).  The score matrix never reaches HBM: a score (one rounding to bf16,
+// the eval similarity's) is compared with its query row's current k-th winner in the accumulator registers and only a score that
+// beats it is appended to the row's candidate list (atomic slot counter in global memory; a few dozen per row and corpus chunk once
+// the winners have seen one chunk).  The tile's 256 thresholds sit in the 10 KiB of LDS behind the ring, loaded one tile ahead.
+// No counted stores: every tile ends in a full drain, like an edge tile of EPI 0.
+struct SimFilter {
+    const float* best_val;        // [Q, k] winners so far, best first: row r's threshold is (best_val, best_idx)[r k + k - 1]
+    const long long* best_idx;
+    float* cand_val;              // [Q, cap]
+    long long* cand_idx;          // [Q, cap]
+    int* cand_cnt;                // [Q]: candidates appended (may exceed cap: the merge reports the overflow)
+    int64_t col0;                 // corpus index of p's row 0
+    int k, cap;
+};
+constexpr int kBigThrOff = 2 * kBigBufBytes;      // EPI 2: float tv[256] | long long ti[256] (3 KiB of the 10 KiB behind the ring)
+
 template <int EPI>
 __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, int64_t lda, int64_t ldb,
     int64_t ldc, float temperature, int scale, int do_stats_arg, bf16_t* __restrict__ scores, float2* __restrict__ partial,
-    int nPt, int nQt, int stagger, int dbg) {
+    int nPt, int nQt, int stagger, int dbg, const SimFilter flt) {
     const int do_stats = EPI == 0 ? do_stats_arg : 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef short8_t Frag;
@@ -421,6 +437,23 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     char* wstage = smem + kBigBufBytes + wave * (16 * kBigStageRowBytes);
     float2* s_stat = reinterpret_cast<float2*>(smem + 8 * kBigStageWaveBytes);   // [wq][64] from the wp == 1 waves
 
+    float* s_tv = reinterpret_cast<float*>(smem + kBigThrOff);
+    long long* s_ti = reinterpret_cast<long long*>(smem + kBigThrOff + kBigTile * 4);
+    // thread t fetches the threshold of query row q0_ + (t & 255), clamped into the matrix (the epilogue does not use a row outside
+    // it).  UNCONDITIONAL, and so is the wait + LDS write that follows at the tile's end: with either under a condition hipcc sees a
+    // path on which the loads are still pending at the K loop's head and puts a vmcnt(0) there -- the end of every counted wait.
+    auto load_thr = [&](int64_t q0_, float& tv_, long long& ti_) {
+        const int64_t r = min(q0_ + (tid & (kBigTile - 1)), Q - 1);
+        tv_ = flt.best_val[r * flt.k + flt.k - 1];
+        ti_ = flt.best_idx[r * flt.k + flt.k - 1];
+    };
+    if constexpr (EPI == 2) {      // BEFORE the first DMAs (nothing in flight yet); visible to the epilogue through the loop's last barrier
+        float tv_;
+        long long ti_;
+        load_thr(q0, tv_, ti_);
+        s_tv[tid & (kBigTile - 1)] = tv_;
+        s_ti[tid & (kBigTile - 1)] = ti_;
+    }
     RPO_BIG_STAGE(0, 0, 0);
     RPO_BIG_STAGE(1, 0, 0);
     RPO_BIG_STAGE(2, 0, 0);
@@ -548,6 +581,9 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         RPO_BIG_STAGE(2, 0, 0);
         RPO_BIG_STAGE(3, 0, 0);
     }
+    float next_tv = 0.f;
+    long long next_ti = 0;
+    if constexpr (EPI == 2) load_thr(q0, next_tv, next_ti);   // (q0: the next tile's, or still this one's) in registers through the filter
 
     // ---- epilogue: acc[m][n][j] = <p_{pbase + 16m + j}, q_{qbase + 16n}>
     const int64_t pbase = p0e + wp * 128 + g * 4;
@@ -557,8 +593,70 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     // instead of 8-byte stores that touch a quarter of a 128-byte line each (measured: the direct stores cost 14 %
     // of the kernel at Q = P = 16384).
     const bool interior = staged && p0e + kBigTile <= P && q0e + kBigTile <= Q;
+    if constexpr (EPI == 2) {
+        // Filter, in two passes over the lane's 4 rows x 32 scores.  Pass 1 marks the survivors (a bit per score); a lane then
+        // reserves its slots with ONE atomic per row -- the (up to) four issued back to back, one wait for all -- and pass 2 writes
+        // them.  (An atomic per survivor with its own wait -- the first form -- cost 23 % of the kernel at ~500 survivors per row
+        // and chunk: every wait also drains the next tile's first DMAs.)
+        unsigned mask[4];
+        float tvn[4];
+        long long tin[4];
+        auto rounded = [&](int m, int n, float (&x)[4]) {
+            const unsigned w01 = pack2_bf16(acc[m][n][0], acc[m][n][1]), w23 = pack2_bf16(acc[m][n][2], acc[m][n][3]);
+            x[0] = __uint_as_float(w01 << 16);
+            x[1] = __uint_as_float(w01 & 0xffff0000u);
+            x[2] = __uint_as_float(w23 << 16);
+            x[3] = __uint_as_float(w23 & 0xffff0000u);
+        };
 #pragma unroll
-    for (int n = 0; n < 4; ++n) {
+        for (int n = 0; n < 4; ++n) {
+            const int lr = wq * 64 + frow + 16 * n;             // the row inside the tile
+            const bool qv = qbase + 16 * n < Q;
+            tvn[n] = qv ? s_tv[lr] : INFINITY;                  // a row outside the matrix: nothing passes
+            tin[n] = qv ? s_ti[lr] : -1;
+            mask[n] = 0;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                float x[4];
+                rounded(m, n, x);
+                // the common case (none of the four reaches the threshold value) costs one max3 pair and one compare
+                if (max3_raw(max3_raw(x[0], x[1], x[2]), x[3], x[3]) >= tvn[n]) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int64_t pi = pbase + 16 * m + j;
+                        if (pi < P && (x[j] > tvn[n] || (x[j] == tvn[n] && flt.col0 + pi < tin[n]))) mask[n] |= 1u << (4 * m + j);
+                    }
+                }
+            }
+        }
+        if (mask[0] | mask[1] | mask[2] | mask[3]) {
+            int slot[4];
+#pragma unroll
+            for (int n = 0; n < 4; ++n) slot[n] = mask[n] ? atomicAdd(flt.cand_cnt + (qbase + 16 * n), __popc(mask[n])) : 0;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (!mask[n]) continue;
+                const int64_t qi = qbase + 16 * n;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    if (!((mask[n] >> (4 * m)) & 15u)) continue;
+                    float x[4];
+                    rounded(m, n, x);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((mask[n] >> (4 * m + j)) & 1u) {
+                            const int pos = slot[n]++;
+                            if (pos < flt.cap) {
+                                flt.cand_val[qi * flt.cap + pos] = x[j];
+                                flt.cand_idx[qi * flt.cap + pos] = flt.col0 + pbase + 16 * m + j;
+                            }
+                        }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < (EPI == 2 ? 0 : 4); ++n) {
         const int64_t qi = qbase + 16 * n;
         const bool qv = qi < Q;
         float mx = RPO_NEG_INF, sum = 0.f;
@@ -687,8 +785,15 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     }
     // an edge tile's stores are not counted (their number depends on the bounds): drain them, and with them the next tile's first
     // units, before the next tile starts; an interior tile leaves its 16 stores in flight
-    carry = have_next && interior && !(dbg & 1);
-    if (have_next && !carry) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if constexpr (EPI == 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // candidate stores, the next tile's first units, its thresholds
+        __syncthreads();                                        // every wave has read this tile's thresholds
+        s_tv[tid & (kBigTile - 1)] = next_tv;                   // (threads t and t + 256 write the same value)
+        s_ti[tid & (kBigTile - 1)] = next_ti;
+    } else {
+        carry = have_next && interior && !(dbg & 1);
+        if (have_next && !carry) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     }
 #undef RPO_BIG_STAGE
 }
@@ -1412,7 +1517,7 @@ int fwd_impl(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, floa
             const int64_t ntile = (int64_t)pl.nPt * pl.nQt;
             RPO_LAUNCH(sim_tile256_kernel<0>, dim3((unsigned)(RPO_SIM_PERSIST ? std::min<int64_t>(ntile, kBigPersistBlocks) : ntile)),
                        dim3(kBigThreads), kBigLdsBytes, st, (const bf16_t*)q, (const bf16_t*)p, Q, P, d, d, d, P, temperature, scale,
-                       do_stats ? 1 : 0, (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0);
+                       do_stats ? 1 : 0, (bf16_t*)scores_out, partial, pl.nPt, pl.nQt, /*stagger=*/1, /*dbg=*/0, SimFilter{});
         }
     } else if (pl.path == PATH_SKINNY) {
         const int ng = Q <= 16 ? 4 : 1;
@@ -1630,7 +1735,38 @@ extern "C" int rpo_sim_gemm_nt(const void* a, int64_t rows_a, int64_t lda, const
     }
     RPO_LAUNCH(sim_tile256_kernel<1>, dim3((unsigned)(RPO_SIM_PERSIST ? std::min<int64_t>(nPt * nQt, kBigPersistBlocks) : nPt * nQt)),
                dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)b, (const bf16_t*)a, rows_b, rows_a, K, lda, ldb, ldc,
-               1.0f, 0, 0, (bf16_t*)c, (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0);
+               1.0f, 0, 0, (bf16_t*)c, (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0, SimFilter{});
+    return rpo_launch_status();
+}
+
+// One step of the exact search (retrieval.FlatIPIndex.search; the k-selection of faiss.IndexFlatIP.search, reference
+// src/utils.py:58-80): the query block against one corpus chunk, survivors of the rows' current k-th winners appended to the rows'
+// candidate lists -- sim_tile256_kernel<2>; rpo_topk_merge_candidates (topk.hip) folds the lists into the winners.
+// 1 when rpo_infonce_fwd scores a bf16 [Q, d] x [P, d] problem with the 256 x 256 kernel: exactly the shapes rpo_sim_topk_filter
+// takes, so that the fused step returns bit for bit what the score-matrix path returns (same kernel frame, same f32 summation order).
+extern "C" int rpo_sim_topk_filter_ok(int64_t Q, int64_t P, int64_t d) {
+    if (Q <= 0 || P <= 0 || d <= 0) return 0;
+    return make_plan(Q, P, d, RPO_DT_BF16, /*aligned=*/true).path == PATH_TILE256 ? 1 : 0;
+}
+
+extern "C" int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int64_t col0, int k,
+                                   const float* best_val, const int64_t* best_idx, float* cand_val, int64_t* cand_idx,
+                                   int32_t* cand_cnt, int cap, rpo_stream_t stream) {
+    if (!q || !p || !best_val || !best_idx || !cand_val || !cand_idx || !cand_cnt || Q <= 0 || P <= 0 || d <= 0 || col0 < 0 ||
+        k <= 0 || cap <= 0)
+        return RPO_ERR_INVALID_ARG;
+    if (!rpo_aligned16(q) || !rpo_aligned16(p) || !rpo_sim_topk_filter_ok(Q, P, d)) return RPO_ERR_UNSUPPORTED;
+    const int64_t nPt = rpo_cdiv(P, kBigTile), nQt = rpo_cdiv(Q, kBigTile);
+    if (nPt * nQt > 0x7fffffff) return RPO_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
+        attr_set = true;
+    }
+    SimFilter flt{best_val, (const long long*)best_idx, cand_val, (long long*)cand_idx, cand_cnt, col0, k, cap};
+    RPO_LAUNCH(sim_tile256_kernel<2>, dim3((unsigned)std::min<int64_t>(nPt * nQt, kBigPersistBlocks)), dim3(kBigThreads), kBigLdsBytes,
+               (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)p, Q, P, d, d, d, P, 1.0f, 0, 0, (bf16_t*)nullptr,
+               (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0, flt);
     return rpo_launch_status();
 }
 

@@ -203,7 +203,35 @@ __global__ __launch_bounds__(kFastThreads) void topk_merge_fast_kernel(const T* 
         // (<= 256 V <= cap elements) goes in alone and is settled; the k-th winner of those already turns away ~95 % of what
         // follows (k = 100), so the rest of the group takes the common path.  (Before: the group overflowed and was replayed in 16
         // quarters with a full 4096-slot sort each: 0.5 ms for the first chunk of a search against 0.09 for the others.)
-        const bool boot = tv == -INFINITY && ti == 0x7fffffffffffffffLL;      // block-uniform
+        bool boot = tv == -INFINITY && ti == 0x7fffffffffffffffLL;            // block-uniform
+        if (boot && first && s0 == 0) {
+            // An EMPTY list (the first group of a search's first chunk; round 6: the fused search step left this call as the only
+            // selection pass of a search, and 0.36 ms of its 0.36 were the two big sorts of the quarter bootstrap below): the k-th
+            // largest of the 1024 threads' own maxima over the group bounds the group's k-th largest element from below -- k
+            // elements, one per thread, reach it.  One 1024-slot sort of the maxima gives a threshold that lets ~k of the group's
+            // 32 K elements through (a thread's maximum of 32 beats it with probability k / 1024) instead of the 5 % the quarter's own
+            // k-th winner admits.  Ties at the threshold all pass (ti = max index); a flood of them overflows into the replay path,
+            // which restarts from an empty threshold.  Fewer than k finite maxima (a chunk of < k columns): the quarter bootstrap.
+            float m = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < kFastDepth; ++u) {
+                if (u >= nseg) break;
+                const int64_t c = u * (int64_t)SEG + (int64_t)tid * V;
+#pragma unroll
+                for (int j = 0; j < V; ++j)
+                    if (c + j < cols) m = fmaxf(m, (float)reg[u].v[j]);
+            }
+            s_val[tid] = m;                                   // (slots [0, 1024): all (-inf, max index) in an empty list)
+            bitonic_sort_desc<kFastThreads>(s_val, s_idx, tid, kFastThreads);      // equal indices: the order of equal maxima is immaterial
+            const float t0 = s_val[k - 1];
+            __syncthreads();
+            s_val[tid] = -INFINITY;                           // the invariant again
+            __syncthreads();
+            if (t0 > -INFINITY) {
+                tv = t0;
+                boot = false;                                 // the group takes the common path under this threshold
+            }
+        }
         if (boot) {
             if (tid < 256) {
                 const int64_t c = s0 * SEG + (int64_t)tid * V;
@@ -264,7 +292,59 @@ __global__ __launch_bounds__(kFastThreads) void topk_merge_fast_kernel(const T* 
     }
 }
 
+// ---- the fused search step's second half (round 6): the candidates rpo_sim_topk_filter appended for a row + the row's k winners
+// -> the row's k winners.  One block per row; sorts the next power of two of k + count slots (a few dozen candidates per corpus
+// chunk once the winners have seen one chunk: 128 or 256 slots).  A list that overflowed (count > cap: its tail was dropped) raises
+// *overflow and the caller redoes the chunk through the score matrix; the counter is reset for the next chunk either way.
+__global__ __launch_bounds__(kTopkThreads) void topk_merge_cand_kernel(const float* __restrict__ cand_val,
+                                                                       const long long* __restrict__ cand_idx, int* __restrict__ cand_cnt,
+                                                                       int cap, int k, float* __restrict__ best_val,
+                                                                       long long* __restrict__ best_idx, int* __restrict__ overflow) {
+    __shared__ float s_val[kTopkSlots];
+    __shared__ long long s_idx[kTopkSlots];
+    const int tid = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    int count = cand_cnt[row];
+    if (count == 0) return;                      // uniform: nothing beat this row's k-th winner in the chunk
+    __syncthreads();                             // everybody has read the counter
+    if (tid == 0) {
+        cand_cnt[row] = 0;
+        if (count > cap) *overflow = 1;
+    }
+    count = count < cap ? count : cap;
+    int n = 64;
+    while (n < k + count) n <<= 1;
+    for (int i = tid; i < n; i += kTopkThreads) {
+        float v = -INFINITY;
+        long long ix = 0x7fffffffffffffffLL;
+        if (i < k) {
+            v = best_val[row * k + i];
+            ix = best_idx[row * k + i];
+        } else if (i < k + count) {
+            v = cand_val[row * cap + (i - k)];
+            ix = cand_idx[row * cap + (i - k)];
+        }
+        s_val[i] = v;
+        s_idx[i] = ix;
+    }
+    bitonic_sort_desc<kTopkThreads>(s_val, s_idx, tid, n);
+    for (int i = tid; i < k; i += kTopkThreads) {
+        best_val[row * k + i] = s_val[i];
+        best_idx[row * k + i] = s_idx[i];
+    }
+}
+
 }  // namespace
+
+extern "C" int rpo_topk_merge_candidates(const float* cand_val, const int64_t* cand_idx, int32_t* cand_cnt, int64_t rows, int cap,
+                                         int k, float* best_val, int64_t* best_idx, int32_t* overflow, rpo_stream_t stream) {
+    if (!cand_val || !cand_idx || !cand_cnt || !best_val || !best_idx || !overflow || rows <= 0 || cap <= 0 || k <= 0)
+        return RPO_ERR_INVALID_ARG;
+    if (k > kTopkMaxK || k + cap > kTopkSlots || rows > INT32_MAX) return RPO_ERR_UNSUPPORTED;
+    RPO_LAUNCH(topk_merge_cand_kernel, dim3((unsigned)rows), dim3(kTopkThreads), 0, (hipStream_t)stream, cand_val,
+               (const long long*)cand_idx, (int*)cand_cnt, cap, k, best_val, (long long*)best_idx, (int*)overflow);
+    return rpo_launch_status();
+}
 
 static int topk_launch(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype, int split,
                        float* best_val, int64_t* best_idx, int first, rpo_stream_t stream) {

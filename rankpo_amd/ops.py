@@ -1155,7 +1155,69 @@ def topk_finish(best_val, best_idx, split: int):
     return v.gather(1, o)[:, :k].contiguous(), i.gather(1, o)[:, :k].contiguous()
 
 
-__all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "topk_finish", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
+TOPK_SLOTS = 4096           # topk.hip: kTopkSlots (winners + candidates of one re-selection)
+
+
+def search_candidate_cap(k: int) -> int:
+    """Candidate slots per query row and corpus chunk of the fused search step: a chunk as large as everything seen before it brings
+    ~k survivors per row on average (exchangeable scores); 3 k, at least 1024, leaves overflow to adversarial corpora (which fall
+    back to the score-matrix path: FlatIPIndex.search)."""
+    return max(1, min(TOPK_SLOTS - k, max(1024, 3 * k)))
+
+
+def search_filter_ok(nq: int, rows: int, d: int) -> bool:
+    """rpo_sim_topk_filter_ok: a bf16 [nq, d] x [rows, d] problem is one the 256 x 256 scoring kernel takes (shape only)."""
+    return bool(_lib.load().rpo_sim_topk_filter_ok(int(nq), int(rows), int(d)))
+
+
+def search_filter_takes(q, p) -> bool:
+    """Shapes rpo_sim_topk_filter takes: bf16 rows, 16-byte aligned, and a problem `similarity` scores with the same 256 x 256 kernel
+    (rpo_sim_topk_filter_ok: > 64 query rows, d % 64 == 0, >= 192 tiles, operands below 4 GB) -- so the fused step changes no bit."""
+    if not (q.dtype == torch.bfloat16 and p.dtype == torch.bfloat16 and q.dim() == 2 and p.dim() == 2 and q.is_contiguous()
+            and p.is_contiguous() and q.shape[1] == p.shape[1] and q.data_ptr() % 16 == 0 and p.data_ptr() % 16 == 0):
+        return False
+    return bool(_lib.load().rpo_sim_topk_filter_ok(q.shape[0], p.shape[0], q.shape[1]))
+
+
+class SearchWorkspace:
+    """Candidate lists of the fused search step for `rows` query rows: values, corpus indices, per-row counters (zero between steps)
+    and the overflow flag."""
+
+    def __init__(self, rows: int, k: int, device):
+        self.rows, self.k, self.cap = rows, k, search_candidate_cap(k)
+        self.cand_val = torch.empty((rows, self.cap), dtype=torch.float32, device=device)
+        self.cand_idx = torch.empty((rows, self.cap), dtype=torch.int64, device=device)
+        self.cand_cnt = torch.zeros((rows,), dtype=torch.int32, device=device)
+        self.overflow = torch.zeros((1,), dtype=torch.int32, device=device)
+
+
+def search_step(q, p, col0: int, best_val, best_idx, ws: SearchWorkspace):
+    """One corpus chunk of the exact search WITHOUT its score matrix: rpo_sim_topk_filter (scores in the MFMA accumulators, survivors of
+    each row's k-th winner appended to the row's candidate list) + rpo_topk_merge_candidates (lists -> winners).  best_val / best_idx
+    [rows, k] are updated in place and must hold k real winners per row; `ws.overflow` is raised when a list ran over (the result is
+    then incomplete: the caller redoes the search through `similarity` + `topk_merge`)."""
+    _need_gpu(q, p)
+    lib = _lib.load()
+    if not search_filter_takes(q, p):
+        raise ValueError("search_step: bf16 [rows, d] operands of a shape the 256 x 256 scoring kernel takes (search_filter_takes)")
+    rows, d = q.shape
+    k = best_val.shape[1]
+    if (ws.rows, ws.k) != (rows, k) or best_val.shape != (rows, k) or best_idx.shape != (rows, k) or not best_val.is_contiguous() \
+            or not best_idx.is_contiguous() or best_val.dtype != torch.float32 or best_idx.dtype != torch.int64:
+        raise ValueError("search_step: best_val / best_idx must be contiguous f32 / int64 [rows, k] matching the workspace")
+    with torch.cuda.device(q.device):
+        st = _stream(q)
+        check(lib.rpo_sim_topk_filter(q.data_ptr(), p.data_ptr(), rows, p.shape[0], d, int(col0), k, best_val.data_ptr(),
+                                      best_idx.data_ptr(), ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(),
+                                      ws.cap, st), "rpo_sim_topk_filter")
+        check(lib.rpo_topk_merge_candidates(ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), rows, ws.cap, k,
+                                            best_val.data_ptr(), best_idx.data_ptr(), ws.overflow.data_ptr(), st),
+              "rpo_topk_merge_candidates")
+    return best_val, best_idx
+
+
+__all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "topk_finish", "search_step", "search_filter_takes", "search_filter_ok", "SearchWorkspace",
+           "search_candidate_cap", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
            "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "rope_flash_attn_varlen_qkv_fwd", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table", "recomputing",
            "attn_key_tile_table"]

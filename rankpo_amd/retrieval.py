@@ -20,6 +20,8 @@ from . import ops
 class FlatIPIndex:
     """Stands where the reference builds `faiss.IndexFlatIP` (utils.py:38-51): keeps the corpus embeddings on the GPU."""
 
+    candidate_fill = 0.25       # fused search: expected survivors per row and chunk / candidate slots (chunk_schedule)
+
     def __init__(self, embeddings, device="cuda:0", dtype=torch.float32, chunk_rows: int = 262144, split=None):
         e = torch.as_tensor(np.asarray(embeddings, dtype=np.float32) if not torch.is_tensor(embeddings) else embeddings)
         self.emb = e.to(device=device, dtype=dtype).contiguous()
@@ -30,6 +32,33 @@ class FlatIPIndex:
         # faiss_search default) sits at the machine balance (256 FLOP per corpus byte) while 1024 reads the corpus a quarter as
         # often and is MFMA-bound; `faiss_search` regroups the caller's batches up to this many rows (rows are independent: same result)
         self.query_rows_per_pass = 1024
+        self.fused = True                   # the fused filter step where it applies (search); False: always through the score matrix
+        self.fused_overflows = 0            # searches redone because a candidate list ran over
+
+    def chunk_schedule(self, nq: int, k: int, fused: bool = True):
+        """[(first row, end row)] of the corpus chunks a search of nq query rows walks.  Plain: `chunk_rows` at a time.  Fused: the
+        only chunk that still needs its score matrix and a selection pass over it is the FIRST (it fills the winners), so it is made
+        as small as the 256 x 256 scoring kernel admits (>= 192 tiles, >= k rows: 12,288 rows at 1024 queries).  A later chunk of n
+        rows behind c seen rows brings ~k n / c survivors per row (exchangeable scores): n grows with c so that this stays at a
+        quarter of the candidate list (`candidate_fill`: 2.56 c at k = 100; at k = 1024, where the lists hold 3 k, never below the
+        first chunk's size, i.e. a third of the list), up to chunk_rows.  Measured at 10^6 x 2048, 1024 queries, k = 100: lists
+        1/8, 1/4, 1/2 full 3.86 / 3.82 / 3.85 ms (gpurun_out/r6_N) -- a chunk with more survivors pays for them in the filter's
+        epilogue what it saves in launches.  A tail too small for the kernel is joined to the last chunk."""
+        plain = [(c0, min(c0 + self.chunk_rows, self.ntotal)) for c0 in range(0, self.ntotal, self.chunk_rows)]
+        if not fused or self.emb.dtype != torch.bfloat16 or nq <= 0:
+            return plain
+        first = max(-(-192 // -(-nq // 256)), -(-k // 256)) * 256
+        if 2 * first > min(self.chunk_rows, self.ntotal) or not ops.search_filter_ok(nq, first, self.emb.shape[1]):
+            return plain
+        out, c = [(0, first)], first
+        while c < self.ntotal:
+            n = max(first, int(c * ops.search_candidate_cap(k) * self.candidate_fill / k) // 256 * 256)
+            n = min(n, self.chunk_rows, self.ntotal - c)
+            if self.ntotal - (c + n) < first:
+                n = self.ntotal - c
+            out.append((c, c + n))
+            c += n
+        return out
 
     def search(self, queries, k: int):
         """(scores f32 [nq, k], corpus indices int64 [nq, k]), best first; k is clamped to the corpus size."""
@@ -43,10 +72,27 @@ class FlatIPIndex:
         # bootstrap and its own re-selections (10^6 x 2048 corpus, 4 x 256 queries, k = 100: 8.6 ms with 4 lists per row against
         # 5.65 with one, gpurun_out/r6_D).  One list per row unless the caller says otherwise.
         split = 1 if self.split is None else int(self.split)
-        top = idx = None
-        for c0 in range(0, self.ntotal, self.chunk_rows):
-            scores = ops.similarity(q, self.emb[c0:c0 + self.chunk_rows])      # [nq, chunk]  (HIP MFMA kernel)
+        # Fused step (round 6, bf16 index): once the winners hold k real entries, a chunk's scores are compared with each row's k-th
+        # winner inside the scoring kernel and only the survivors leave the chip -- no [nq, chunk] score matrix (512 MB per chunk at
+        # 1024 queries), no second pass over it.  A candidate list that runs over (a corpus whose later rows keep beating everything
+        # before them) raises the workspace's flag and the search is redone the plain way.
+        fused = self.fused and split == 1
+        top = idx = ws = None
+        for c0, c1 in self.chunk_schedule(q.shape[0], k, fused):
+            chunk = self.emb[c0:c1]
+            if fused and c0 >= k and ops.search_filter_takes(q, chunk):
+                ws = ws or ops.SearchWorkspace(q.shape[0], k, q.device)
+                ops.search_step(q, chunk, c0, top, idx, ws)
+                continue
+            scores = ops.similarity(q, chunk)                                   # [nq, chunk]  (HIP MFMA kernel)
             top, idx = ops.topk_merge(scores, c0, top, idx, k, split=split)     # HIP selection kernel
+        if ws is not None and int(ws.overflow.item()):
+            self.fused_overflows += 1
+            saved, self.fused = self.fused, False
+            try:
+                return self.search(q, k)
+            finally:
+                self.fused = saved
         return ops.topk_finish(top, idx, split)
 
 

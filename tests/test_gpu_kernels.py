@@ -674,6 +674,127 @@ def test_flat_index_search_with_split_lists_returns_the_same():
     assert torch.equal(si, bi) and torch.equal(sv, bv)
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# the fused search step (rpo_sim_topk_filter + rpo_topk_merge_candidates): no score matrix
+# ------------------------------------------------------------------------------------------------------------------
+def _search_plain(q, corpus, k, chunk_rows):
+    from rankpo_amd.retrieval import FlatIPIndex
+    ix = FlatIPIndex(corpus, device=DEV, dtype=torch.bfloat16, chunk_rows=chunk_rows)
+    ix.fused = False
+    return ix.search(q, k)
+
+
+@pytest.mark.parametrize("nq,ncorpus,d,k,chunk_rows", [(256, 147_404, 128, 100, 49_152), (300, 125_001, 64, 10, 50_000),
+                                                       (1024, 131_072, 256, 100, 65_536), (70, 200_000, 192, 1024, 100_000),
+                                                       (65, 149_999, 64, 1, 50_000)])
+def test_fused_search_step_equals_the_score_matrix_path(nq, ncorpus, d, k, chunk_rows):
+    """FlatIPIndex.search with the fused step (chunks after the first: scores compared with the row's k-th winner in the scoring
+    kernel's accumulators, survivors merged from candidate lists) == the plain path (similarity -> topk_merge) bit for bit: values
+    (bf16 scores widened) and corpus indices, query counts and chunk sizes that are not multiples of the 256-row tile, k = 1 and
+    k = 1024, d = 64 ... 256; and both == the oracle's stable-argsort winners of the same score matrix."""
+    from oracle.scoring_ref import topk_ref
+    from rankpo_amd import ops
+    from rankpo_amd.retrieval import FlatIPIndex
+    g = torch.Generator(device=DEV).manual_seed(nq + ncorpus)
+    corpus = torch.nn.functional.normalize(torch.randn(ncorpus, d, generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    ix = FlatIPIndex(corpus, device=DEV, dtype=torch.bfloat16, chunk_rows=chunk_rows)
+    steps = []
+    real = ops.search_step
+    ops.search_step = lambda *a, **kw: (steps.append(a[2]), real(*a, **kw))[1]
+    try:
+        fv, fi = ix.search(q, k)
+    finally:
+        ops.search_step = real
+    sched = ix.chunk_schedule(nq, k)
+    assert steps == [c0 for c0, _ in sched[1:]] and ix.fused_overflows == 0                       # every chunk but the first
+    assert sched[0][0] == 0 and sched[-1][1] == ncorpus and all(a[1] == b[0] for a, b in zip(sched, sched[1:]))
+    assert all(ops.search_filter_takes(q, corpus[a:b]) for a, b in sched)                         # (the first too: the same kernel frame)
+    pv, pi = _search_plain(q, corpus, k, chunk_rows)
+    assert torch.equal(fi, pi) and torch.equal(fv, pv)
+    if nq * ncorpus <= 40_000_000:
+        # the plain path's kernel choice depends on the shape (its f32 summation order with it): the oracle sees the score matrix
+        # of ONE call per chunk, as search computes it
+        full = torch.cat([ops.similarity(q, corpus[c:c + chunk_rows]) for c in range(0, ncorpus, chunk_rows)], 1)
+        rv, ri = topk_ref(full.float().cpu().numpy(), k)
+        assert np.array_equal(pi.cpu().numpy(), ri) and np.array_equal(pv.cpu().numpy(), rv)
+
+
+def test_fused_search_step_ties_take_the_smaller_corpus_index():
+    """A corpus of 64 distinct rows repeated 3000 times: every score value occurs 3000 times per query, the winners are decided by the
+    corpus index alone, across chunk boundaries; the filter admits an equal score only with a SMALLER index than the k-th winner's
+    (none in a later chunk), so its lists stay short."""
+    from rankpo_amd.retrieval import FlatIPIndex
+    g = torch.Generator(device=DEV).manual_seed(9)
+    base = torch.nn.functional.normalize(torch.randn(64, 128, generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    from rankpo_amd import ops
+    corpus = base.repeat(3000, 1)                                   # 192,000 rows
+    q = torch.cat([base, base[:36]])                                # 100 queries: query j is row j % 64
+    ix = FlatIPIndex(corpus, device=DEV, dtype=torch.bfloat16, chunk_rows=64_000)
+    assert ops.search_filter_takes(q, corpus[64_000:128_000])       # (the fused step does run: chunks 2 and 3)
+    fv, fi = ix.search(q, 200)
+    pv, pi = _search_plain(q, corpus, 200, 64_000)
+    assert torch.equal(fi, pi) and torch.equal(fv, pv) and ix.fused_overflows == 0
+    # the best 200 of query j: the copies of ITS row (score 1), smallest indices first: r, r + 64, ...
+    want = torch.arange(200, device=DEV)[None, :] * 64 + (torch.arange(100, device=DEV) % 64)[:, None]
+    assert torch.equal(fi, want)
+
+
+def test_fused_search_step_overflow_falls_back_to_the_score_matrix():
+    """A corpus sorted AGAINST the search (every later chunk beats everything before it for every query): the candidate lists run
+    over, the flag is raised, and search() returns the plain path's result."""
+    from rankpo_amd import ops
+    from rankpo_amd.retrieval import FlatIPIndex
+    g = torch.Generator(device=DEV).manual_seed(4)
+    d = 64
+    u = torch.nn.functional.normalize(torch.randn(d, generator=g, device=DEV), dim=0)
+    n = 150_000
+    scale = torch.linspace(0.1, 1.0, n, device=DEV)[:, None]       # <q, row i> grows with i for q ~ u
+    corpus = (scale * u[None, :] + 0.001 * torch.randn(n, d, generator=g, device=DEV)).to(torch.bfloat16)
+    q = (u[None, :] + 0.01 * torch.randn(256, d, generator=g, device=DEV)).to(torch.bfloat16)
+    ix = FlatIPIndex(corpus, device=DEV, dtype=torch.bfloat16, chunk_rows=50_000)
+    assert ops.search_filter_takes(q, corpus[50_000:100_000])
+    fv, fi = ix.search(q, 50)
+    assert ix.fused_overflows == 1
+    pv, pi = _search_plain(q, corpus, 50, 50_000)
+    assert torch.equal(fi, pi) and torch.equal(fv, pv)
+    # the step itself: the flag is raised and the counters are back to zero for the next chunk
+    ws = ops.SearchWorkspace(256, 50, DEV)
+    bv, bi = ops.topk_merge(ops.similarity(q, corpus[:50_000]), 0, None, None, 50)
+    ops.search_step(q, corpus[50_000:100_000], 50_000, bv, bi, ws)
+    assert int(ws.overflow.item()) == 1 and int(ws.cand_cnt.abs().sum().item()) == 0
+
+
+def test_fused_search_step_argument_checks():
+    from rankpo_amd import _lib, ops
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    x = torch.zeros(256, 128, device=DEV, dtype=torch.bfloat16)
+    bv = torch.zeros(256, 4, device=DEV)
+    bi = torch.zeros(256, 4, device=DEV, dtype=torch.int64)
+    ws = ops.SearchWorkspace(256, 4, DEV)
+    a = (bv.data_ptr(), bi.data_ptr(), ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), ws.cap, st)
+    big = torch.zeros(49_152, 128, device=DEV, dtype=torch.bfloat16)
+    assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 256, 49_152, 96, 0, 4, *a) == -2       # d % 64
+    assert lib.rpo_sim_topk_filter(x.data_ptr() + 2, big.data_ptr(), 255, 49_152, 128, 0, 4, *a) == -2  # alignment
+    assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 256, 49_152 - 256, 128, 0, 4, *a) == -2    # < 192 tiles: another kernel scores it
+    assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 64, 49_152, 128, 0, 4, *a) == -2       # <= 64 query rows: the skinny kernel
+    assert lib.rpo_sim_topk_filter(None, big.data_ptr(), 256, 49_152, 128, 0, 4, *a) == -1
+    assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 256, 49_152, 128, -1, 4, *a) == -1
+    assert lib.rpo_sim_topk_filter_ok(256, 49_152, 128) == 1 and lib.rpo_sim_topk_filter_ok(256, 49_152, 100) == 0
+    assert not ops.search_filter_takes(x[:64], big) and ops.search_filter_takes(x, big) and not ops.search_filter_takes(x.float(), big)
+    assert lib.rpo_topk_merge_candidates(ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), 256, 4000, 200,
+                                         bv.data_ptr(), bi.data_ptr(), ws.overflow.data_ptr(), st) == -2   # k + cap > 4096
+    assert lib.rpo_topk_merge_candidates(ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), 256, ws.cap, 4,
+                                         bv.data_ptr(), bi.data_ptr(), None, st) == -1
+    with pytest.raises(ValueError):
+        ops.search_step(x.float(), big, 0, bv, bi, ws)                                                   # f32 operand
+    with pytest.raises(ValueError):
+        ops.search_step(x, big, 0, bv[:, :2], bi[:, :2], ws)                                             # winners do not match
+    assert ops.search_candidate_cap(100) == 1024 and ops.search_candidate_cap(1024) == 3072 and ops.search_candidate_cap(1) == 1024
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,L,d", [(600, 512, 2048), (1024, 33, 384), (513, 1000, 4096), (2000, 7, 64), (700, 128, 1024)])
 def test_pool_normalize_one_wave_per_sample_kernel(dtype, N, L, d):

@@ -1296,3 +1296,35 @@ def test_encode_bench_counts_the_same_forward_flops_as_the_training_bench():
         assert BI.forward_flops(cfg, lens) == f["gemm_required"] // 3 + round(f["attn_required"] / 3.5)
     texts = BI.synthetic_texts(BI.load_bench_tokenizer(), 5, 20, 40, seed=1)
     assert len(texts) == 5 and len(texts[0].split()) == 40 and all(20 <= len(t.split()) <= 40 for t in texts)
+
+
+def test_fused_search_chunk_schedule():
+    """retrieval.FlatIPIndex.chunk_schedule (host arithmetic + one shape query of the C library): the fused search makes its first chunk
+    -- the only one that still pays a score matrix and a selection pass -- as small as the 256 x 256 scoring kernel admits, then grows with the rows seen;
+    chunks tile the corpus exactly; shapes the kernel does not take keep the plain schedule."""
+    import torch
+    from rankpo_amd.retrieval import FlatIPIndex
+
+    def index(n, d, chunk_rows=262144, dtype=torch.bfloat16):
+        ix = FlatIPIndex.__new__(FlatIPIndex)
+        ix.emb, ix.ntotal, ix.chunk_rows, ix.split, ix.fused = torch.empty((n, d), dtype=dtype, device="meta"), n, chunk_rows, None, True
+        return ix
+
+    sizes = lambda sch: [b - a for a, b in sch]
+    big = index(1_000_000, 2048)
+    assert sizes(big.chunk_schedule(1024, 100)) == [12288, 31232, 111360, 262144, 262144, 262144, 58688]   # 2.56 x the rows seen, whole tiles
+    assert sizes(big.chunk_schedule(256, 100)) == [49152, 125696, 262144, 262144, 300864]                  # (a tail below the first chunk's size joins)
+    assert sizes(big.chunk_schedule(1024, 1024)) == [12288, 12288, 18432, 32256, 56320, 98560, 172544, 262144, 262144, 73024]
+    assert sizes(big.chunk_schedule(1024, 100, fused=False)) == [262144, 262144, 262144, 213568]
+    assert sizes(big.chunk_schedule(64, 100)) == [262144, 262144, 262144, 213568]               # <= 64 query rows: another kernel scores them
+    assert sizes(index(1_000_000, 2048, dtype=torch.float32).chunk_schedule(1024, 100)) == [262144, 262144, 262144, 213568]
+    assert sizes(index(1_000_000, 100).chunk_schedule(1024, 100)) == [262144, 262144, 262144, 213568]     # d % 64
+    assert sizes(index(200_000, 192, 100_000).chunk_schedule(70, 1024)) == [49152, 49152, 101696]
+    assert sizes(index(131_072, 256, 65_536).chunk_schedule(1024, 100)) == [12288, 31232, 65536, 22016]
+    assert sizes(index(80_000, 64).chunk_schedule(1024, 100)) == [12288, 31232, 36480]
+    assert sizes(index(149_999, 64, 50_000).chunk_schedule(65, 1)) == [50000, 50000, 49999]               # chunk_rows < 2 first chunks: plain
+    assert sizes(index(30_000, 64).chunk_schedule(1024, 1024)) == [12288, 17712]
+    assert sizes(index(5_000, 64).chunk_schedule(1024, 100)) == [5000]
+    for nq, k in ((1024, 100), (300, 1000), (65, 7)):
+        sch = big.chunk_schedule(nq, k)
+        assert sch[0][0] == 0 and sch[-1][1] == 1_000_000 and all(a[1] == b[0] for a, b in zip(sch, sch[1:])) and sch[0][1] >= k
