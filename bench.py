@@ -170,6 +170,9 @@ def _algo(name, a):
     if name == "rpo_sim_topk_filter":           # the fused search step: both operands once, a threshold per row; survivors are a few dozen per row
         Q, P, d = a[2], a[3], a[4]
         return (Q + P) * d * 2 + 12 * Q, 2 * Q * P * d
+    if name == "rpo_sim_scores_f32":
+        Q, P, d = a[2], a[3], a[4]
+        return (Q + P) * d * 2 + 4 * Q * P, 2 * Q * P * d
     if name == "rpo_topk_merge_candidates":     # counters + the winners in and out (+ the few candidates)
         rows, k = a[3], a[5]
         return rows * (4 + 2 * k * 12), 0

@@ -24,6 +24,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 MFMA_BF16_PEAK_TFLOPS = 2500.0
+MFMA_F32_PEAK_TFLOPS = 157.3      # f32-input MFMA = the f32 vector rate (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -159,19 +160,22 @@ def oracle_sample(cfg, enc, tok, texts, got, note, rows=2, max_length=1280, core
                 cosine_min_vs_product_bf16=float(cos.min()), parity="pass" if cos.min() > 1 - 2e-3 else "FAIL")
 
 
-def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, batch=256, reps=3):
+def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, batch=256, reps=3, dtype=torch.bfloat16, exact16=False):
+    name_of = {torch.bfloat16: "bf16", torch.float32: "f32", torch.float16: "f16"}[dtype]
+    peak = MFMA_F32_PEAK_TFLOPS if dtype == torch.float32 and not exact16 else MFMA_BF16_PEAK_TFLOPS     # (exact16: the bf16 frame scores it)
     from rankpo_amd import ops
     from rankpo_amd.retrieval import FlatIPIndex, faiss_search
     g = torch.Generator(device=device).manual_seed(5)
-    note(f"search: corpus {ntotal} x {d} bf16, {nq} queries, k = {k}")
-    corpus = torch.empty((ntotal, d), dtype=torch.bfloat16, device=device)
+    note(f"search: corpus {ntotal} x {d} {name_of}, {nq} queries, k = {k}")
+    corpus = torch.empty((ntotal, d), dtype=dtype, device=device)
     for c0 in range(0, ntotal, 131072):
         x = torch.randn((min(131072, ntotal - c0), d), generator=g, device=device)
-        corpus[c0:c0 + x.shape[0]] = torch.nn.functional.normalize(x, dim=-1).to(torch.bfloat16)
+        x = torch.nn.functional.normalize(x, dim=-1)
+        corpus[c0:c0 + x.shape[0]] = (x.to(torch.bfloat16) if exact16 else x).to(dtype)      # exact16: what a bf16 encoder hands over as f32
     idx_true = torch.randint(0, ntotal, (nq,), generator=g, device=device)
     q = torch.nn.functional.normalize(corpus[idx_true].float() + 0.02 * torch.randn((nq, d), generator=g, device=device), dim=-1)
-    q = q.to(torch.bfloat16)
-    index = FlatIPIndex(corpus, device=device, dtype=torch.bfloat16)
+    q = (q.to(torch.bfloat16) if exact16 else q).to(dtype)
+    index = FlatIPIndex(corpus, device=device, dtype=dtype)
     scores, ids = faiss_search(index, q, topk=k, batch_size=batch)                     # warm-up + the result that is checked
     torch.cuda.synchronize(device)
     arms = {}
@@ -201,13 +205,19 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
     kern = {r["entry"]: r for r in timed.summary()}
     timed.records.clear()
     fil_ms = kern.get("rpo_sim_topk_filter", {}).get("total_ms", 0.0)              # scoring + filter of the chunks after the first
-    sim_ms = kern.get("rpo_infonce_fwd", {}).get("total_ms", 0.0) + fil_ms
+    sim_ms = kern.get("rpo_infonce_fwd", {}).get("total_ms", 0.0) + kern.get("rpo_sim_scores_f32", {}).get("total_ms", 0.0) + fil_ms
     top_ms = kern.get("rpo_topk_merge_split", kern.get("rpo_topk_merge", {})).get("total_ms", 0.0)      # the first chunk's selection
     cand_ms = kern.get("rpo_topk_merge_candidates", {}).get("total_ms", 0.0)
     # exactness: the planted neighbour wins, and the k winners' VALUES equal a full sort of the kernel's own scores (sample)
     hit = float((torch.as_tensor(ids[:, 0]) == idx_true.cpu()).float().mean())
     sample = list(range(0, nq, max(1, nq // 8)))[:8]
-    full = torch.cat([ops.similarity(q[sample], corpus[c0:c0 + 262144]).float() for c0 in range(0, ntotal, 262144)], 1)
+    # (scored with ALL query rows, as the search scores them: a kernel chosen for 8 rows sums in another order, and a last-bit
+    # difference of one bf16 score would read as an inexact search)
+    if getattr(index, "emb16", None) is not None:                  # f32 index scored by the bf16 frame: its own f32 score matrix
+        q16 = q.to(torch.bfloat16)
+        full = torch.cat([ops.similarity_f32(q16, index.emb16[c0:c0 + 262144])[sample] for c0 in range(0, ntotal, 262144)], 1)
+    else:
+        full = torch.cat([ops.similarity(q, corpus[c0:c0 + 262144])[sample].float() for c0 in range(0, ntotal, 262144)], 1)
     ref_top = torch.topk(full, k, dim=1).values.cpu().numpy()
     exact = bool(np.array_equal(ref_top, scores[sample]))
     rows_ok = bool(np.array_equal(np.take_along_axis(full.cpu().numpy(), ids[sample], 1), scores[sample]))
@@ -215,12 +225,13 @@ def search_block(device, timed, note, ntotal=1_000_000, d=2048, nq=1024, k=100, 
     flops = 2.0 * nq * ntotal * d
     cbytes = ntotal * d * 2
     nb = -(-nq // max(batch, index.query_rows_per_pass))          # passes over the corpus
-    out = dict(corpus_rows=ntotal, d=d, dtype="bf16", queries=nq, k=k, query_batch=batch,
+    out = dict(corpus_rows=ntotal, d=d, dtype=name_of, values_exact_in_bf16=bool(exact16 or dtype == torch.bfloat16),
+               bf16_frame_with_f32_scores=bool(getattr(index, "emb16", None) is not None), queries=nq, k=k, query_batch=batch,
                driver="retrieval.faiss_search(index, q, topk=100, batch_size=256) (reference utils.py:58-80; the index regroups the caller's batches to 1024 query rows per pass over the corpus), results on the host",
                seconds=round(wall, 4), queries_per_s=round(nq / wall, 1), scored_pairs_per_s=round(nq * ntotal / wall, 1),
                corpus_GBs=round(nb * cbytes / wall / 1e9, 1), frac_hbm_corpus_stream=round(nb * cbytes / wall / 1e9 / HBM_PEAK_GBS, 4),
                similarity=dict(total_ms=round(sim_ms, 2), achieved_TFLOPs=round(flops / (sim_ms * 1e-3) / 1e12, 1) if sim_ms else None,
-                               frac_mfma=round(flops / (sim_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4) if sim_ms else None),
+                               frac_mfma=round(flops / (sim_ms * 1e-3) / 1e12 / peak, 4) if sim_ms else None, mfma_peak_TFLOPs=peak),
                fused_filter=dict(total_ms=round(fil_ms, 2), calls=kern.get("rpo_sim_topk_filter", {}).get("calls", 0),
                                  frac_mfma=kern.get("rpo_sim_topk_filter", {}).get("frac_mfma"),
                                  note="chunks after the first: scored and filtered against the rows' k-th winners in one kernel, no score matrix"),

@@ -354,8 +354,15 @@ int rpo_topk_merge_split(const void* scores, int64_t ld, int64_t rows, int64_t c
  * frame (more than 64 query rows, d % 64 == 0, >= 192 tiles, operands below 4 GB), so that the fused step and the score-matrix path
  * agree bit for bit; everything else returns RPO_ERR_UNSUPPORTED and stays on the score-matrix path. */
 int rpo_sim_topk_filter_ok(int64_t Q, int64_t P, int64_t d);
-int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int64_t col0, int k, const float* best_val,
-                        const int64_t* best_idx, float* cand_val, int64_t* cand_idx, int32_t* cand_cnt, int cap, rpo_stream_t stream);
+int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int64_t col0, int k, int round_scores,
+                        const float* best_val, const int64_t* best_idx, float* cand_val, int64_t* cand_idx, int32_t* cand_cnt,
+                        int cap, rpo_stream_t stream);
+/* round_scores = 0 and rpo_sim_scores_f32: the search of an F32 index (the reference's faiss.IndexFlatIP dtype, utils.py:38-51) whose
+ * embeddings are exactly representable in bf16 -- what an encoder that computes in bf16 hands over.  Products of bf16 values are
+ * exact in f32 and the sums are f32 sums: an f32 inner product in this kernel's summation order, at the bf16 MFMA rate (16 x the
+ * f32 MFMA's).  The score is the unrounded f32 sum; rpo_sim_scores_f32 writes the [Q, P] score matrix (row stride ldc floats) of
+ * the same frame for the search's first chunk, so that equal rows score equal wherever they lie.  Same shapes as the filter. */
+int rpo_sim_scores_f32(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, float* scores, int64_t ldc, rpo_stream_t stream);
 int rpo_topk_merge_candidates(const float* cand_val, const int64_t* cand_idx, int32_t* cand_cnt, int64_t rows, int cap, int k,
                               float* best_val, int64_t* best_idx, int32_t* overflow, rpo_stream_t stream);
 

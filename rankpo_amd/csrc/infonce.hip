@@ -351,6 +351,11 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
 // beats it is appended to the row's candidate list (atomic slot counter in global memory; a few dozen per row and corpus chunk once
 // the winners have seen one chunk).  The tile's 256 thresholds sit in the 10 KiB of LDS behind the ring, loaded one tile ahead.
 // No counted stores: every tile ends in a full drain, like an edge tile of EPI 0.
+// EPI = 3: EPI 2 on the UNROUNDED f32 accumulators -- the search step of an f32 index whose embeddings are exactly representable in
+// bf16 (what an encoder that computes in bf16 hands over): the bf16 products are exact, the sums are f32 sums, i.e. an f32 inner
+// product in this frame's summation order at 16 x the f32 MFMA rate.
+// EPI = 4: the score matrix of the same problem as f32 (`scores` is a float*, ldc its row stride in elements), direct 16-byte
+// stores: the first chunk of such a search (small), so that every score of it comes out of ONE summation order.
 struct SimFilter {
     const float* best_val;        // [Q, k] winners so far, best first: row r's threshold is (best_val, best_idx)[r k + k - 1]
     const long long* best_idx;
@@ -447,7 +452,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         tv_ = flt.best_val[r * flt.k + flt.k - 1];
         ti_ = flt.best_idx[r * flt.k + flt.k - 1];
     };
-    if constexpr (EPI == 2) {      // BEFORE the first DMAs (nothing in flight yet); visible to the epilogue through the loop's last barrier
+    if constexpr (EPI == 2 || EPI == 3) {      // BEFORE the first DMAs (nothing in flight yet); visible to the epilogue through the loop's last barrier
         float tv_;
         long long ti_;
         load_thr(q0, tv_, ti_);
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     }
     float next_tv = 0.f;
     long long next_ti = 0;
-    if constexpr (EPI == 2) load_thr(q0, next_tv, next_ti);   // (q0: the next tile's, or still this one's) in registers through the filter
+    if constexpr (EPI == 2 || EPI == 3) load_thr(q0, next_tv, next_ti);   // (q0: the next tile's, or still this one's) in registers through the filter
 
     // ---- epilogue: acc[m][n][j] = <p_{pbase + 16m + j}, q_{qbase + 16n}>
     const int64_t pbase = p0e + wp * 128 + g * 4;
@@ -593,7 +598,28 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     // instead of 8-byte stores that touch a quarter of a 128-byte line each (measured: the direct stores cost 14 %
     // of the kernel at Q = P = 16384).
     const bool interior = staged && p0e + kBigTile <= P && q0e + kBigTile <= Q;
-    if constexpr (EPI == 2) {
+    if constexpr (EPI == 4) {
+        float* out = reinterpret_cast<float*>(scores);
+        const bool v4 = (ldc % 4 == 0) && rpo_aligned16_dev(out);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int64_t qi = qbase + 16 * n;
+            if (qi >= Q) continue;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int64_t pi = pbase + 16 * m;
+                float* dst = out + qi * ldc + pi;
+                if (v4 && pi + 3 < P) {
+                    *reinterpret_cast<float4_t*>(dst) = acc[m][n];
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (pi + j < P) dst[j] = acc[m][n][j];
+                }
+            }
+        }
+    }
+    if constexpr (EPI == 2 || EPI == 3) {
         // Filter, in two passes over the lane's 4 rows x 32 scores.  Pass 1 marks the survivors (a bit per score); a lane then
         // reserves its slots with ONE atomic per row -- the (up to) four issued back to back, one wait for all -- and pass 2 writes
         // them.  (An atomic per survivor with its own wait -- the first form -- cost 23 % of the kernel at ~500 survivors per row
@@ -601,12 +627,17 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         unsigned mask[4];
         float tvn[4];
         long long tin[4];
-        auto rounded = [&](int m, int n, float (&x)[4]) {
-            const unsigned w01 = pack2_bf16(acc[m][n][0], acc[m][n][1]), w23 = pack2_bf16(acc[m][n][2], acc[m][n][3]);
-            x[0] = __uint_as_float(w01 << 16);
-            x[1] = __uint_as_float(w01 & 0xffff0000u);
-            x[2] = __uint_as_float(w23 << 16);
-            x[3] = __uint_as_float(w23 & 0xffff0000u);
+        auto rounded = [&](int m, int n, float (&x)[4]) {       // the score as the search defines it: bf16 once (EPI 2) / the f32 sum (EPI 3)
+            if constexpr (EPI == 3) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = acc[m][n][j];
+            } else {
+                const unsigned w01 = pack2_bf16(acc[m][n][0], acc[m][n][1]), w23 = pack2_bf16(acc[m][n][2], acc[m][n][3]);
+                x[0] = __uint_as_float(w01 << 16);
+                x[1] = __uint_as_float(w01 & 0xffff0000u);
+                x[2] = __uint_as_float(w23 << 16);
+                x[3] = __uint_as_float(w23 & 0xffff0000u);
+            }
         };
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -656,7 +687,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
         }
     }
 #pragma unroll
-    for (int n = 0; n < (EPI == 2 ? 0 : 4); ++n) {
+    for (int n = 0; n < (EPI >= 2 ? 0 : 4); ++n) {
         const int64_t qi = qbase + 16 * n;
         const bool qv = qi < Q;
         float mx = RPO_NEG_INF, sum = 0.f;
@@ -785,7 +816,9 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     }
     // an edge tile's stores are not counted (their number depends on the bounds): drain them, and with them the next tile's first
     // units, before the next tile starts; an interior tile leaves its 16 stores in flight
-    if constexpr (EPI == 2) {
+    if constexpr (EPI == 4) {
+        if (have_next) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // uncounted stores: a full drain, like an edge tile
+    } else if constexpr (EPI == 2 || EPI == 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // candidate stores, the next tile's first units, its thresholds
         __syncthreads();                                        // every wave has read this tile's thresholds
         s_tv[tid & (kBigTile - 1)] = next_tv;                   // (threads t and t + 256 write the same value)
@@ -1750,8 +1783,8 @@ extern "C" int rpo_sim_topk_filter_ok(int64_t Q, int64_t P, int64_t d) {
 }
 
 extern "C" int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int64_t col0, int k,
-                                   const float* best_val, const int64_t* best_idx, float* cand_val, int64_t* cand_idx,
-                                   int32_t* cand_cnt, int cap, rpo_stream_t stream) {
+                                   int round_scores, const float* best_val, const int64_t* best_idx, float* cand_val,
+                                   int64_t* cand_idx, int32_t* cand_cnt, int cap, rpo_stream_t stream) {
     if (!q || !p || !best_val || !best_idx || !cand_val || !cand_idx || !cand_cnt || Q <= 0 || P <= 0 || d <= 0 || col0 < 0 ||
         k <= 0 || cap <= 0)
         return RPO_ERR_INVALID_ARG;
@@ -1761,12 +1794,38 @@ extern "C" int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int6
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
+        (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
         attr_set = true;
     }
     SimFilter flt{best_val, (const long long*)best_idx, cand_val, (long long*)cand_idx, cand_cnt, col0, k, cap};
-    RPO_LAUNCH(sim_tile256_kernel<2>, dim3((unsigned)std::min<int64_t>(nPt * nQt, kBigPersistBlocks)), dim3(kBigThreads), kBigLdsBytes,
-               (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)p, Q, P, d, d, d, P, 1.0f, 0, 0, (bf16_t*)nullptr,
-               (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0, flt);
+    const dim3 grid((unsigned)std::min<int64_t>(nPt * nQt, kBigPersistBlocks));
+    if (round_scores)
+        RPO_LAUNCH(sim_tile256_kernel<2>, grid, dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)q,
+                   (const bf16_t*)p, Q, P, d, d, d, P, 1.0f, 0, 0, (bf16_t*)nullptr, (float2*)nullptr, (int)nPt, (int)nQt,
+                   /*stagger=*/1, /*dbg=*/0, flt);
+    else
+        RPO_LAUNCH(sim_tile256_kernel<3>, grid, dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)q,
+                   (const bf16_t*)p, Q, P, d, d, d, P, 1.0f, 0, 0, (bf16_t*)nullptr, (float2*)nullptr, (int)nPt, (int)nQt,
+                   /*stagger=*/1, /*dbg=*/0, flt);
+    return rpo_launch_status();
+}
+
+// scores f32 [Q, P] (row stride ldc) = q [Q, d] p [P, d]^T, bf16 operands, f32 sums UNROUNDED, in the 256 x 256 frame's summation
+// order (sim_tile256_kernel<4>): the score matrix that goes with rpo_sim_topk_filter(round_scores = 0); same shapes.
+extern "C" int rpo_sim_scores_f32(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, float* scores, int64_t ldc,
+                                  rpo_stream_t stream) {
+    if (!q || !p || !scores || Q <= 0 || P <= 0 || d <= 0 || ldc < P) return RPO_ERR_INVALID_ARG;
+    if (!rpo_aligned16(q) || !rpo_aligned16(p) || !rpo_sim_topk_filter_ok(Q, P, d)) return RPO_ERR_UNSUPPORTED;
+    const int64_t nPt = rpo_cdiv(P, kBigTile), nQt = rpo_cdiv(Q, kBigTile);
+    if (nPt * nQt > 0x7fffffff) return RPO_ERR_UNSUPPORTED;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
+        attr_set = true;
+    }
+    RPO_LAUNCH(sim_tile256_kernel<4>, dim3((unsigned)std::min<int64_t>(nPt * nQt, kBigPersistBlocks)), dim3(kBigThreads), kBigLdsBytes,
+               (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)p, Q, P, d, d, d, ldc, 1.0f, 0, 0, (bf16_t*)scores,
+               (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0, SimFilter{});
     return rpo_launch_status();
 }
 

@@ -1191,11 +1191,26 @@ class SearchWorkspace:
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=device)
 
 
-def search_step(q, p, col0: int, best_val, best_idx, ws: SearchWorkspace):
+def similarity_f32(q, p):
+    """f32 scores [Q, P] of bf16 operands, UNROUNDED f32 sums in the 256 x 256 scoring frame's summation order (rpo_sim_scores_f32):
+    the score matrix of an f32 index whose embeddings are exact in bf16 (retrieval.FlatIPIndex).  Shapes: search_filter_takes."""
+    _need_gpu(q, p)
+    lib = _lib.load()
+    if not search_filter_takes(q, p):
+        raise ValueError("similarity_f32: bf16 [rows, d] operands of a shape the 256 x 256 scoring kernel takes (search_filter_takes)")
+    scores = torch.empty((q.shape[0], p.shape[0]), dtype=torch.float32, device=q.device)
+    with torch.cuda.device(q.device):
+        check(lib.rpo_sim_scores_f32(q.data_ptr(), p.data_ptr(), q.shape[0], p.shape[0], q.shape[1], scores.data_ptr(), scores.stride(0),
+                                     _stream(q)), "rpo_sim_scores_f32")
+    return scores
+
+
+def search_step(q, p, col0: int, best_val, best_idx, ws: SearchWorkspace, round_scores: bool = True):
     """One corpus chunk of the exact search WITHOUT its score matrix: rpo_sim_topk_filter (scores in the MFMA accumulators, survivors of
     each row's k-th winner appended to the row's candidate list) + rpo_topk_merge_candidates (lists -> winners).  best_val / best_idx
     [rows, k] are updated in place and must hold k real winners per row; `ws.overflow` is raised when a list ran over (the result is
-    then incomplete: the caller redoes the search through `similarity` + `topk_merge`)."""
+    then incomplete: the caller redoes the search through `similarity` + `topk_merge`).  round_scores: the score is the sum rounded
+    to bf16 once (what `similarity` stores for a bf16 index); False: the f32 sum itself (an f32 index exact in bf16: `similarity_f32`)."""
     _need_gpu(q, p)
     lib = _lib.load()
     if not search_filter_takes(q, p):
@@ -1207,7 +1222,7 @@ def search_step(q, p, col0: int, best_val, best_idx, ws: SearchWorkspace):
         raise ValueError("search_step: best_val / best_idx must be contiguous f32 / int64 [rows, k] matching the workspace")
     with torch.cuda.device(q.device):
         st = _stream(q)
-        check(lib.rpo_sim_topk_filter(q.data_ptr(), p.data_ptr(), rows, p.shape[0], d, int(col0), k, best_val.data_ptr(),
+        check(lib.rpo_sim_topk_filter(q.data_ptr(), p.data_ptr(), rows, p.shape[0], d, int(col0), k, int(bool(round_scores)), best_val.data_ptr(),
                                       best_idx.data_ptr(), ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(),
                                       ws.cap, st), "rpo_sim_topk_filter")
         check(lib.rpo_topk_merge_candidates(ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), rows, ws.cap, k,
@@ -1216,7 +1231,7 @@ def search_step(q, p, col0: int, best_val, best_idx, ws: SearchWorkspace):
     return best_val, best_idx
 
 
-__all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "topk_finish", "search_step", "search_filter_takes", "search_filter_ok", "SearchWorkspace",
+__all__ = ["sim_gemm_nt", "pool_normalize", "topk_merge", "topk_finish", "search_step", "similarity_f32", "search_filter_takes", "search_filter_ok", "SearchWorkspace",
            "search_candidate_cap", "linear", "transpose2d", "wgrad", "infonce_loss", "similarity", "rankpo_loss_metrics", "RankPOConfig", "METRIC_KEYS",
            "swiglu_down", "rope_", "fused_encoder_ops_ok", "add_rmsnorm", "fused_norm_ok",
            "flash_attn_varlen", "flash_attn_varlen_qkv", "last_query_attn", "last_query_attn_ok", "rope_flash_attn_varlen_qkv", "rope_flash_attn_varlen_qkv_fwd", "flash_attn_varlen_fwd", "flash_attn_varlen_bwd", "attn_tile_table", "attn_fwd_tile_table", "recomputing",

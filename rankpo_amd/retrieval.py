@@ -2,7 +2,8 @@
 used by src/evaluate.py and src/get_hard_negatives.py through FAISS `IndexFlatIP`).
 
 `FlatIPIndex.search` is the flat-index search: the corpus is walked in chunks; scores = Q C_chunk^T come from the HIP
-similarity kernel of the hot path (f32 storage -> f32 MFMA, like FAISS' sgemm) and `rpo_topk_merge` folds every chunk's
+similarity kernel of the hot path (f32 storage -> f32 MFMA, like FAISS' sgemm; bf16 MFMA with f32 sums when every value is
+exact in bf16) and `rpo_topk_merge` folds every chunk's
 scores into the k winners per query (value descending, ties by the smaller corpus index) -- the [nq, ntotal] score matrix is
 never materialised, so the corpus size is bounded by the embeddings alone (288 GB of HBM: ~35 M rows of d = 2048 in f32).  `compute_metrics` keeps the reference's definitions (its non-standard Recall denominator
 `max(min(cutoff, len(pred), len(label)), 1)`, the flattened "naive AUC") but computes them on one boolean hit matrix.
@@ -17,8 +18,28 @@ import torch
 from . import ops
 
 
+def exact_in_bf16(x):
+    """x (f32, on the GPU) as bf16 if EVERY value survives f32 -> bf16 -> f32 unchanged, else None.  One device flag, one sync."""
+    if x.dtype != torch.float32 or not x.is_cuda or x.numel() == 0:
+        return None
+    h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    ok = torch.ones((), dtype=torch.bool, device=x.device)
+    step = max(1, (1 << 27) // max(1, x.shape[-1]))                 # ~0.5 GB of f32 per piece
+    for r0 in range(0, x.shape[0], step):
+        piece = x[r0:r0 + step]
+        h[r0:r0 + step] = piece
+        ok &= (h[r0:r0 + step].float() == piece).all()
+    return h if bool(ok.item()) else None
+
+
 class FlatIPIndex:
-    """Stands where the reference builds `faiss.IndexFlatIP` (utils.py:38-51): keeps the corpus embeddings on the GPU."""
+    """Stands where the reference builds `faiss.IndexFlatIP` (utils.py:38-51): keeps the corpus embeddings on the GPU.
+
+    An f32 index (the reference's dtype) whose embeddings are exactly representable in bf16 -- what `ModelForInference.encode` hands
+    over when the encoder computes in bf16, as scripts/evaluate/run_evaluate.sh runs it -- keeps a bf16 copy (`emb16`) and scores
+    queries that are exact in bf16 too with the bf16 MFMA kernel frame: the products are exact in f32 and the sums are f32 sums, i.e.
+    an f32 inner product in that kernel's summation order (as FAISS' sgemm has its own), at 16 x the f32 MFMA rate and with the
+    fused filter step.  Scores stay f32, unrounded.  Anything else (values or queries not exact in bf16) takes the f32 kernel."""
 
     candidate_fill = 0.25       # fused search: expected survivors per row and chunk / candidate slots (chunk_schedule)
 
@@ -34,6 +55,7 @@ class FlatIPIndex:
         self.query_rows_per_pass = 1024
         self.fused = True                   # the fused filter step where it applies (search); False: always through the score matrix
         self.fused_overflows = 0            # searches redone because a candidate list ran over
+        self.emb16 = exact_in_bf16(self.emb) if self.emb.shape[1] % 64 == 0 else None      # f32 index, values exact in bf16: see above
 
     def chunk_schedule(self, nq: int, k: int, fused: bool = True):
         """[(first row, end row)] of the corpus chunks a search of nq query rows walks.  Plain: `chunk_rows` at a time.  Fused: the
@@ -45,7 +67,7 @@ class FlatIPIndex:
         1/8, 1/4, 1/2 full 3.86 / 3.82 / 3.85 ms (gpurun_out/r6_N) -- a chunk with more survivors pays for them in the filter's
         epilogue what it saves in launches.  A tail too small for the kernel is joined to the last chunk."""
         plain = [(c0, min(c0 + self.chunk_rows, self.ntotal)) for c0 in range(0, self.ntotal, self.chunk_rows)]
-        if not fused or self.emb.dtype != torch.bfloat16 or nq <= 0:
+        if not fused or not (self.emb.dtype == torch.bfloat16 or getattr(self, "emb16", None) is not None) or nq <= 0:
             return plain
         first = max(-(-192 // -(-nq // 256)), -(-k // 256)) * 256
         if 2 * first > min(self.chunk_rows, self.ntotal) or not ops.search_filter_ok(nq, first, self.emb.shape[1]):
@@ -77,14 +99,21 @@ class FlatIPIndex:
         # 1024 queries), no second pass over it.  A candidate list that runs over (a corpus whose later rows keep beating everything
         # before them) raises the workspace's flag and the search is redone the plain way.
         fused = self.fused and split == 1
+        # f32 index exact in bf16 + queries exact in bf16: the bf16 kernel frame with f32 scores (class docstring)
+        q16 = exact_in_bf16(q) if self.emb16 is not None and q.shape[0] > 0 else None
+        frame = q16 is not None or self.emb.dtype == torch.bfloat16
         top = idx = ws = None
-        for c0, c1 in self.chunk_schedule(q.shape[0], k, fused):
-            chunk = self.emb[c0:c1]
-            if fused and c0 >= k and ops.search_filter_takes(q, chunk):
+        for c0, c1 in self.chunk_schedule(q.shape[0], k, fused and frame):
+            qq, chunk = (q16, self.emb16[c0:c1]) if q16 is not None else (q, self.emb[c0:c1])
+            takes = frame and ops.search_filter_takes(qq, chunk)
+            if fused and c0 >= k and takes:
                 ws = ws or ops.SearchWorkspace(q.shape[0], k, q.device)
-                ops.search_step(q, chunk, c0, top, idx, ws)
+                ops.search_step(qq, chunk, c0, top, idx, ws, round_scores=q16 is None)
                 continue
-            scores = ops.similarity(q, chunk)                                   # [nq, chunk]  (HIP MFMA kernel)
+            if q16 is not None:                                                 # [nq, chunk] f32: the same frame where it applies, else the f32 kernel
+                scores = ops.similarity_f32(qq, chunk) if takes else ops.similarity(q, self.emb[c0:c1])
+            else:
+                scores = ops.similarity(q, chunk)                               # [nq, chunk]  (HIP MFMA kernel)
             top, idx = ops.topk_merge(scores, c0, top, idx, k, split=split)     # HIP selection kernel
         if ws is not None and int(ws.overflow.item()):
             self.fused_overflows += 1

@@ -765,6 +765,78 @@ def test_fused_search_step_overflow_falls_back_to_the_score_matrix():
     assert int(ws.overflow.item()) == 1 and int(ws.cand_cnt.abs().sum().item()) == 0
 
 
+@pytest.mark.parametrize("nq,ncorpus,d,k,chunk_rows", [(256, 147_404, 128, 100, 49_152), (300, 125_001, 64, 10, 50_000),
+                                                       (1024, 131_072, 256, 100, 65_536), (70, 200_000, 192, 1024, 100_000)])
+def test_f32_index_exact_in_bf16_takes_the_bf16_frame_with_f32_scores(nq, ncorpus, d, k, chunk_rows):
+    """An f32 FlatIPIndex (the reference's faiss dtype) over embeddings that are exact in bf16 -- what encode() of a bf16 encoder hands
+    over -- searched with queries exact in bf16: scored by the bf16 MFMA frame with UNROUNDED f32 sums.  (a) fused step == score-matrix
+    path of the same frame (`similarity_f32`) bit for bit, == the oracle's stable-argsort winners of that score matrix; (b) against the
+    f32 MFMA kernel on the same values (another summation order): the winners' values agree to f32 summation accuracy and every
+    non-selected score is bounded by the k-th winner (the size-independent property), i.e. the same search up to last-bit near-ties;
+    (c) the scores are f32 sums, NOT bf16-rounded."""
+    from oracle.scoring_ref import topk_ref
+    from rankpo_amd import ops
+    from rankpo_amd.retrieval import FlatIPIndex
+    g = torch.Generator(device=DEV).manual_seed(nq + ncorpus + 1)
+    c16 = torch.nn.functional.normalize(torch.randn(ncorpus, d, generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    q16 = torch.nn.functional.normalize(torch.randn(nq, d, generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    corpus, q = c16.float(), q16.float()
+    ix = FlatIPIndex(corpus, device=DEV, chunk_rows=chunk_rows)                      # dtype f32, the default
+    assert ix.emb.dtype == torch.float32 and ix.emb16 is not None and torch.equal(ix.emb16, c16)
+    steps = []
+    real = ops.search_step
+    ops.search_step = lambda *a, **kw: (steps.append((a[2], kw.get("round_scores"))), real(*a, **kw))[1]
+    try:
+        fv, fi = ix.search(q, k)
+    finally:
+        ops.search_step = real
+    sched = ix.chunk_schedule(nq, k)
+    assert steps == [(c0, False) for c0, _ in sched[1:]] and ix.fused_overflows == 0
+    ix.fused = False
+    pv, pi = ix.search(q, k)                                                         # score matrices of the same frame
+    assert torch.equal(fi, pi) and torch.equal(fv, pv)
+    full = torch.cat([ops.similarity_f32(q16, c16[c:c + chunk_rows]) for c in range(0, ncorpus, chunk_rows)], 1)
+    rv, ri = topk_ref(full.cpu().numpy(), k)
+    assert np.array_equal(pi.cpu().numpy(), ri) and np.array_equal(pv.cpu().numpy(), rv)
+    assert not torch.equal(fv, fv.to(torch.bfloat16).float())                        # (c)
+    # (b) the f32 kernel on the same values
+    ix.emb16 = None
+    sv, si = ix.search(q, k)
+    assert float((sv - fv).abs().max()) < 2e-6 * max(1.0, d ** 0.5 / 8)
+    f32_full = torch.cat([ops.similarity(q, corpus[c:c + chunk_rows]) for c in range(0, ncorpus, chunk_rows)], 1)
+    got = torch.gather(f32_full, 1, fi)
+    assert float((got - fv).abs().max()) < 2e-6 * max(1.0, d ** 0.5 / 8)
+    f32_full.scatter_(1, fi, float("-inf"))
+    assert bool((f32_full.max(1).values <= fv[:, -1] + 2e-6 * max(1.0, d ** 0.5 / 8)).all())
+    assert float((si == fi).float().mean()) > 0.99                                   # (near-ties may swap neighbours)
+
+
+def test_f32_index_not_exact_in_bf16_keeps_the_f32_kernel():
+    """Embeddings or queries with more than 8 significant bits: no bf16 copy / no bf16 queries, the f32 kernel scores them as before."""
+    from rankpo_amd import ops
+    from rankpo_amd.retrieval import FlatIPIndex, exact_in_bf16
+    g = torch.Generator(device=DEV).manual_seed(17)
+    corpus = torch.nn.functional.normalize(torch.randn(120_000, 64, generator=g, device=DEV), dim=-1)
+    q = torch.nn.functional.normalize(torch.randn(300, 64, generator=g, device=DEV), dim=-1)
+    assert exact_in_bf16(corpus) is None and exact_in_bf16(corpus.to(torch.bfloat16).float()) is not None
+    calls = []
+    real = ops.search_step
+    ops.search_step = lambda *a, **kw: (calls.append(a[2]), real(*a, **kw))[1]
+    try:
+        a = FlatIPIndex(corpus, device=DEV, chunk_rows=50_000)
+        assert a.emb16 is None
+        av, ai = a.search(q, 10)
+        b = FlatIPIndex(corpus.to(torch.bfloat16).float(), device=DEV, chunk_rows=50_000)      # corpus exact, queries not
+        assert b.emb16 is not None
+        bv, bi = b.search(q, 10)
+    finally:
+        ops.search_step = real
+    assert calls == []
+    b.emb16 = None
+    cv, ci = b.search(q, 10)
+    assert torch.equal(bi, ci) and torch.equal(bv, cv)
+
+
 def test_fused_search_step_argument_checks():
     from rankpo_amd import _lib, ops
     lib = _lib.load()
@@ -773,7 +845,7 @@ def test_fused_search_step_argument_checks():
     bv = torch.zeros(256, 4, device=DEV)
     bi = torch.zeros(256, 4, device=DEV, dtype=torch.int64)
     ws = ops.SearchWorkspace(256, 4, DEV)
-    a = (bv.data_ptr(), bi.data_ptr(), ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), ws.cap, st)
+    a = (1, bv.data_ptr(), bi.data_ptr(), ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), ws.cap, st)      # (round_scores, ...)
     big = torch.zeros(49_152, 128, device=DEV, dtype=torch.bfloat16)
     assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 256, 49_152, 96, 0, 4, *a) == -2       # d % 64
     assert lib.rpo_sim_topk_filter(x.data_ptr() + 2, big.data_ptr(), 255, 49_152, 128, 0, 4, *a) == -2  # alignment
@@ -782,6 +854,12 @@ def test_fused_search_step_argument_checks():
     assert lib.rpo_sim_topk_filter(None, big.data_ptr(), 256, 49_152, 128, 0, 4, *a) == -1
     assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 256, 49_152, 128, -1, 4, *a) == -1
     assert lib.rpo_sim_topk_filter_ok(256, 49_152, 128) == 1 and lib.rpo_sim_topk_filter_ok(256, 49_152, 100) == 0
+    f = torch.zeros(256, 49_152, device=DEV)
+    assert lib.rpo_sim_scores_f32(x.data_ptr(), big.data_ptr(), 256, 49_152, 128, f.data_ptr(), 49_151, st) == -1       # ldc < P
+    assert lib.rpo_sim_scores_f32(x.data_ptr(), big.data_ptr(), 64, 49_152, 128, f.data_ptr(), 49_152, st) == -2        # not the 256 x 256 frame's shape
+    assert lib.rpo_sim_scores_f32(x.data_ptr(), None, 256, 49_152, 128, f.data_ptr(), 49_152, st) == -1
+    with pytest.raises(ValueError):
+        ops.similarity_f32(x[:64], big)
     assert not ops.search_filter_takes(x[:64], big) and ops.search_filter_takes(x, big) and not ops.search_filter_takes(x.float(), big)
     assert lib.rpo_topk_merge_candidates(ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), 256, 4000, 200,
                                          bv.data_ptr(), bi.data_ptr(), ws.overflow.data_ptr(), st) == -2   # k + cap > 4096

@@ -18,6 +18,8 @@ def main():
     ap.add_argument("--queries", type=int, default=1024)
     ap.add_argument("--d", type=int, default=2048)
     ap.add_argument("--k", type=int, default=100)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16", help="f32: the reference's own faiss dtype (score-matrix path)")
+    ap.add_argument("--exact16", action="store_true", help="f32 values that are exact in bf16 (the output of a bf16 encoder)")
     args = ap.parse_args()
     import bench
     import bench_inference as BI
@@ -27,7 +29,8 @@ def main():
     timed = bench.TimedLib(_lib.load())
     _lib._lib = timed
     note = lambda m: print(f"[search_bench {time.strftime('%H:%M:%S')}] {m}", file=sys.stderr, flush=True)
-    out = BI.search_block(device, timed, note, ntotal=args.rows, d=args.d, nq=args.queries, k=args.k)
+    out = BI.search_block(device, timed, note, ntotal=args.rows, d=args.d, nq=args.queries, k=args.k,
+                          dtype=torch.float32 if args.dtype == "f32" else torch.bfloat16, exact16=args.exact16)
     print(json.dumps(out), flush=True)
 
 
