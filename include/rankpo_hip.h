@@ -339,7 +339,7 @@ int rpo_topk_merge(const void* scores, int64_t ld, int64_t rows, int64_t cols, i
 int rpo_topk_merge_split(const void* scores, int64_t ld, int64_t rows, int64_t cols, int64_t col0, int k, int dtype, int split,
                          float* best_val, int64_t* best_idx, int first, rpo_stream_t stream);
 
-/* The search step with the k-selection FUSED into the scoring kernel (round 6; bf16 operands, d a multiple of 64, both operands below
+/* The search step with the k-selection FUSED into the scoring kernel (round 6; bf16 operands -- dtype RPO_DT_BF16 --, d a multiple of 64, both operands below
  * 4 GB): the [Q, P] score matrix of the query block against one corpus chunk (p: rows [col0, col0 + P) of the corpus) is never written.
  * A score -- <q_r, p_c> accumulated in f32, rounded to bf16 once: bit for bit what the eval similarity (rpo_infonce_fwd without
  * temperature) stores -- that beats row r's current k-th winner, (best_val, best_idx)[r k + k - 1] in the order of rpo_topk_merge,
@@ -354,15 +354,17 @@ int rpo_topk_merge_split(const void* scores, int64_t ld, int64_t rows, int64_t c
  * frame (more than 64 query rows, d % 64 == 0, >= 192 tiles, operands below 4 GB), so that the fused step and the score-matrix path
  * agree bit for bit; everything else returns RPO_ERR_UNSUPPORTED and stays on the score-matrix path. */
 int rpo_sim_topk_filter_ok(int64_t Q, int64_t P, int64_t d);
-int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int64_t col0, int k, int round_scores,
-                        const float* best_val, const int64_t* best_idx, float* cand_val, int64_t* cand_idx, int32_t* cand_cnt,
-                        int cap, rpo_stream_t stream);
+int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int dtype, int64_t col0, int k,
+                        int round_scores, const float* best_val, const int64_t* best_idx, float* cand_val, int64_t* cand_idx,
+                        int32_t* cand_cnt, int cap, rpo_stream_t stream);
 /* round_scores = 0 and rpo_sim_scores_f32: the search of an F32 index (the reference's faiss.IndexFlatIP dtype, utils.py:38-51) whose
- * embeddings are exactly representable in bf16 -- what an encoder that computes in bf16 hands over.  Products of bf16 values are
- * exact in f32 and the sums are f32 sums: an f32 inner product in this kernel's summation order, at the bf16 MFMA rate (16 x the
- * f32 MFMA's).  The score is the unrounded f32 sum; rpo_sim_scores_f32 writes the [Q, P] score matrix (row stride ldc floats) of
- * the same frame for the search's first chunk, so that equal rows score equal wherever they lie.  Same shapes as the filter. */
-int rpo_sim_scores_f32(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, float* scores, int64_t ldc, rpo_stream_t stream);
+ * embeddings are exactly representable in bf16 (dtype RPO_DT_BF16) or fp16 (RPO_DT_F16; f32 scores only) -- what an encoder that
+ * computes in bf16 / fp16 hands over (modeling.py:533-539).  Products of such values are exact in f32 and the sums are f32 sums: an
+ * f32 inner product in this kernel's summation order, at the 16-bit MFMA rate (16 x the f32 MFMA's).  The score is the unrounded
+ * f32 sum; rpo_sim_scores_f32 writes the [Q, P] score matrix (row stride ldc floats) of the same frame for the search's first
+ * chunk, so that equal rows score equal wherever they lie.  Same shapes as the filter. */
+int rpo_sim_scores_f32(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int dtype, float* scores, int64_t ldc,
+                       rpo_stream_t stream);
 int rpo_topk_merge_candidates(const float* cand_val, const int64_t* cand_idx, int32_t* cand_cnt, int64_t rows, int cap, int k,
                               float* best_val, int64_t* best_idx, int32_t* overflow, rpo_stream_t stream);
 

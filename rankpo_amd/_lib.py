@@ -61,8 +61,8 @@ SIGNATURES = {
     "rpo_topk_merge": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _i32, _vp]),
     "rpo_topk_merge_split": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "rpo_sim_topk_filter_ok": (C.c_int, [_i64, _i64, _i64]),
-    "rpo_sim_topk_filter": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
-    "rpo_sim_scores_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _vp]),
+    "rpo_sim_topk_filter": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
+    "rpo_sim_scores_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _i64, _vp]),
     "rpo_topk_merge_candidates": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp]),
     "rpo_swiglu_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),
     "rpo_swiglu_bwd_t": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i32, _vp]),

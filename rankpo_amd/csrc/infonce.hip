@@ -354,6 +354,7 @@ __device__ __forceinline__ int big_unit_row(int unit, int u) {
 // EPI = 3: EPI 2 on the UNROUNDED f32 accumulators -- the search step of an f32 index whose embeddings are exactly representable in
 // bf16 (what an encoder that computes in bf16 hands over): the bf16 products are exact, the sums are f32 sums, i.e. an f32 inner
 // product in this frame's summation order at 16 x the f32 MFMA rate.
+//          (F16 = true: the same for values exact in fp16 -- an fp16 encoder's output -- with the f16 MFMA.)
 // EPI = 4: the score matrix of the same problem as f32 (`scores` is a float*, ldc its row stride in elements), direct 16-byte
 // stores: the first chunk of such a search (small), so that every score of it comes out of ONE summation order.
 struct SimFilter {
@@ -367,7 +368,16 @@ struct SimFilter {
 };
 constexpr int kBigThrOff = 2 * kBigBufBytes;      // EPI 2: float tv[256] | long long ti[256] (3 KiB of the 10 KiB behind the ring)
 
-template <int EPI>
+// F16 (EPI 3 / 4 only: the outputs are f32): the operands are fp16 -- the same 2-byte staging and fragment layout, v_mfma_f32_16x16x32_f16.
+template <bool F16>
+__device__ __forceinline__ float4_t big_mma(const short8_t a, const short8_t b, const float4_t c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(half8_t, a), __builtin_bit_cast(half8_t, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int EPI, bool F16 = false>
 __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ p, int64_t Q, int64_t P, int64_t d, int64_t lda, int64_t ldb,
     int64_t ldc, float temperature, int scale, int do_stats_arg, bf16_t* __restrict__ scores, float2* __restrict__ partial,
@@ -512,7 +522,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][h], b0[n][h], acc[m][n], 0, 0, 0);
+                    acc[m][n] = big_mma<F16>(a[m][h], b0[n][h], acc[m][n]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         // ---------------- phase 1
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc[m][2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][h], b1[n][h], acc[m][2 + n], 0, 0, 0);
+                    acc[m][2 + n] = big_mma<F16>(a[m][h], b1[n][h], acc[m][2 + n]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         // ---------------- phase 2
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc[4 + m][2 + n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][h], b1[n][h], acc[4 + m][2 + n], 0, 0, 0);
+                    acc[4 + m][2 + n] = big_mma<F16>(a[m][h], b1[n][h], acc[4 + m][2 + n]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
         // ---------------- phase 3
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(kBigThreads, 2) void sim_tile256_kernel(
             for (int m = 0; m < 4; ++m)
 #pragma unroll
                 for (int n = 0; n < 2; ++n)
-                    acc[4 + m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][h], b0[n][h], acc[4 + m][n], 0, 0, 0);
+                    acc[4 + m][n] = big_mma<F16>(a[m][h], b0[n][h], acc[4 + m][n]);
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_s_barrier();
     }
@@ -1782,12 +1792,13 @@ extern "C" int rpo_sim_topk_filter_ok(int64_t Q, int64_t P, int64_t d) {
     return make_plan(Q, P, d, RPO_DT_BF16, /*aligned=*/true).path == PATH_TILE256 ? 1 : 0;
 }
 
-extern "C" int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int64_t col0, int k,
+extern "C" int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int dtype, int64_t col0, int k,
                                    int round_scores, const float* best_val, const int64_t* best_idx, float* cand_val,
                                    int64_t* cand_idx, int32_t* cand_cnt, int cap, rpo_stream_t stream) {
     if (!q || !p || !best_val || !best_idx || !cand_val || !cand_idx || !cand_cnt || Q <= 0 || P <= 0 || d <= 0 || col0 < 0 ||
-        k <= 0 || cap <= 0)
+        k <= 0 || cap <= 0 || (dtype != RPO_DT_BF16 && dtype != RPO_DT_F16))
         return RPO_ERR_INVALID_ARG;
+    if (dtype == RPO_DT_F16 && round_scores) return RPO_ERR_UNSUPPORTED;        // fp16 operands: f32 scores only
     if (!rpo_aligned16(q) || !rpo_aligned16(p) || !rpo_sim_topk_filter_ok(Q, P, d)) return RPO_ERR_UNSUPPORTED;
     const int64_t nPt = rpo_cdiv(P, kBigTile), nQt = rpo_cdiv(Q, kBigTile);
     if (nPt * nQt > 0x7fffffff) return RPO_ERR_UNSUPPORTED;
@@ -1795,37 +1806,46 @@ extern "C" int rpo_sim_topk_filter(const void* q, const void* p, int64_t Q, int6
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
         (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
+        (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
         attr_set = true;
     }
     SimFilter flt{best_val, (const long long*)best_idx, cand_val, (long long*)cand_idx, cand_cnt, col0, k, cap};
     const dim3 grid((unsigned)std::min<int64_t>(nPt * nQt, kBigPersistBlocks));
-    if (round_scores)
-        RPO_LAUNCH(sim_tile256_kernel<2>, grid, dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)q,
-                   (const bf16_t*)p, Q, P, d, d, d, P, 1.0f, 0, 0, (bf16_t*)nullptr, (float2*)nullptr, (int)nPt, (int)nQt,
-                   /*stagger=*/1, /*dbg=*/0, flt);
-    else
-        RPO_LAUNCH(sim_tile256_kernel<3>, grid, dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)q,
-                   (const bf16_t*)p, Q, P, d, d, d, P, 1.0f, 0, 0, (bf16_t*)nullptr, (float2*)nullptr, (int)nPt, (int)nQt,
-                   /*stagger=*/1, /*dbg=*/0, flt);
+#define RPO_FILTER_LAUNCH(...)                                                                                                   \
+    RPO_LAUNCH((sim_tile256_kernel<__VA_ARGS__>), grid, dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)q, \
+               (const bf16_t*)p, Q, P, d, d, d, P, 1.0f, 0, 0, (bf16_t*)nullptr, (float2*)nullptr, (int)nPt, (int)nQt,          \
+               /*stagger=*/1, /*dbg=*/0, flt)
+    if (dtype == RPO_DT_F16) RPO_FILTER_LAUNCH(3, true);
+    else if (round_scores) RPO_FILTER_LAUNCH(2);
+    else RPO_FILTER_LAUNCH(3);
+#undef RPO_FILTER_LAUNCH
     return rpo_launch_status();
 }
 
-// scores f32 [Q, P] (row stride ldc) = q [Q, d] p [P, d]^T, bf16 operands, f32 sums UNROUNDED, in the 256 x 256 frame's summation
-// order (sim_tile256_kernel<4>): the score matrix that goes with rpo_sim_topk_filter(round_scores = 0); same shapes.
-extern "C" int rpo_sim_scores_f32(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, float* scores, int64_t ldc,
+// scores f32 [Q, P] (row stride ldc) = q [Q, d] p [P, d]^T, bf16 or fp16 operands, f32 sums UNROUNDED, in the 256 x 256 frame's
+// summation order (sim_tile256_kernel<4>): the score matrix that goes with rpo_sim_topk_filter(round_scores = 0); same shapes.
+extern "C" int rpo_sim_scores_f32(const void* q, const void* p, int64_t Q, int64_t P, int64_t d, int dtype, float* scores, int64_t ldc,
                                   rpo_stream_t stream) {
-    if (!q || !p || !scores || Q <= 0 || P <= 0 || d <= 0 || ldc < P) return RPO_ERR_INVALID_ARG;
+    if (!q || !p || !scores || Q <= 0 || P <= 0 || d <= 0 || ldc < P || (dtype != RPO_DT_BF16 && dtype != RPO_DT_F16))
+        return RPO_ERR_INVALID_ARG;
     if (!rpo_aligned16(q) || !rpo_aligned16(p) || !rpo_sim_topk_filter_ok(Q, P, d)) return RPO_ERR_UNSUPPORTED;
     const int64_t nPt = rpo_cdiv(P, kBigTile), nQt = rpo_cdiv(Q, kBigTile);
     if (nPt * nQt > 0x7fffffff) return RPO_ERR_UNSUPPORTED;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
+        (void)hipFuncSetAttribute((const void*)sim_tile256_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLdsBytes);
         attr_set = true;
     }
-    RPO_LAUNCH(sim_tile256_kernel<4>, dim3((unsigned)std::min<int64_t>(nPt * nQt, kBigPersistBlocks)), dim3(kBigThreads), kBigLdsBytes,
-               (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)p, Q, P, d, d, d, ldc, 1.0f, 0, 0, (bf16_t*)scores,
-               (float2*)nullptr, (int)nPt, (int)nQt, /*stagger=*/1, /*dbg=*/0, SimFilter{});
+    const dim3 grid((unsigned)std::min<int64_t>(nPt * nQt, kBigPersistBlocks));
+    if (dtype == RPO_DT_F16)
+        RPO_LAUNCH((sim_tile256_kernel<4, true>), grid, dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)q,
+                   (const bf16_t*)p, Q, P, d, d, d, ldc, 1.0f, 0, 0, (bf16_t*)scores, (float2*)nullptr, (int)nPt, (int)nQt,
+                   /*stagger=*/1, /*dbg=*/0, SimFilter{});
+    else
+        RPO_LAUNCH((sim_tile256_kernel<4>), grid, dim3(kBigThreads), kBigLdsBytes, (hipStream_t)stream, (const bf16_t*)q,
+                   (const bf16_t*)p, Q, P, d, d, d, ldc, 1.0f, 0, 0, (bf16_t*)scores, (float2*)nullptr, (int)nPt, (int)nQt,
+                   /*stagger=*/1, /*dbg=*/0, SimFilter{});
     return rpo_launch_status();
 }
 

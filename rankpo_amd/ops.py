@@ -1171,9 +1171,10 @@ def search_filter_ok(nq: int, rows: int, d: int) -> bool:
 
 
 def search_filter_takes(q, p) -> bool:
-    """Shapes rpo_sim_topk_filter takes: bf16 rows, 16-byte aligned, and a problem `similarity` scores with the same 256 x 256 kernel
-    (rpo_sim_topk_filter_ok: > 64 query rows, d % 64 == 0, >= 192 tiles, operands below 4 GB) -- so the fused step changes no bit."""
-    if not (q.dtype == torch.bfloat16 and p.dtype == torch.bfloat16 and q.dim() == 2 and p.dim() == 2 and q.is_contiguous()
+    """Shapes rpo_sim_topk_filter takes: bf16 (or, with f32 scores, fp16) rows, 16-byte aligned, and a problem `similarity` scores
+    with the same 256 x 256 kernel (rpo_sim_topk_filter_ok: > 64 query rows, d % 64 == 0, >= 192 tiles, operands below 4 GB) -- so
+    the fused step changes no bit."""
+    if not (q.dtype in (torch.bfloat16, torch.float16) and p.dtype == q.dtype and q.dim() == 2 and p.dim() == 2 and q.is_contiguous()
             and p.is_contiguous() and q.shape[1] == p.shape[1] and q.data_ptr() % 16 == 0 and p.data_ptr() % 16 == 0):
         return False
     return bool(_lib.load().rpo_sim_topk_filter_ok(q.shape[0], p.shape[0], q.shape[1]))
@@ -1192,7 +1193,7 @@ class SearchWorkspace:
 
 
 def similarity_f32(q, p):
-    """f32 scores [Q, P] of bf16 operands, UNROUNDED f32 sums in the 256 x 256 scoring frame's summation order (rpo_sim_scores_f32):
+    """f32 scores [Q, P] of bf16 (or fp16) operands, UNROUNDED f32 sums in the 256 x 256 scoring frame's summation order (rpo_sim_scores_f32):
     the score matrix of an f32 index whose embeddings are exact in bf16 (retrieval.FlatIPIndex).  Shapes: search_filter_takes."""
     _need_gpu(q, p)
     lib = _lib.load()
@@ -1200,8 +1201,8 @@ def similarity_f32(q, p):
         raise ValueError("similarity_f32: bf16 [rows, d] operands of a shape the 256 x 256 scoring kernel takes (search_filter_takes)")
     scores = torch.empty((q.shape[0], p.shape[0]), dtype=torch.float32, device=q.device)
     with torch.cuda.device(q.device):
-        check(lib.rpo_sim_scores_f32(q.data_ptr(), p.data_ptr(), q.shape[0], p.shape[0], q.shape[1], scores.data_ptr(), scores.stride(0),
-                                     _stream(q)), "rpo_sim_scores_f32")
+        check(lib.rpo_sim_scores_f32(q.data_ptr(), p.data_ptr(), q.shape[0], p.shape[0], q.shape[1], _dt(q), scores.data_ptr(),
+                                     scores.stride(0), _stream(q)), "rpo_sim_scores_f32")
     return scores
 
 
@@ -1213,8 +1214,9 @@ def search_step(q, p, col0: int, best_val, best_idx, ws: SearchWorkspace, round_
     to bf16 once (what `similarity` stores for a bf16 index); False: the f32 sum itself (an f32 index exact in bf16: `similarity_f32`)."""
     _need_gpu(q, p)
     lib = _lib.load()
-    if not search_filter_takes(q, p):
-        raise ValueError("search_step: bf16 [rows, d] operands of a shape the 256 x 256 scoring kernel takes (search_filter_takes)")
+    if not search_filter_takes(q, p) or (q.dtype == torch.float16 and round_scores):
+        raise ValueError("search_step: bf16 [rows, d] operands (fp16 with round_scores=False) of a shape the 256 x 256 scoring kernel takes "
+                         "(search_filter_takes)")
     rows, d = q.shape
     k = best_val.shape[1]
     if (ws.rows, ws.k) != (rows, k) or best_val.shape != (rows, k) or best_idx.shape != (rows, k) or not best_val.is_contiguous() \
@@ -1222,7 +1224,7 @@ def search_step(q, p, col0: int, best_val, best_idx, ws: SearchWorkspace, round_
         raise ValueError("search_step: best_val / best_idx must be contiguous f32 / int64 [rows, k] matching the workspace")
     with torch.cuda.device(q.device):
         st = _stream(q)
-        check(lib.rpo_sim_topk_filter(q.data_ptr(), p.data_ptr(), rows, p.shape[0], d, int(col0), k, int(bool(round_scores)), best_val.data_ptr(),
+        check(lib.rpo_sim_topk_filter(q.data_ptr(), p.data_ptr(), rows, p.shape[0], d, _dt(q), int(col0), k, int(bool(round_scores)), best_val.data_ptr(),
                                       best_idx.data_ptr(), ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(),
                                       ws.cap, st), "rpo_sim_topk_filter")
         check(lib.rpo_topk_merge_candidates(ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), rows, ws.cap, k,

@@ -18,11 +18,13 @@ import torch
 from . import ops
 
 
-def exact_in_bf16(x):
-    """x (f32, on the GPU) as bf16 if EVERY value survives f32 -> bf16 -> f32 unchanged, else None.  One device flag, one sync."""
+def exact_in_16(x, dtype=torch.bfloat16):
+    """x (f32, on the GPU) as `dtype` (bf16 / fp16) if EVERY value survives f32 -> dtype -> f32 unchanged, else None.  fp16 subnormals
+    count as exact: v_mfma_f32_16x16x32_f16 multiplies them exactly (tests/test_gpu_kernels.py pins that; a normalized d = 384
+    embedding has one in a thousand values below 2^-14).  One device flag, one sync."""
     if x.dtype != torch.float32 or not x.is_cuda or x.numel() == 0:
         return None
-    h = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    h = torch.empty(x.shape, dtype=dtype, device=x.device)
     ok = torch.ones((), dtype=torch.bool, device=x.device)
     step = max(1, (1 << 27) // max(1, x.shape[-1]))                 # ~0.5 GB of f32 per piece
     for r0 in range(0, x.shape[0], step):
@@ -32,12 +34,16 @@ def exact_in_bf16(x):
     return h if bool(ok.item()) else None
 
 
+def exact_in_bf16(x):
+    return exact_in_16(x, torch.bfloat16)
+
+
 class FlatIPIndex:
     """Stands where the reference builds `faiss.IndexFlatIP` (utils.py:38-51): keeps the corpus embeddings on the GPU.
 
     An f32 index (the reference's dtype) whose embeddings are exactly representable in bf16 -- what `ModelForInference.encode` hands
-    over when the encoder computes in bf16, as scripts/evaluate/run_evaluate.sh runs it -- keeps a bf16 copy (`emb16`) and scores
-    queries that are exact in bf16 too with the bf16 MFMA kernel frame: the products are exact in f32 and the sums are f32 sums, i.e.
+    over when the encoder computes in bf16, as scripts/evaluate/run_evaluate.sh runs it -- or in fp16 (`use_fp16`, the BGE setup) keeps
+    a 16-bit copy (`emb16`) and scores queries that are exact in that type too with the 16-bit MFMA kernel frame: the products are exact in f32 and the sums are f32 sums, i.e.
     an f32 inner product in that kernel's summation order (as FAISS' sgemm has its own), at 16 x the f32 MFMA rate and with the
     fused filter step.  Scores stay f32, unrounded.  Anything else (values or queries not exact in bf16) takes the f32 kernel."""
 
@@ -55,7 +61,12 @@ class FlatIPIndex:
         self.query_rows_per_pass = 1024
         self.fused = True                   # the fused filter step where it applies (search); False: always through the score matrix
         self.fused_overflows = 0            # searches redone because a candidate list ran over
-        self.emb16 = exact_in_bf16(self.emb) if self.emb.shape[1] % 64 == 0 else None      # f32 index, values exact in bf16: see above
+        # f32 index, values exact in bf16 (a --bf16 encoder run) or in fp16 (--fp16): see above
+        self.emb16 = None
+        if self.emb.shape[1] % 64 == 0:
+            self.emb16 = exact_in_16(self.emb, torch.bfloat16)
+            if self.emb16 is None:
+                self.emb16 = exact_in_16(self.emb, torch.float16)
 
     def chunk_schedule(self, nq: int, k: int, fused: bool = True):
         """[(first row, end row)] of the corpus chunks a search of nq query rows walks.  Plain: `chunk_rows` at a time.  Fused: the
@@ -100,7 +111,7 @@ class FlatIPIndex:
         # before them) raises the workspace's flag and the search is redone the plain way.
         fused = self.fused and split == 1
         # f32 index exact in bf16 + queries exact in bf16: the bf16 kernel frame with f32 scores (class docstring)
-        q16 = exact_in_bf16(q) if self.emb16 is not None and q.shape[0] > 0 else None
+        q16 = exact_in_16(q, self.emb16.dtype) if self.emb16 is not None and q.shape[0] > 0 else None
         frame = q16 is not None or self.emb.dtype == torch.bfloat16
         top = idx = ws = None
         for c0, c1 in self.chunk_schedule(q.shape[0], k, fused and frame):

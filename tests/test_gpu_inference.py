@@ -142,6 +142,14 @@ def test_model_for_inference_encode_bf16_fast_path(hd):
     assert (whole.float().cpu() - torch.tensor(out)).abs().max() < 2.0 ** -7    # same arithmetic on other GEMM shapes: a bf16 ulp
     one = inf.encode(texts[3], max_length=384)
     assert one.shape == (512,) and np.abs(one - out[3]).max() < 2.0 ** -7
+    # what a --bf16 run hands to create_faiss_index (reference evaluate.py / get_hard_negatives.py): f32 numpy, every value exact in
+    # bf16 -- the premise of the f32 index's bf16 kernel frame (retrieval.FlatIPIndex.emb16)
+    from rankpo_amd.retrieval import create_faiss_index, faiss_search
+    index = create_faiss_index(out, device=DEV)
+    assert index.emb.dtype == torch.float32 and index.emb16 is not None and torch.equal(index.emb16.float(), index.emb)
+    sc, ids = faiss_search(index, out[:5], topk=3)
+    self_score = (out[:5].astype(np.float64) ** 2).sum(1)
+    assert sc.shape == (5, 3) and ids.shape == (5, 3) and (np.diff(sc, axis=1) <= 0).all() and (sc[:, 0] >= self_score - 1e-5).all()
 
 
 @pytest.mark.parametrize("hd", [64, 128])

@@ -765,9 +765,10 @@ def test_fused_search_step_overflow_falls_back_to_the_score_matrix():
     assert int(ws.overflow.item()) == 1 and int(ws.cand_cnt.abs().sum().item()) == 0
 
 
+@pytest.mark.parametrize("t16", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("nq,ncorpus,d,k,chunk_rows", [(256, 147_404, 128, 100, 49_152), (300, 125_001, 64, 10, 50_000),
                                                        (1024, 131_072, 256, 100, 65_536), (70, 200_000, 192, 1024, 100_000)])
-def test_f32_index_exact_in_bf16_takes_the_bf16_frame_with_f32_scores(nq, ncorpus, d, k, chunk_rows):
+def test_f32_index_exact_in_bf16_takes_the_bf16_frame_with_f32_scores(nq, ncorpus, d, k, chunk_rows, t16):
     """An f32 FlatIPIndex (the reference's faiss dtype) over embeddings that are exact in bf16 -- what encode() of a bf16 encoder hands
     over -- searched with queries exact in bf16: scored by the bf16 MFMA frame with UNROUNDED f32 sums.  (a) fused step == score-matrix
     path of the same frame (`similarity_f32`) bit for bit, == the oracle's stable-argsort winners of that score matrix; (b) against the
@@ -778,11 +779,13 @@ def test_f32_index_exact_in_bf16_takes_the_bf16_frame_with_f32_scores(nq, ncorpu
     from rankpo_amd import ops
     from rankpo_amd.retrieval import FlatIPIndex
     g = torch.Generator(device=DEV).manual_seed(nq + ncorpus + 1)
-    c16 = torch.nn.functional.normalize(torch.randn(ncorpus, d, generator=g, device=DEV), dim=-1).to(torch.bfloat16)
-    q16 = torch.nn.functional.normalize(torch.randn(nq, d, generator=g, device=DEV), dim=-1).to(torch.bfloat16)
+    c16 = torch.nn.functional.normalize(torch.randn(ncorpus, d, generator=g, device=DEV), dim=-1).to(t16)
+    q16 = torch.nn.functional.normalize(torch.randn(nq, d, generator=g, device=DEV), dim=-1).to(t16)
+    if t16 == torch.float16:                                                         # (fp16: an fp16 encoder's output, subnormals included)
+        assert int(((c16 != 0) & (c16.abs() < 2.0 ** -14)).sum()) > 0
     corpus, q = c16.float(), q16.float()
     ix = FlatIPIndex(corpus, device=DEV, chunk_rows=chunk_rows)                      # dtype f32, the default
-    assert ix.emb.dtype == torch.float32 and ix.emb16 is not None and torch.equal(ix.emb16, c16)
+    assert ix.emb.dtype == torch.float32 and ix.emb16 is not None and ix.emb16.dtype == t16 and torch.equal(ix.emb16, c16)
     steps = []
     real = ops.search_step
     ops.search_step = lambda *a, **kw: (steps.append((a[2], kw.get("round_scores"))), real(*a, **kw))[1]
@@ -798,7 +801,7 @@ def test_f32_index_exact_in_bf16_takes_the_bf16_frame_with_f32_scores(nq, ncorpu
     full = torch.cat([ops.similarity_f32(q16, c16[c:c + chunk_rows]) for c in range(0, ncorpus, chunk_rows)], 1)
     rv, ri = topk_ref(full.cpu().numpy(), k)
     assert np.array_equal(pi.cpu().numpy(), ri) and np.array_equal(pv.cpu().numpy(), rv)
-    assert not torch.equal(fv, fv.to(torch.bfloat16).float())                        # (c)
+    assert not torch.equal(fv, fv.to(t16).float())                                   # (c)
     # (b) the f32 kernel on the same values
     ix.emb16 = None
     sv, si = ix.search(q, k)
@@ -811,6 +814,19 @@ def test_f32_index_exact_in_bf16_takes_the_bf16_frame_with_f32_scores(nq, ncorpu
     assert float((si == fi).float().mean()) > 0.99                                   # (near-ties may swap neighbours)
 
 
+def test_f16_mfma_multiplies_subnormal_operands_exactly():
+    """The premise of an f32 index exact in fp16 (retrieval.exact_in_16 admits fp16 subnormals): v_mfma_f32_16x16x32_f16 does not flush
+    them.  q = 2^-16 (subnormal) x p = 1, and subnormal x subnormal: every score is the exact product sum."""
+    from rankpo_amd import ops
+    d = 64
+    q = torch.full((256, d), 2.0 ** -16, device=DEV, dtype=torch.float16)
+    p = torch.ones((49_152, d), device=DEV, dtype=torch.float16)
+    s = ops.similarity_f32(q, p)
+    assert float(s.min()) == d * 2.0 ** -16 == float(s.max())
+    s = ops.similarity_f32(q * 2.0 ** -4, p * 2.0 ** -18)
+    assert float(s.min()) == d * 2.0 ** -38 == float(s.max())
+
+
 def test_f32_index_not_exact_in_bf16_keeps_the_f32_kernel():
     """Embeddings or queries with more than 8 significant bits: no bf16 copy / no bf16 queries, the f32 kernel scores them as before."""
     from rankpo_amd import ops
@@ -818,7 +834,10 @@ def test_f32_index_not_exact_in_bf16_keeps_the_f32_kernel():
     g = torch.Generator(device=DEV).manual_seed(17)
     corpus = torch.nn.functional.normalize(torch.randn(120_000, 64, generator=g, device=DEV), dim=-1)
     q = torch.nn.functional.normalize(torch.randn(300, 64, generator=g, device=DEV), dim=-1)
+    from rankpo_amd.retrieval import exact_in_16
     assert exact_in_bf16(corpus) is None and exact_in_bf16(corpus.to(torch.bfloat16).float()) is not None
+    h = corpus.half()
+    assert exact_in_16(corpus, torch.float16) is None and exact_in_16(h.float(), torch.float16) is not None and exact_in_bf16(h.float()) is None
     calls = []
     real = ops.search_step
     ops.search_step = lambda *a, **kw: (calls.append(a[2]), real(*a, **kw))[1]
@@ -845,22 +864,30 @@ def test_fused_search_step_argument_checks():
     bv = torch.zeros(256, 4, device=DEV)
     bi = torch.zeros(256, 4, device=DEV, dtype=torch.int64)
     ws = ops.SearchWorkspace(256, 4, DEV)
-    a = (1, bv.data_ptr(), bi.data_ptr(), ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), ws.cap, st)      # (round_scores, ...)
+    a = (bv.data_ptr(), bi.data_ptr(), ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), ws.cap, st)
     big = torch.zeros(49_152, 128, device=DEV, dtype=torch.bfloat16)
-    assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 256, 49_152, 96, 0, 4, *a) == -2       # d % 64
-    assert lib.rpo_sim_topk_filter(x.data_ptr() + 2, big.data_ptr(), 255, 49_152, 128, 0, 4, *a) == -2  # alignment
-    assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 256, 49_152 - 256, 128, 0, 4, *a) == -2    # < 192 tiles: another kernel scores it
-    assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 64, 49_152, 128, 0, 4, *a) == -2       # <= 64 query rows: the skinny kernel
-    assert lib.rpo_sim_topk_filter(None, big.data_ptr(), 256, 49_152, 128, 0, 4, *a) == -1
-    assert lib.rpo_sim_topk_filter(x.data_ptr(), big.data_ptr(), 256, 49_152, 128, -1, 4, *a) == -1
+    BF, F16 = 1, 2                                                                                       # RPO_DT_BF16, RPO_DT_F16
+    filt = lambda q_, Q, P, d, dt=BF, col0=0, rnd=1: lib.rpo_sim_topk_filter(q_, big.data_ptr(), Q, P, d, dt, col0, 4, rnd, *a)
+    assert filt(x.data_ptr(), 256, 49_152, 96) == -2                 # d % 64
+    assert filt(x.data_ptr() + 2, 255, 49_152, 128) == -2            # alignment
+    assert filt(x.data_ptr(), 256, 49_152 - 256, 128) == -2          # < 192 tiles: another kernel scores it
+    assert filt(x.data_ptr(), 64, 49_152, 128) == -2                 # <= 64 query rows: the skinny kernel
+    assert filt(None, 256, 49_152, 128) == -1
+    assert filt(x.data_ptr(), 256, 49_152, 128, col0=-1) == -1
+    assert filt(x.data_ptr(), 256, 49_152, 128, dt=0) == -1          # f32 operands: not this kernel's
+    assert filt(x.data_ptr(), 256, 49_152, 128, dt=F16, rnd=1) == -2     # fp16 operands: f32 scores only
     assert lib.rpo_sim_topk_filter_ok(256, 49_152, 128) == 1 and lib.rpo_sim_topk_filter_ok(256, 49_152, 100) == 0
     f = torch.zeros(256, 49_152, device=DEV)
-    assert lib.rpo_sim_scores_f32(x.data_ptr(), big.data_ptr(), 256, 49_152, 128, f.data_ptr(), 49_151, st) == -1       # ldc < P
-    assert lib.rpo_sim_scores_f32(x.data_ptr(), big.data_ptr(), 64, 49_152, 128, f.data_ptr(), 49_152, st) == -2        # not the 256 x 256 frame's shape
-    assert lib.rpo_sim_scores_f32(x.data_ptr(), None, 256, 49_152, 128, f.data_ptr(), 49_152, st) == -1
+    assert lib.rpo_sim_scores_f32(x.data_ptr(), big.data_ptr(), 256, 49_152, 128, BF, f.data_ptr(), 49_151, st) == -1       # ldc < P
+    assert lib.rpo_sim_scores_f32(x.data_ptr(), big.data_ptr(), 64, 49_152, 128, BF, f.data_ptr(), 49_152, st) == -2        # not the frame's shape
+    assert lib.rpo_sim_scores_f32(x.data_ptr(), None, 256, 49_152, 128, BF, f.data_ptr(), 49_152, st) == -1
+    assert lib.rpo_sim_scores_f32(x.data_ptr(), big.data_ptr(), 256, 49_152, 128, 0, f.data_ptr(), 49_152, st) == -1
     with pytest.raises(ValueError):
         ops.similarity_f32(x[:64], big)
+    with pytest.raises(ValueError):
+        ops.search_step(x.half(), big.half(), 0, bv, bi, ws)             # fp16 operands with rounded scores
     assert not ops.search_filter_takes(x[:64], big) and ops.search_filter_takes(x, big) and not ops.search_filter_takes(x.float(), big)
+    assert ops.search_filter_takes(x.half(), big.half()) and not ops.search_filter_takes(x.half(), big)
     assert lib.rpo_topk_merge_candidates(ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), 256, 4000, 200,
                                          bv.data_ptr(), bi.data_ptr(), ws.overflow.data_ptr(), st) == -2   # k + cap > 4096
     assert lib.rpo_topk_merge_candidates(ws.cand_val.data_ptr(), ws.cand_idx.data_ptr(), ws.cand_cnt.data_ptr(), 256, ws.cap, 4,
