@@ -5,7 +5,8 @@ used by src/evaluate.py and src/get_hard_negatives.py through FAISS `IndexFlatIP
 similarity kernel of the hot path (f32 storage -> f32 MFMA, like FAISS' sgemm; bf16 MFMA with f32 sums when every value is
 exact in bf16) and `rpo_topk_merge` folds every chunk's
 scores into the k winners per query (value descending, ties by the smaller corpus index) -- the [nq, ntotal] score matrix is
-never materialised, so the corpus size is bounded by the embeddings alone (288 GB of HBM: ~35 M rows of d = 2048 in f32).  `compute_metrics` keeps the reference's definitions (its non-standard Recall denominator
+never materialised, so the corpus size is bounded by the embeddings alone (288 GB of HBM: ~35 M rows of d = 2048 in f32; the
+16-bit copy of an f32 index that is exact in bf16 / fp16 is taken only while it fits beside it).  `compute_metrics` keeps the reference's definitions (its non-standard Recall denominator
 `max(min(cutoff, len(pred), len(label)), 1)`, the flattened "naive AUC") but computes them on one boolean hit matrix.
 """
 from __future__ import annotations
@@ -24,6 +25,9 @@ def exact_in_16(x, dtype=torch.bfloat16):
     embedding has one in a thousand values below 2^-14).  One device flag, one sync."""
     if x.dtype != torch.float32 or not x.is_cuda or x.numel() == 0:
         return None
+    free, _ = torch.cuda.mem_get_info(x.device)
+    if free + torch.cuda.memory_reserved(x.device) - torch.cuda.memory_allocated(x.device) < 2 * x.numel() + (2 << 30):
+        return None                                                 # an index that fills the HBM keeps its one copy and the f32 kernel
     h = torch.empty(x.shape, dtype=dtype, device=x.device)
     ok = torch.ones((), dtype=torch.bool, device=x.device)
     step = max(1, (1 << 27) // max(1, x.shape[-1]))                 # ~0.5 GB of f32 per piece
@@ -49,7 +53,7 @@ class FlatIPIndex:
 
     candidate_fill = 0.25       # fused search: expected survivors per row and chunk / candidate slots (chunk_schedule)
 
-    def __init__(self, embeddings, device="cuda:0", dtype=torch.float32, chunk_rows: int = 262144, split=None):
+    def __init__(self, embeddings, device="cuda:0", dtype=torch.float32, chunk_rows: int = 262144, split=None, exact16: bool = True):
         e = torch.as_tensor(np.asarray(embeddings, dtype=np.float32) if not torch.is_tensor(embeddings) else embeddings)
         self.emb = e.to(device=device, dtype=dtype).contiguous()
         self.ntotal = self.emb.shape[0]
@@ -63,7 +67,7 @@ class FlatIPIndex:
         self.fused_overflows = 0            # searches redone because a candidate list ran over
         # f32 index, values exact in bf16 (a --bf16 encoder run) or in fp16 (--fp16): see above
         self.emb16 = None
-        if self.emb.shape[1] % 64 == 0:
+        if exact16 and self.emb.shape[1] % 64 == 0:                  # (exact16 = False: never take the 16-bit copy, half an index more of HBM)
             self.emb16 = exact_in_16(self.emb, torch.bfloat16)
             if self.emb16 is None:
                 self.emb16 = exact_in_16(self.emb, torch.float16)
